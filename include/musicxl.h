@@ -1,0 +1,122 @@
+/*
+ * libmusicxl -- C ABI of the MI355X-native Transformer-XL / Reformer hot path.
+ *
+ * The reference (StefanHeng/Symbolic-Music-Generation) has no FFI for this path: its boundary is the Python object
+ * contract of `get_model_n_tokenizer` (musicnlp/trainer/train.py:31-59) and the arithmetic sits in HuggingFace
+ * `transformers==4.25.1` (its transfo_xl and reformer model directories).  Each entry point below names the upstream /
+ * reference operation it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless said otherwise; tensors are row-major, batch-major (B, T, ...);
+ *   - bf16 tensors are raw 16-bit words; "f32" means IEEE float;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no allocation) and is
+ *     therefore safe to capture into a hipGraph;
+ *   - return value: 0 ok, negative = argument error (MXL_E*), positive = hipError_t from the launch.
+ */
+#ifndef MUSICXL_H
+#define MUSICXL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXL_ABI_VERSION 1
+
+int mxl_abi_version(void);
+/* human-readable text for a negative libmusicxl code or a positive hipError_t */
+const char* mxl_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM (bf16 in, fp32 accumulate on MFMA).  Replaces F.linear / torch.einsum in upstream qkv_net, r_net, o_net,
+ * CoreNet (PositionwiseFF), crit.out_layers (modeling_transfo_xl.py), and their autograd backward.
+ *   C[M,N] (+)= alpha * op(A) * op(B);  transA=0: A[M][K]  transA=1: A[K][M];  transB=0: B[N][K]  transB=1: B[K][N]
+ *   lda/ldb multiples of 8 elements, base pointers 16-byte aligned, K % 8 == 0 unless both operands are transposed.
+ * flags: output type (default bf16) and fused epilogue.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define MXL_GEMM_OUT_F32        0x01  /* C is f32, plain store                                   */
+#define MXL_GEMM_OUT_F32_ATOMIC 0x02  /* C is f32, atomicAdd (required when ksplits > 1)         */
+#define MXL_GEMM_BIAS           0x04  /* + bias[n]                                               */
+#define MXL_GEMM_RELU           0x08  /* max(.,0)            (CoreNet.1)                         */
+#define MXL_GEMM_DROPOUT        0x10  /* inverted dropout with the (seed, site, m*N+n) keep-mask */
+#define MXL_GEMM_RELU_BWD       0x20  /* C = aux[m][n] > 0 ? acc : 0  (backward through relu+dropout) */
+int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int transA, int transB, int flags, float alpha, const float* bias,
+                  const void* aux, int ldaux, int ksplits,
+                  float drop_p, unsigned long long seed, unsigned site, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Relative-position banded attention (K4).  Replaces RelPartialLearnableMultiHeadAttn.forward between qkv_net and
+ * o_net in upstream modeling_transfo_xl.py (AC/BD einsums, _rel_shift, same_length mask, softmax, P.V), as called
+ * through musicnlp/models/transformer_xl.py:163-171.
+ *   q   : (B, T, H, dh) bf16, element (b,i,h,e) at q + b*q_bs + i*q_rs + h*dh + e   (strides in elements)
+ *   k,v : (B, Kc, H, dh) bf16 with row r = key position p - (T - Kc); T <= Kc <= M + T; positions below are the
+ *         zero mems of upstream init_mems (k = v = 0) and are synthesised, not read
+ *   rd  : (M, H, dh) bf16, rd[d] = r_net(pos_emb(min(d, clamp_len))), d = query position - key position
+ *   r_w_bias, r_r_bias : (H, dh) f32;  out : (B, T, H, dh) bf16;  lse : (B, H, T) f32 (natural log) or NULL
+ *   dh in {16, 32, 64};  scale = 1/sqrt(dh)
+ * ---------------------------------------------------------------------------------------------------------- */
+int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                    const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
+                    long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                    float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * HBM-bound layer pieces.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* upstream PositionalEmbedding + drop(pos_emb): out[dist][0:d/2]=sin, [d/2:d]=cos of min(dist,clamp)*inv_freq; (M,d) bf16 */
+int mxl_sinusoid_table(void* out, int M, int d, int clamp_len, float drop_p, unsigned long long seed, unsigned site,
+                       void* stream);
+/* upstream AdaptiveEmbedding (div_val=1) + drop: out[n] = drop(E[ids[n]] * scale); ids int64, E (V,d) bf16 */
+int mxl_embed_fwd(const void* ids, const void* E, void* out, int N, int d, int V, float scale, float drop_p,
+                  unsigned long long seed, unsigned site, void* stream);
+/* its backward: dE[ids[n]] += keep * scale * dout[n]  (f32 atomics) */
+int mxl_embed_bwd(const void* ids, const void* dout, float* dE, int N, int d, int V, float scale, float drop_p,
+                  unsigned long long seed, unsigned site, void* stream);
+/* y = LayerNorm(res + drop(x)) * gamma + beta  (post-LN of dec_attn / pos_ff); z (pre-norm sum), mean, rstd saved
+ * for the backward (any of z/mean/rstd/res may be NULL).  x,res,y,z (N,d) bf16; d % 8 == 0, d <= 2048 */
+int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z,
+                        float* mean, float* rstd, int N, int d, float eps, float drop_p, unsigned long long seed,
+                        unsigned site, void* stream);
+/* backward of the above for upstream grad dy (+ dy2 if non-NULL): dres = dz, dx = keep*dz/(1-p), dgamma/dbeta += */
+int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                        const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
+                        float drop_p, unsigned long long seed, unsigned site, void* stream);
+/* out[n] += sum_m X[m][n]  (bias gradients), X (M,N) bf16 with leading dimension ld */
+int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream);
+/* upstream TransfoXLModel._update_mems: out[b] = cat(mem[b], hid[b])[-M:], all (B, len, d) bf16, out != mem */
+int mxl_mem_update(const void* mem, const void* hid, void* out, int B, int M, int T, int d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Projected adaptive log-softmax head (K7) = upstream ProjectedAdaptiveLogSoftmax (div_val=1) as used at
+ * musicnlp/models/transformer_xl.py:185,193,198-200.  logits (B*T, ldl) f32 = hidden . [E ; cluster_weight]^T + bias,
+ * columns [0,V) tokens, [V, V+ncl) clusters.  cutoffs_host: ncl ints on the HOST (read at enqueue time).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* transformer_xl.py:176-182 all-ignored guard on label row 0 (in place, device) */
+int mxl_label_guard(void* labels_row0, int T, long long eos, void* stream);
+/* nll (B, T-1) f32 with the shift inside; lse (B*T, 2) f32 scratch kept for backward;
+ * acc2[0] += sum(nll), acc2[1] += count(nll != 0)  (caller zeroes acc2) */
+int mxl_adaptive_nll_fwd(const float* logits, int ldl, const void* labels, float* nll, float* lse, float* acc2, int B,
+                         int T, int V, int ncl, const int* cutoffs_host, void* stream);
+/* dlogits (B*T, ldd) bf16 of loss = sum(nll[nll != 0]) / count, times grad_scale; pad columns zeroed */
+int mxl_adaptive_nll_bwd(const float* logits, int ldl, const void* labels, const float* nll, const float* lse,
+                         const float* acc2, void* dlogits, int ldd, int B, int T, int V, int ncl,
+                         const int* cutoffs_host, float grad_scale, void* stream);
+/* labels=None branch: out (N, ldo) f32 full log-probabilities over the V tokens */
+int mxl_adaptive_logprob(const float* logits, int ldl, float* out, int ldo, int N, int V, int ncl,
+                         const int* cutoffs_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser (K18): torch.optim.AdamW + clip_grad_norm_ as configured at musicnlp/trainer/train.py:165-190.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mxl_sumsq_f32(const float* x, long long n, float* out_accum, void* stream);
+/* p,g,m,v f32 [n]; w16 bf16 working copy (or NULL).  g_eff = g * grad_scale * min(1, max_norm/(sqrt(*sumsq)*grad_scale+1e-6));
+ * decoupled weight decay on elements [0, n_decay) only; step >= 1 */
+int mxl_adamw_step(float* p, const float* g, float* m, float* v, void* w16, long long n, long long n_decay, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
+                   float max_norm, float grad_scale, void* stream);
+int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSICXL_H */

@@ -1,0 +1,67 @@
+// Shared device/host helpers for libmusicxl (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MXL_OK 0
+#define MXL_EINVAL (-1)
+#define MXL_EUNSUPPORTED (-2)
+
+#define MXL_CHECK_ARG(cond) do { if (!(cond)) return MXL_EINVAL; } while (0)
+#define MXL_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;   // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+
+// round-to-nearest-even f32 -> bf16; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t v = {lo, hi};
+    bf2_t r = __builtin_convertvector(v, bf2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based keep-mask for dropout.  Regenerated (not stored) in backward from (seed, site, index).
+// lowbias32-style integer hash: cheap, stateless, identical in forward and backward.
+__device__ __forceinline__ uint32_t mxl_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
+    // thresh = p * 2^32 ; keep iff rnd >= thresh
+    uint32_t h = mxl_hash32((uint32_t)idx ^ mxl_hash32((uint32_t)(idx >> 32) + site * 0x9E3779B9U + (uint32_t)seed));
+    h = mxl_hash32(h + (uint32_t)(seed >> 32));
+    return h >= thresh;
+}
+static inline uint32_t dropout_thresh(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}

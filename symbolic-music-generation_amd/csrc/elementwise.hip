@@ -1,0 +1,318 @@
+// HBM-bound kernels of the TransfoXL path: sinusoid table (K3 input), embedding (K1), residual+LayerNorm (K5/K6
+// epilogue), column sums (bias grads), memory append (K8).  All bf16 traffic is 16-byte vectorised; one wave owns a row.
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// sinusoid table: out[dist][0:d/2] = sin(p*inv_freq), out[dist][d/2:d] = cos(p*inv_freq), p = min(dist, clamp)
+// (upstream PositionalEmbedding; [sin | cos] halves), followed by drop(pos_emb).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void sinusoid_kernel(bf16_t* out, int M, int d, int clamp_len, unsigned thresh, float scale,
+                                unsigned long long seed, unsigned site) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = d >> 1;
+    if (idx >= M * half) return;
+    const int dist = idx / half, k = idx % half;
+    const float p = (float)((clamp_len > 0 && dist > clamp_len) ? clamp_len : dist);
+    // inv_freq_k = 1 / 10000^(2k/d)   (torch: 1 / (10000 ** (arange(0, d, 2) / d)))
+    const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * k) / (float)d);
+    const float a = p * inv_freq;
+    float s = sinf(a), c = cosf(a);
+    if (thresh) {
+        const uint64_t i0 = (uint64_t)dist * d + k, i1 = i0 + half;
+        s = dropout_keep(seed, site, i0, thresh) ? s * scale : 0.f;
+        c = dropout_keep(seed, site, i1, thresh) ? c * scale : 0.f;
+    }
+    out[(size_t)dist * d + k] = f2bf(s);
+    out[(size_t)dist * d + half + k] = f2bf(c);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// embedding: out[n][:] = drop(E[ids[n]][:] * scale)      (AdaptiveEmbedding, div_val = 1)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const long long* ids, const bf16_t* E, bf16_t* out, int N, int d, int V, float scale,
+                                 unsigned thresh, float dscale, unsigned long long seed, unsigned site) {
+    const int chunks = d >> 3;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)N * chunks) return;
+    const int n = (int)(gid / chunks), c = (int)(gid % chunks);
+    long long id = ids[n];
+    if (id < 0 || id >= V) id = 0;  // defensive: never index out of the table
+    const bf16x8 e = *reinterpret_cast<const bf16x8*>(E + (size_t)id * d + c * 8);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v[j] = bf2f((bf16_t)e[j]) * scale;
+        if (thresh) v[j] = dropout_keep(seed, site, (uint64_t)n * d + c * 8 + j, thresh) ? v[j] * dscale : 0.f;
+    }
+    u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(out + (size_t)n * d + c * 8) = o;
+}
+
+// dE[ids[n]][:] += dout[n][:] * scale * keep   (fp32 atomics; rows are 4*d contiguous bytes per wave-instruction)
+__global__ void embed_bwd_kernel(const long long* ids, const bf16_t* dout, float* dE, int N, int d, int V, float scale,
+                                 unsigned thresh, float dscale, unsigned long long seed, unsigned site) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)N * d) return;
+    const int n = (int)(gid / d), k = (int)(gid % d);
+    const long long id = ids[n];
+    if (id < 0 || id >= V) return;
+    float g = bf2f(dout[(size_t)n * d + k]) * scale;
+    if (thresh) g = dropout_keep(seed, site, (uint64_t)n * d + k, thresh) ? g * dscale : 0.f;
+    atomicAdd(dE + (size_t)id * d + k, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// z = res + drop(x);  y = LayerNorm(z) * gamma + beta        (post-LN of dec_attn / pos_ff)
+// one wave per row; row kept in registers (d <= 2048).  Saves z (bf16), mean, rstd for the backward.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> d <= 64*8*4 = 2048
+
+__global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const bf16_t* res, const float* gamma,
+                                                         const float* beta, bf16_t* y, bf16_t* z, float* mean,
+                                                         float* rstd, int N, int d, float eps, unsigned thresh,
+                                                         float dscale, unsigned long long seed, unsigned site) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int chunks = d >> 3;
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * d + c * 8);
+            bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (res) rv = *reinterpret_cast<const bf16x8*>(res + (size_t)row * d + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float a = bf2f((bf16_t)xv[j]);
+                if (thresh) a = dropout_keep(seed, site, (uint64_t)row * d + c * 8 + j, thresh) ? a * dscale : 0.f;
+                a += bf2f((bf16_t)rv[j]);
+                // z is stored in bf16; normalise the *stored* value so forward and backward agree
+                a = bf2f(f2bf(a));
+                v[i][j] = a;
+                s += a;
+            }
+        }
+    }
+    s = wave_sum(s);
+    const float mu = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float t = v[i][j] - mu; q += t * t; }
+        }
+    }
+    q = wave_sum(q);
+    const float rs = rsqrtf(q / (float)d + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
+            u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(y + (size_t)row * d + c * 8) = ov;
+            if (z) {
+                u32x4 zv = {pack2bf(v[i][0], v[i][1]), pack2bf(v[i][2], v[i][3]), pack2bf(v[i][4], v[i][5]),
+                            pack2bf(v[i][6], v[i][7])};
+                *reinterpret_cast<u32x4*>(z + (size_t)row * d + c * 8) = zv;
+            }
+        }
+    }
+}
+
+// backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dres = dz (+ dres_in);  dx = keep*dscale*dz
+// dgamma += sum_rows dy*xhat, dbeta += sum_rows dy : per-block partials through LDS, then one fp32 atomic per column.
+constexpr int LNB_ROWS = 32;  // rows per block (4 waves x 8 rows)
+
+__global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
+                                                         const float* mean, const float* rstd, const float* gamma,
+                                                         bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, int N,
+                                                         int d, unsigned thresh, float dscale, unsigned long long seed,
+                                                         unsigned site) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sg = reinterpret_cast<float*>(smem_raw);  // [d] dgamma partial
+    float* sb = sg + d;                              // [d] dbeta partial
+    for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
+    __syncthreads();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunks = d >> 3;
+    float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+    for (int rr = 0; rr < LNB_ROWS / 4; rr++) {
+        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
+        if (row >= N) break;
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXCH][8], xh[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; i++) {
+            const int c = lane + i * 64;
+            if (c < chunks) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * d + c * 8);
+                bf16x8 dv2 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (dy2) dv2 = *reinterpret_cast<const bf16x8*>(dy2 + (size_t)row * d + c * 8);
+                const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + (size_t)row * d + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float dyv = bf2f((bf16_t)dv[j]) + bf2f((bf16_t)dv2[j]);
+                    const float xhat = (bf2f((bf16_t)zv[j]) - mu) * rs;
+                    const float gg = dyv * gamma[c * 8 + j];
+                    g[i][j] = gg; xh[i][j] = xhat;
+                    s1 += gg; s2 += gg * xhat;
+                    ag[i][j] += dyv * xhat; ab[i][j] += dyv;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; i++) {
+            const int c = lane + i * 64;
+            if (c < chunks) {
+                float o[8], ox[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                    ox[j] = o[j];
+                    if (thresh) ox[j] = dropout_keep(seed, site, (uint64_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
+                }
+                if (dres) {
+                    u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+                    *reinterpret_cast<u32x4*>(dres + (size_t)row * d + c * 8) = ov;
+                }
+                if (dx) {
+                    u32x4 ov = {pack2bf(ox[0], ox[1]), pack2bf(ox[2], ox[3]), pack2bf(ox[4], ox[5]), pack2bf(ox[6], ox[7])};
+                    *reinterpret_cast<u32x4*>(dx + (size_t)row * d + c * 8) = ov;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { atomicAdd(&sg[c * 8 + j], ag[i][j]); atomicAdd(&sb[c * 8 + j], ab[i][j]); }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256) {
+        atomicAdd(dgamma + i, sg[i]);
+        atomicAdd(dbeta + i, sb[i]);
+    }
+}
+
+// out[n] += sum_m X[m][n]   (bias gradients: CoreNet.0/3 bias, crit bias).  bf16 in, fp32 atomic out.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out, int M, int N, int ld, int rows_per_block) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    if (col >= N) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; r++) s += bf2f(X[(size_t)r * ld + col]);
+    atomicAdd(out + col, s);
+}
+
+// new_mem[b] = cat(mem[b], hid[b])[-M:]   (TransfoXLModel._update_mems; batch-major (B, len, d))
+__global__ void mem_update_kernel(const bf16_t* mem, const bf16_t* hid, bf16_t* out, int B, int M, int T, int d) {
+    const int chunks = d >> 3;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * M * chunks) return;
+    const int c = (int)(gid % chunks);
+    const int r = (int)((gid / chunks) % M);
+    const int b = (int)(gid / ((long long)chunks * M));
+    const int src = r + T;  // index into cat(mem, hid) of length M+T, keeping the last M
+    u32x4 v;
+    if (src < M) v = *reinterpret_cast<const u32x4*>(mem + ((size_t)b * M + src) * d + c * 8);
+    else v = *reinterpret_cast<const u32x4*>(hid + ((size_t)b * T + (src - M)) * d + c * 8);
+    *reinterpret_cast<u32x4*>(out + ((size_t)b * M + r) * d + c * 8) = v;
+}
+
+}  // namespace
+
+extern "C" int mxl_sinusoid_table(void* out, int M, int d, int clamp_len, float drop_p, unsigned long long seed,
+                                  unsigned site, void* stream) {
+    MXL_CHECK_ARG(out && M > 0 && d > 0 && (d % 2) == 0);
+    const int n = M * (d / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, M, d,
+                       clamp_len, dropout_thresh(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_embed_fwd(const void* ids, const void* E, void* out, int N, int d, int V, float scale, float drop_p,
+                             unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(ids && E && out && N > 0 && d > 0 && (d % 8) == 0 && V > 0);
+    const long long n = (long long)N * (d / 8);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const bf16_t*)E, (bf16_t*)out, N, d, V, scale, dropout_thresh(drop_p),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_embed_bwd(const void* ids, const void* dout, float* dE, int N, int d, int V, float scale,
+                             float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(ids && dout && dE && N > 0 && d > 0 && V > 0);
+    const long long n = (long long)N * d;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const bf16_t*)dout, dE, N, d, V, scale, dropout_thresh(drop_p),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                                   void* z, float* mean, float* rstd, int N, int d, float eps, float drop_p,
+                                   unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(x && gamma && beta && y && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    hipLaunchKernelGGL(ln_res_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)res, gamma, beta, (bf16_t*)y, (bf16_t*)z, mean, rstd, N, d, eps,
+                       dropout_thresh(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                   const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
+                                   float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    hipLaunchKernelGGL(ln_res_bwd_kernel, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
+                       (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream) {
+    MXL_CHECK_ARG(X && out && M > 0 && N > 0 && ld >= N);
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X, out, M, N, ld, rpb);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_mem_update(const void* mem, const void* hid, void* out, int B, int M, int T, int d, void* stream) {
+    MXL_CHECK_ARG(mem && hid && out && B > 0 && M > 0 && T > 0 && (d % 8) == 0 && out != mem);
+    const long long n = (long long)B * M * (d / 8);
+    hipLaunchKernelGGL(mem_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)mem, (const bf16_t*)hid, (bf16_t*)out, B, M, T, d);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

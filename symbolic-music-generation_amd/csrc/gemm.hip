@@ -1,0 +1,275 @@
+// bf16 MFMA GEMM for the TransfoXL / Reformer linear layers (K2, K3, K5, K6, K7 of SURVEY.md 2.3).
+//
+//   C[M,N] (+)= alpha * op(A)[M,K] * op(B)[K,N]      fp32 accumulate on v_mfma_f32_16x16x32_bf16
+//
+// Operand storage (row-major):
+//   transA = 0 : A is [M][K] (K contiguous)      transA = 1 : A is [K][M] (M contiguous)
+//   transB = 0 : B is [N][K] (K contiguous, i.e. a torch Linear weight)   transB = 1 : B is [K][N]
+// so   y  = x W^T      -> (0,0)     replaces F.linear in upstream qkv_net/o_net/r_net/CoreNet/out_layers
+//      dx = dy W       -> (0,1)
+//      dW = dy^T x     -> (1,1)     (contraction over tokens; split-K + fp32 atomics)
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 fragments of 16x16.
+// global -> registers -> LDS (XOR-swizzled images), LDS double-buffered, one barrier per K-tile.
+// K-contiguous operands are read with ds_read_b128, K-strided ones with ds_read_b64_tr_b16.
+// The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4 consecutive n of one m (8-byte stores).
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+struct GemmP {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    int ksplit;            // K elements per grid.z slice (multiple of BK)
+    const float* bias;     // [N] or null
+    const bf16_t* aux;     // relu-backward mask source [M][ldaux] or null
+    int ldaux;
+    float alpha;
+    int flags;
+    unsigned long long seed; unsigned site; unsigned thresh; float drop_scale;
+    int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+__device__ __forceinline__ int swzT(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <bool T>
+__device__ __forceinline__ void g2r(const bf16_t* __restrict__ X, int ld, int R, int kend, int r0, int k0, u32x4 (&v)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = t + i * 256;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (!T) {
+            const int row = c >> 3, kc = c & 7;
+            const int gr = r0 + row, gk = k0 + kc * 8;
+            const bool ok = (gr < R) && (gk < kend);
+            v[i] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)gr * ld + gk) : z;
+        } else {
+            const int kr = c >> 4, rc = c & 15;
+            const int gk = k0 + kr, gr = r0 + rc * 8;
+            const bool ok = (gk < kend) && (gr < R);
+            v[i] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)gk * ld + gr) : z;
+        }
+    }
+}
+
+template <bool T>
+__device__ __forceinline__ void r2s(char* base, const u32x4 (&v)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = t + i * 256;
+        int off;
+        if (!T) {
+            const int row = c >> 3, kc = c & 7;
+            off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int kr = c >> 4, rc = c & 15;
+            off = kr * 256 + (((rc >> 1) ^ swzT(kr)) << 5) + ((rc & 1) << 4);
+        }
+        *reinterpret_cast<u32x4*>(base + off) = v[i];
+    }
+}
+
+// fragment for 16 rows [rb, rb+16) of the tile, k-step ks (32 k's): lane l holds row rb+(l&15), k = 8*(l>>4)+j
+template <bool T>
+__device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
+    const int l = threadIdx.x & 63;
+    const int g = l >> 4, li = l & 15;
+    if (!T) {
+        const int row = rb + li;
+        const int chunk = ks * 4 + g;
+        return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    } else {
+        const int q = li >> 2, pp = li & 3;
+        const int krow = ks * 32 + 8 * g + q;
+        const int col = rb + 4 * pp;
+        const int off = krow * 256 + (((col >> 4) ^ swzT(krow)) << 5) + ((col & 15) << 1);
+        const lds_bf16x4* p0 = (const lds_bf16x4*)(base + off);
+        const lds_bf16x4* p1 = (const lds_bf16x4*)(base + off + 4 * 256);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p1);
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware remap: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles so
+    // neighbouring tiles (same A row panel) hit the same L2.  Bijective for any grid size.
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int wid = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    g2r<AT>(p.A, p.lda, p.M, kend, m0, kbeg, ra);
+    g2r<BT>(p.B, p.ldb, p.N, kend, n0, kbeg, rb);
+    r2s<AT>(smem, ra);
+    r2s<BT>(smem + TILE_BYTES, rb);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            g2r<AT>(p.A, p.lda, p.M, kend, m0, kbeg + (kt + 1) * BK, ra);
+            g2r<BT>(p.B, p.ldb, p.N, kend, n0, kbeg + (kt + 1) * BK, rb);
+        }
+        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fa[i] = ldfrag<AT>(sa, wr * 64 + i * 16, ks);
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = ldfrag<BT>(sb, wc * 64 + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(mfma_bf16x8, fb[j]), __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* da = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            r2s<AT>(da, ra);
+            r2s<BT>(da + TILE_BYTES, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue.  acc[i][j][r]: m = m0 + wr*64 + i*16 + (l&15), n = n0 + wc*64 + j*16 + (l>>4)*4 + r
+    const int flags = p.flags;
+    const int mrow_l = l & 15, nq = (l >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + wr * 64 + i * 16 + mrow_l;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wc * 64 + j * 16 + nq;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] * p.alpha;
+            const bool full = (n + 3 < p.N);
+            if (flags & MXL_GEMM_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if (flags & MXL_GEMM_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (flags & MXL_GEMM_DROPOUT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool keep = dropout_keep(p.seed, p.site, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), p.thresh);
+                    v[r] = keep ? v[r] * p.drop_scale : 0.f;
+                }
+            }
+            if (flags & MXL_GEMM_RELU_BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (n + r < p.N) {
+                        const float a = bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                        v[r] = a > 0.f ? v[r] : 0.f;
+                    }
+            }
+            if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (n + r < p.N) atomicAdd(c + r, v[r]);
+            } else if (flags & MXL_GEMM_OUT_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (full && ((p.ldc & 3) == 0)) {
+                    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = v[r];
+                }
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+                if (full && ((p.ldc & 3) == 0)) {
+                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(c) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int transA, int transB, int flags, float alpha, const float* bias,
+                             const void* aux, int ldaux, int ksplits,
+                             float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+    MXL_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0);
+    MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
+    // K-contiguous operands are fetched in 8-element chunks along K: K must be chunk-exact.
+    if (!transA || !transB) MXL_CHECK_ARG((K % 8) == 0);
+    MXL_CHECK_ARG(transA ? lda >= ((M + 7) & ~7) : lda >= K);
+    MXL_CHECK_ARG(transB ? ldb >= ((N + 7) & ~7) : ldb >= K);
+    MXL_CHECK_ARG(ldc >= N);
+    if (flags & MXL_GEMM_BIAS) MXL_CHECK_ARG(bias != nullptr);
+    if (flags & MXL_GEMM_RELU_BWD) MXL_CHECK_ARG(aux != nullptr && ldaux >= N);
+    if (ksplits < 1) ksplits = 1;
+    if (ksplits > 1) {
+        MXL_CHECK_ARG(flags & MXL_GEMM_OUT_F32_ATOMIC);
+        MXL_CHECK_ARG(!(flags & (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_RELU_BWD)));
+    }
+    GemmP p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    int ktiles = (K + BK - 1) / BK;
+    int per = (ktiles + ksplits - 1) / ksplits;
+    ksplits = (ktiles + per - 1) / per;
+    p.ksplit = per * BK;
+    p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.alpha = alpha; p.flags = flags;
+    p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
+    p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, ksplits), block(256);
+    const size_t shm = 4 * TILE_BYTES;
+    hipStream_t s = (hipStream_t)stream;
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, shm, s, p);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, shm, s, p);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, shm, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, shm, s, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

@@ -1,0 +1,382 @@
+// K4 forward: Transformer-XL relative-position attention, band-only, flash-style (never materialises (T, K)).
+// Replaces upstream RelPartialLearnableMultiHeadAttn.forward between qkv_net and o_net:
+//
+//   score[i,p] = ((q_i + r_w_bias) . k_p  +  (q_i + r_r_bias) . Rd[i - p]) / sqrt(dh)      p = key position
+//   visible    : 0 <= i - p <= M-1           (same_length=True with mlen == mem_len: exactly M keys per query)
+//   out_i      = softmax_p(score[i,:]) . v
+//
+// Key positions: current tokens p = 0..T-1, memory p = -M..-1.  The caller supplies Kc >= T rows of K/V covering
+// p in [T-Kc, T); positions below that are the zero mems upstream `init_mems` fabricates (k = v = 0 exactly, qkv_net
+// has no bias): they add exp(BD) to the softmax denominator and nothing else -- reproduced here by feeding zeros.
+// Rd[d] = r_net(pos_emb(min(d, clamp_len))) for d = 0..M-1 (the rel-shift folded into the index).
+//
+// Layout per workgroup (256 threads = 4 waves): 128 queries, wave w owns 32.  "Swapped" products: S^T = K.Qw^T and
+// G^T = Rd.Qr^T on v_mfma_f32_32x32x16_bf16, so a lane owns ONE query (column) and the softmax row reductions are
+// lane-local.  The rel-shift (BD[i,p] = G[i, i-p]) is a lane-private LDS round trip: lane writes its column of G^T as a
+// row [query][distance & 127] and reads it back at distance i - p.  P stays in registers and feeds O^T += V^T.P^T directly
+// (accumulator-as-operand, V^T fragments via ds_read_b64_tr_b16).
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct RelAttnP {
+    const bf16_t *q, *k, *v, *rd;
+    const float *rwb, *rrb;
+    bf16_t* out;
+    float* lse;
+    int B, T, H, M, Kc;
+    long long q_bs, kv_bs, o_bs;
+    int q_rs, kv_rs, rd_rs, o_rs;
+    float scale_log2e;
+};
+
+constexpr int QB = 128;      // queries per workgroup
+constexpr int KT = 64;       // keys per tile
+constexpr int GRS = 132;     // skew-buffer row stride in floats (even -> conflict-free skewed reads; %4 -> b128 writes)
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+template <int DH> struct Geo {
+    static constexpr int KS = DH / 16;
+    static constexpr int EB = (DH + 31) / 32;
+    static constexpr int VW = EB * 32;
+    static constexpr int ROWB = DH * 2;
+    static constexpr int VROWB = VW * 2;
+    static constexpr int CH = DH / 8;                   // 16-byte chunks per K / Rd row
+    static constexpr int VCH = VW / 8;
+    static constexpr int K_BYTES = KT * ROWB;
+    static constexpr int V_BYTES = KT * VROWB;
+    static constexpr int R_BYTES = 256 * ROWB;
+    static constexpr int G_BYTES = 4 * 32 * GRS * 4;
+    static constexpr int SMEM = 2 * K_BYTES + 2 * V_BYTES + R_BYTES + G_BYTES;
+    static constexpr int NLD_K = (KT * CH + 255) / 256;  // 16-byte chunks per thread per tile
+    static constexpr int NLD_V = (KT * CH + 255) / 256;
+    __device__ static __forceinline__ int koff(int row, int ch) {  // K / Rd image: [row][DH], XOR swizzle for 128-B rows
+        if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        return row * ROWB + (ch << 4);
+    }
+    __device__ static __forceinline__ int voff(int row, int byte) {  // V image: [key][VW]
+        if (DH == 64) return row * VROWB + (byte ^ (((row >> 1) & 1) << 6));
+        return row * VROWB + byte;
+    }
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
+    using G = Geo<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                          // [2][64][DH]
+    char* sV = sK + 2 * G::K_BYTES;           // [2][64][VW]
+    char* sR = sV + 2 * G::V_BYTES;           // ring [256][DH]
+    float* sG = reinterpret_cast<float*>(sR + G::R_BYTES);  // [4][32][GRS]
+
+    const int tid = threadIdx.x;
+    const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * QB;
+    const int iw0 = i0 + 32 * wid;
+    const int T = p.T, M = p.M;
+    const int p0 = T - p.Kc;  // lowest stored key position
+    float* myG = sG + wid * 32 * GRS + r * GRS;
+
+    const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* rbase = p.rd + (size_t)h * DH;
+
+    // ---- Q fragments (B operand: lane = query r, k = 16ks + 8hh + j), biases added in fp32
+    bf16x8 qw[KS], qr[KS];
+    {
+        const int i = iw0 + r;
+        const bool ok = i < T;
+        const bf16_t* qp = p.q + (size_t)b * p.q_bs + (size_t)(ok ? i : 0) * p.q_rs + (size_t)h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int e0 = 16 * ks + 8 * hh;
+            bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + e0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float qf = ok ? bf2f((bf16_t)qv[j]) : 0.f;
+                qw[ks][j] = (short)f2bf(qf + p.rwb[h * DH + e0 + j]);
+                qr[ks][j] = (short)f2bf(qf + p.rrb[h * DH + e0 + j]);
+            }
+        }
+    }
+
+    const int p_lo = i0 - M + 1;
+    const int p_hi = min(i0 + QB - 1, T - 1);
+    const int kt_lo = floordiv(p_lo, KT), kt_hi = floordiv(p_hi, KT);
+
+    // ---- staging helpers -----------------------------------------------------------------------------------
+    u32x4 rk[G::NLD_K], rv[G::NLD_V], rr[G::NLD_K];
+    auto load_kv = [&](int kt) {
+        const int P = kt * KT;
+#pragma unroll
+        for (int n = 0; n < G::NLD_K; n++) {
+            const int c = tid + n * 256;
+            const int row = c / G::CH, ch = c % G::CH;
+            const int srow = P + row - p0;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            const bool ok = (c < KT * G::CH) && (srow >= 0) && (srow < p.Kc);
+            rk[n] = ok ? *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+            rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < G::NLD_K; n++) {
+            const int c = tid + n * 256;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = rk[n];
+                *reinterpret_cast<u32x4*>(sV + buf * G::V_BYTES + G::voff(row, ch * 16)) = rv[n];
+            }
+        }
+    };
+    // 64 Rd rows d in [dbase, dbase+64) -> registers / ring slots (d & 255); row index clamped (masked anyway)
+    auto load_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < G::NLD_K; n++) {
+            const int c = tid + n * 256;
+            const int row = c / G::CH, ch = c % G::CH;
+            int d = dbase + row;
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rr[n] = (c < KT * G::CH) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8) : z;
+        }
+    };
+    auto store_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < G::NLD_K; n++) {
+            const int c = tid + n * 256;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                const int slot = (dbase + row) & 255;
+                *reinterpret_cast<u32x4*>(sR + G::koff(slot, ch)) = rr[n];
+            }
+        }
+    };
+
+    // zero the V pad columns once (DH < 32): tr-reads of O^T rows >= DH must see zeros
+    if (DH < G::VW) {
+        for (int i = tid; i < 2 * G::V_BYTES / 4; i += 256) reinterpret_cast<uint32_t*>(sV)[i] = 0u;
+        __syncthreads();
+    }
+
+    // ---- prologue: first tile + its distance window [i0-P0-64, i0-P0+127] (wave w: dlo_w = i0+32w-P0-64, 96 rows)
+    {
+        const int P0 = kt_lo * KT;
+        load_kv(kt_lo);
+        store_kv(0);
+#pragma unroll 1
+        for (int q4 = 0; q4 < 3; q4++) {
+            const int dbase = i0 - P0 - 64 + 64 * q4;
+            load_r(dbase);
+            store_r(dbase);
+        }
+    }
+    __syncthreads();
+
+    f32x16 o[EB];
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    bool have_ring = false;
+    int cur = 0;
+
+#pragma unroll 1
+    for (int kt = kt_lo; kt <= kt_hi; kt++) {
+        const int P = kt * KT;
+        const bool more = kt < kt_hi;
+        if (more) {
+            load_kv(kt + 1);
+            load_r(i0 - (P + KT) - 64);   // next step's 64 new (lowest) distances
+        }
+        const int dmin_w = iw0 - P - (KT - 1), dmax_w = iw0 + 31 - P;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);
+        if (active) {
+            const char* cK = sK + cur * G::K_BYTES;
+            const char* cV = sV + cur * G::V_BYTES;
+            const int dlo = iw0 - P - 64;
+            // ---- S^T = K . Qw^T : two 32-key blocks
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) s[kb][j] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
+                }
+            }
+            // ---- G^T = Rd . Qr^T for the new distance blocks, written to the lane-private skew ring
+            const int nb = have_ring ? 2 : 3;
+#pragma unroll 1
+            for (int gb = 0; gb < nb; gb++) {
+                f32x16 g;
+#pragma unroll
+                for (int j = 0; j < 16; j++) g[j] = 0.f;
+                const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const int d = dlo + 32 * gb + 8 * grp + 4 * hh;
+                    *reinterpret_cast<f32x4*>(myG + (d & 127)) = f32x4{g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                }
+            }
+            have_ring = true;
+            // ---- scores: (AC + BD) * scale, band mask, online softmax (lane = query)
+            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T);
+            const int qi = iw0 + r;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const int d = qi - P - jj;
+                    const float bd = myG[d & 127];
+                    float val = (s[kb][j] + bd) * p.scale_log2e;
+                    if (!full) {
+                        const bool valid = (d >= 0) && (d <= M - 1) && (qi < T);
+                        val = valid ? val : NEG_BIG;
+                    }
+                    s[kb][j] = val;
+                    mx = fmaxf(mx, val);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    float pv = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
+                    pv = (s[kb][j] > 0.5f * NEG_BIG) ? pv : 0.f;
+                    s[kb][j] = pv;
+                    rs += pv;
+                }
+            }
+            l_run = l_run * alpha + rs;
+#pragma unroll
+            for (int e = 0; e < EB; e++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) o[e][j] *= alpha;
+            // ---- O^T += V^T . P^T
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const uint32_t w = pack2bf(s[kb][8 * st + j], s[kb][8 * st + j + 1]);
+                        pf[j] = (short)(w & 0xffff);
+                        pf[j + 1] = (short)(w >> 16);
+                    }
+                    const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+#pragma unroll
+                    for (int e = 0; e < EB; e++) {
+                        const int key = 32 * kb + 16 * st + 4 * hh + q4;
+                        const int byte = (32 * e + 16 * (gq & 1) + 4 * pp) * 2;
+                        const lds_bf16x4* a0 = (const lds_bf16x4*)(cV + G::voff(key, byte));
+                        const lds_bf16x4* a1 = (const lds_bf16x4*)(cV + G::voff(key + 8, byte));
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)a0);
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)a1);
+                        const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                       __builtin_bit_cast(mfma_bf16x8, pf), o[e], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) {
+            store_kv(cur ^ 1);
+            store_r(i0 - (P + KT) - 64);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: normalise, store O (lane = query, 4 consecutive e per register group) and LSE
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int qi = iw0 + r;
+    if (qi < T) {
+        bf16_t* op = p.out + (size_t)b * p.o_bs + (size_t)qi * p.o_rs + (size_t)h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    u32x2 w = {pack2bf(o[e][4 * grp] * inv, o[e][4 * grp + 1] * inv),
+                               pack2bf(o[e][4 * grp + 2] * inv, o[e][4 * grp + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(op + e0) = w;
+                }
+            }
+        }
+        if (hh == 0 && p.lse)
+            p.lse[((size_t)b * p.H + h) * T + qi] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+template <int DH>
+int launch_fwd(const RelAttnP& p, hipStream_t s) {
+    using G = Geo<DH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_fwd_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((p.T + QB - 1) / QB, p.H, p.B);
+    hipLaunchKernelGGL((relattn_fwd_kernel<DH>), grid, dim3(256), G::SMEM, s, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+}  // namespace
+
+extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
+                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                               float scale, void* stream) {
+    MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
+    MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
+    MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
+    MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 4) == 0);
+    MXL_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                  ((uintptr_t)rd % 16) == 0 && ((uintptr_t)out % 8) == 0);
+    RelAttnP p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.rd = (const bf16_t*)rd;
+    p.rwb = r_w_bias; p.rrb = r_r_bias; p.out = (bf16_t*)out; p.lse = lse;
+    p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
+    p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 16: return launch_fwd<16>(p, s);
+        case 32: return launch_fwd<32>(p, s);
+        case 64: return launch_fwd<64>(p, s);
+        default: return MXL_EUNSUPPORTED;
+    }
+}

@@ -1,0 +1,175 @@
+"""Thin torch-tensor front-ends over the C ABI (include/musicxl.h).
+
+torch is used only for device memory and the current HIP stream; every function here enqueues hand-written HIP kernels
+from libmusicxl.so and raises if the library is missing or a launch fails.  No CPU / eager fallbacks.
+"""
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from ._lib import lib, check, MusicXLError
+
+GEMM_OUT_F32 = 0x01
+GEMM_OUT_F32_ATOMIC = 0x02
+GEMM_BIAS = 0x04
+GEMM_RELU = 0x08
+GEMM_DROPOUT = 0x10
+GEMM_RELU_BWD = 0x20
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise MusicXLError(f'{name}: expected a device tensor (the HIP path has no CPU fallback)')
+    if t.dtype != dtype:
+        raise MusicXLError(f'{name}: expected {dtype}, got {t.dtype}')
+
+
+def _cut(cutoffs: Sequence[int]):
+    n = len(cutoffs)
+    arr = (C.c_int * max(n, 1))(*cutoffs) if n else None
+    return n, arr
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,
+         flags=0, alpha=1.0, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, ksplits=1,
+         lda=None, ldb=None, ldc=None, ldaux=None, drop_p=0.0, seed=0, site=0):
+    """C[M,N] (+)= alpha * op(A) op(B); see mxl_gemm_bf16.  Leading dimensions default to the last-dim stride."""
+    _req(a, torch.bfloat16, 'A'); _req(b, torch.bfloat16, 'B')
+    lda = lda if lda is not None else a.stride(-2)
+    ldb = ldb if ldb is not None else b.stride(-2)
+    ldc = ldc if ldc is not None else c.stride(-2)
+    if aux is not None and ldaux is None:
+        ldaux = aux.stride(-2)
+    check(lib().mxl_gemm_bf16(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,
+                              float(alpha), _p(bias), _p(aux), ldaux or 0, ksplits, float(drop_p), seed, site,
+                              _stream()), 'mxl_gemm_bf16')
+    return c
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, relu=False, out=None,
+           out_f32=False, drop_p=0.0, seed=0, site=0) -> torch.Tensor:
+    """y = x @ w.T (+bias)(relu)(dropout); x (N, K) bf16, w (O, K) bf16."""
+    N, K = x.shape
+    O = w.shape[0]
+    if out is None:
+        out = torch.empty(N, O, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    flags = (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_BIAS if bias is not None else 0) | (GEMM_RELU if relu else 0)
+    if drop_p > 0:
+        flags |= GEMM_DROPOUT
+    return gemm(x, w, out, N, O, K, flags=flags, bias=bias, drop_p=drop_p, seed=seed, site=site)
+
+
+def sinusoid_table(M: int, d: int, clamp_len: int, device, drop_p=0.0, seed=0, site=0, out=None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(M, d, device=device, dtype=torch.bfloat16)
+    check(lib().mxl_sinusoid_table(_p(out), M, d, clamp_len, float(drop_p), seed, site, _stream()), 'mxl_sinusoid_table')
+    return out
+
+
+def embed_fwd(ids: torch.Tensor, E: torch.Tensor, out: torch.Tensor, scale: float, drop_p=0.0, seed=0, site=0):
+    _req(ids, torch.int64, 'ids'); _req(E, torch.bfloat16, 'E')
+    N, d = ids.numel(), E.shape[1]
+    check(lib().mxl_embed_fwd(_p(ids), _p(E), _p(out), N, d, E.shape[0], float(scale), float(drop_p), seed, site,
+                              _stream()), 'mxl_embed_fwd')
+    return out
+
+
+def embed_bwd(ids: torch.Tensor, dout: torch.Tensor, dE: torch.Tensor, scale: float, drop_p=0.0, seed=0, site=0):
+    _req(ids, torch.int64, 'ids'); _req(dout, torch.bfloat16, 'dout'); _req(dE, torch.float32, 'dE')
+    N, d = ids.numel(), dE.shape[1]
+    check(lib().mxl_embed_bwd(_p(ids), _p(dout), _p(dE), N, d, dE.shape[0], float(scale), float(drop_p), seed, site,
+                              _stream()), 'mxl_embed_bwd')
+    return dE
+
+
+def ln_residual_fwd(x, res, gamma, beta, y, z=None, mean=None, rstd=None, eps=1e-5, drop_p=0.0, seed=0, site=0):
+    _req(x, torch.bfloat16, 'x'); _req(gamma, torch.float32, 'gamma'); _req(beta, torch.float32, 'beta')
+    d = x.shape[-1]
+    N = x.numel() // d
+    check(lib().mxl_ln_residual_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(z), _p(mean), _p(rstd), N, d,
+                                    float(eps), float(drop_p), seed, site, _stream()), 'mxl_ln_residual_fwd')
+    return y
+
+
+def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, drop_p=0.0, seed=0, site=0):
+    d = z.shape[-1]
+    N = z.numel() // d
+    check(lib().mxl_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx),
+                                    _p(dgamma), _p(dbeta), N, d, float(drop_p), seed, site, _stream()),
+          'mxl_ln_residual_bwd')
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int] = None):
+    check(lib().mxl_colsum_bf16(_p(x), _p(out), M, N, ld if ld is not None else x.stride(-2), _stream()), 'mxl_colsum_bf16')
+    return out
+
+
+def mem_update(mem, hid, out):
+    B, M, d = mem.shape
+    T = hid.shape[1]
+    check(lib().mxl_mem_update(_p(mem), _p(hid), _p(out), B, M, T, d, _stream()), 'mxl_mem_update')
+    return out
+
+
+def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,
+                o_bs, o_rs, scale=None):
+    """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements."""
+    scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    check(lib().mxl_relattn_fwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), B, T, H, dh,
+                                M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale), _stream()),
+          'mxl_relattn_fwd')
+    return out
+
+
+def label_guard(labels: torch.Tensor, eos: int):
+    _req(labels, torch.int64, 'labels')
+    check(lib().mxl_label_guard(_p(labels), labels.shape[1], int(eos), _stream()), 'mxl_label_guard')
+
+
+def adaptive_nll_fwd(logits, labels, nll, lse, acc2, B, T, V, cutoffs=()):
+    n, arr = _cut(cutoffs)
+    check(lib().mxl_adaptive_nll_fwd(_p(logits), logits.stride(0), _p(labels), _p(nll), _p(lse), _p(acc2), B, T, V, n,
+                                     C.cast(arr, C.c_void_p) if arr is not None else None, _stream()),
+          'mxl_adaptive_nll_fwd')
+
+
+def adaptive_nll_bwd(logits, labels, nll, lse, acc2, dlogits, B, T, V, cutoffs=(), grad_scale=1.0):
+    n, arr = _cut(cutoffs)
+    check(lib().mxl_adaptive_nll_bwd(_p(logits), logits.stride(0), _p(labels), _p(nll), _p(lse), _p(acc2), _p(dlogits),
+                                     dlogits.stride(0), B, T, V, n,
+                                     C.cast(arr, C.c_void_p) if arr is not None else None, float(grad_scale), _stream()),
+          'mxl_adaptive_nll_bwd')
+
+
+def adaptive_logprob(logits, out, N, V, cutoffs=()):
+    n, arr = _cut(cutoffs)
+    check(lib().mxl_adaptive_logprob(_p(logits), logits.stride(0), _p(out), out.stride(0), N, V, n,
+                                     C.cast(arr, C.c_void_p) if arr is not None else None, _stream()),
+          'mxl_adaptive_logprob')
+    return out
+
+
+def sumsq(x: torch.Tensor, out_accum: torch.Tensor):
+    check(lib().mxl_sumsq_f32(_p(x), x.numel(), _p(out_accum), _stream()), 'mxl_sumsq_f32')
+
+
+def adamw_step(p, g, m, v, w16, n_decay, lr, beta1, beta2, eps, weight_decay, step, sumsq_buf=None, max_norm=0.0,
+               grad_scale=1.0):
+    check(lib().mxl_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(w16), p.numel(), n_decay, float(lr), float(beta1),
+                               float(beta2), float(eps), float(weight_decay), int(step), _p(sumsq_buf), float(max_norm),
+                               float(grad_scale), _stream()), 'mxl_adamw_step')
+
+
+def cast_bf16(x: torch.Tensor, y: torch.Tensor):
+    check(lib().mxl_cast_f32_bf16(_p(x), _p(y), x.numel(), _stream()), 'mxl_cast_f32_bf16')
+    return y

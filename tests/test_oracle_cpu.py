@@ -1,0 +1,96 @@
+"""CPU tests of the oracle itself: structural known-answers the reference leaves."""
+import torch
+
+from oracle.transfoxl_ref import (RefXLConfig, RefTransfoXLLMHeadModel, RelPartialLearnableMultiHeadAttn,
+                                  count_parameters, cutoffs_for_vocab)
+from oracle.relattn_ref import relattn_dense
+
+
+def test_param_count_kat():
+    # notebook/train/transformer-xl.ipynb:491 logs 92.4 M for base @ V=418
+    c = RefXLConfig.from_preset('base', vocab_size=418)
+    assert c.cutoffs == [] and c.mem_len == 256 and c.clamp_len == 1024 and c.d_inner == 3072
+    assert count_parameters(RefTransfoXLLMHeadModel(c)) == 92_435_362
+
+
+def test_cutoff_policy():
+    assert cutoffs_for_vocab(418) == [] and cutoffs_for_vocab(1190) == [1000]
+    assert cutoffs_for_vocab(16384) == [5000] and cutoffs_for_vocab(32768) == [10000]
+    assert cutoffs_for_vocab(262144) == [20000, 40000, 200000]
+
+
+def _tiny(**kw):
+    torch.manual_seed(0)
+    kw = dict(dict(vocab_size=97, n_layer=2, mem_len=24, clamp_len=16, cutoffs=[], dropout=0.0), **kw)
+    return RefTransfoXLLMHeadModel(RefXLConfig.from_preset('debug', **kw)).eval()
+
+
+def test_segmentation_invariance():
+    m = _tiny()
+    ids = torch.randint(0, 97, (2, 40))
+    full = m(ids).prediction_scores
+    mems, outs = None, []
+    for s in range(0, 40, 8):
+        o = m(ids[:, s:s + 8], mems=mems)
+        mems = o.mems
+        outs.append(o.prediction_scores)
+    assert torch.allclose(full, torch.cat(outs, 1), atol=2e-5)
+    mems, outs = None, []
+    for s in range(40):
+        o = m(ids[:, s:s + 1], mems=mems)
+        mems = o.mems
+        outs.append(o.prediction_scores)
+    assert torch.allclose(full, torch.cat(outs, 1), atol=2e-5)
+
+
+def test_logprobs_normalised_and_adaptive_consistent():
+    m = _tiny(vocab_size=130, cutoffs=[100])
+    ids = torch.randint(0, 130, (2, 12))
+    lp = m(ids).prediction_scores
+    assert torch.allclose(lp.exp().sum(-1), torch.ones(2, 12), atol=1e-4)
+    lab = ids.clone()
+    lab[1, 6:] = -100
+    o = m(ids, labels=lab)
+    # per-token NLL (cluster order) must equal -logprob[label] as a multiset; loss = mean over non-zero
+    want = -lp[:, :-1].gather(2, lab[:, 1:].clamp(min=0)[..., None])[..., 0][lab[:, 1:] != -100]
+    got = o.losses[o.losses != 0]
+    assert torch.allclose(got.sort().values, want.sort().values, atol=1e-4)
+    assert torch.allclose(o.loss, want.mean(), atol=1e-5)
+
+
+def test_rel_shift_identity_and_window():
+    """position-coordinate dense form == upstream einsum + pad/view rel-shift + same_length mask."""
+    torch.manual_seed(1)
+    H, dh, d, M, T, B = 2, 8, 16, 12, 20, 2
+    att = RelPartialLearnableMultiHeadAttn(H, d, dh, 0.0, 0.0, 1e-5).eval()
+    for p_ in att.parameters():
+        torch.nn.init.normal_(p_, 0, 0.3)
+    w = torch.randn(T, B, d)
+    mems = torch.randn(M, B, d)
+    klen = M + T
+    pos_seq = torch.arange(klen - 1, -1, -1.0).clamp(max=7)
+    inv_freq = 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d))
+    sin_inp = torch.outer(pos_seq, inv_freq)
+    pos_emb = torch.cat([sin_inp.sin(), sin_inp.cos()], -1)[:, None, :]
+    ones = torch.ones(T, klen, dtype=torch.uint8)
+    mask = (torch.triu(ones, 1 + M) + torch.tril(ones, 0))[:, :, None]  # mlen == mem_len -> shift 0
+    with torch.no_grad():
+        ref = att(w, pos_emb, mask, mems)  # LN(w + o_net(attn_vec))
+        heads = att.qkv_net(torch.cat([mems, w], 0))
+        q, k, v = heads.chunk(3, -1)
+        q = q[-T:].view(T, B, H, dh).transpose(0, 1)
+        k = k.view(klen, B, H, dh).transpose(0, 1)
+        v = v.view(klen, B, H, dh).transpose(0, 1)
+        dist = torch.arange(0, M).float().clamp(max=7)
+        sin_d = torch.outer(dist, inv_freq)
+        rd = att.r_net(torch.cat([sin_d.sin(), sin_d.cos()], -1)).view(M, H, dh)
+        out, _ = relattn_dense(q, k, v, rd, att.r_w_bias, att.r_r_bias, M)
+        mine = att.layer_norm(w + att.o_net(out.transpose(0, 1).reshape(T, B, H * dh)))
+    assert torch.allclose(ref, mine, atol=1e-5)
+    # zero mems (init_mems): dropping the stored memory rows must give the same answer as explicit zeros
+    with torch.no_grad():
+        zk = k.clone(); zk[:, :M] = 0
+        zv = v.clone(); zv[:, :M] = 0
+        a, la = relattn_dense(q, zk, zv, rd, att.r_w_bias, att.r_r_bias, M)
+        b_, lb = relattn_dense(q, zk[:, M:], zv[:, M:], rd, att.r_w_bias, att.r_r_bias, M)
+    assert torch.allclose(a, b_, atol=1e-6) and torch.allclose(la, lb, atol=1e-6)
