@@ -44,6 +44,12 @@ int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                   const void* aux, int ldaux, int ksplits,
                   float drop_p, unsigned long long seed, unsigned site, void* stream);
 
+/* same kernel, grid.y = batch: operand element offsets (by / bdiv) * s?1 + (by % bdiv) * s?2 */
+int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                          int transA, int transB, int flags, float alpha, int ksplits, int batch, int bdiv,
+                          long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Relative-position banded attention (K4).  Replaces RelPartialLearnableMultiHeadAttn.forward between qkv_net and
  * o_net in upstream modeling_transfo_xl.py (AC/BD einsums, _rel_shift, same_length mask, softmax, P.V), as called
@@ -58,6 +64,18 @@ int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
 int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                     const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
                     long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                    float scale, void* stream);
+
+/* Backward of mxl_relattn_fwd (autograd of the upstream attention core).  out/dout share the (o_bs, o_rs) layout.
+ *   delta : (B,H,T) f32 scratch (written);  dq (B,T,H,dh) / dk, dv (B,Kc,H,dh) bf16 with their own strides (written);
+ *   dg    : (B,H,T,M) bf16, un-skewed score gradient dG[b,h,i,d] = dSr[i, i-d] (written; may be NULL).  The caller
+ *           contracts it with (q + r_r_bias) to get d rd:  d rd[d,h,:] = sum_{b,i} dg[b,h,i,d] * (q + r_r_bias)[b,i,h,:]
+ *   d_r_w_bias, d_r_r_bias : (H,dh) f32, accumulated (+=).   M % 8 == 0. */
+int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                    const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                    void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
+                    int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                    long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                     float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -81,6 +99,9 @@ int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, cons
 int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                         const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
                         float drop_p, unsigned long long seed, unsigned site, void* stream);
+/* out[b][t][:] = bf16(x[b][t][:] + bias[:]) with x strided (x_bs, x_rs elements), out compact (B,T,n) */
+int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* bias, void* out, int B, int T, int n,
+                         void* stream);
 /* out[n] += sum_m X[m][n]  (bias gradients), X (M,N) bf16 with leading dimension ld */
 int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream);
 /* upstream TransfoXLModel._update_mems: out[b] = cat(mem[b], hid[b])[-M:], all (B, len, d) bf16, out != mem */

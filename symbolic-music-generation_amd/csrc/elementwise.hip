@@ -242,7 +242,33 @@ __global__ void mem_update_kernel(const bf16_t* mem, const bf16_t* hid, bf16_t* 
     *reinterpret_cast<u32x4*>(out + ((size_t)b * M + r) * d + c * 8) = v;
 }
 
+// out[b][t][:] = bf16(x[b][t][:] + bias[:])  (materialises q + r_r_bias for the dRd contraction)
+__global__ void add_rowbias_kernel(const bf16_t* x, long long x_bs, int x_rs, const float* bias, bf16_t* out, int B, int T, int n) {
+    const int chunks = n >> 3;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T * chunks) return;
+    const int c = (int)(gid % chunks);
+    const long long row = gid / chunks;
+    const int b = (int)(row / T), t = (int)(row % T);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + b * x_bs + (long long)t * x_rs + c * 8);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = bf2f((bf16_t)v[j]) + bias[c * 8 + j];
+    u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(out + row * n + c * 8) = w;
+}
+
 }  // namespace
+
+extern "C" int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* bias, void* out, int B, int T,
+                                    int n, void* stream) {
+    MXL_CHECK_ARG(x && bias && out && B > 0 && T > 0 && n > 0 && (n % 8) == 0 && (x_rs % 8) == 0 && (x_bs % 8) == 0);
+    const long long tot = (long long)B * T * (n / 8);
+    hipLaunchKernelGGL(add_rowbias_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, x_bs, x_rs, bias, (bf16_t*)out, B, T, n);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
 
 extern "C" int mxl_sinusoid_table(void* out, int M, int d, int clamp_len, float drop_p, unsigned long long seed,
                                   unsigned site, void* stream) {

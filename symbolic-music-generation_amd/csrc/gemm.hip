@@ -32,6 +32,9 @@ struct GemmP {
     int flags;
     unsigned long long seed; unsigned site; unsigned thresh; float drop_scale;
     int tiles_m, tiles_n;
+    // batching: grid.y = batch index by; operand offsets (elements) = (by / bdiv) * s?1 + (by % bdiv) * s?2
+    int bdiv;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -111,6 +114,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    if (gridDim.y > 1) {
+        const long long b1 = blockIdx.y / p.bdiv, b2 = blockIdx.y % p.bdiv;
+        p.A += b1 * p.sA1 + b2 * p.sA2;
+        p.B += b1 * p.sB1 + b2 * p.sB2;
+        const long long co = b1 * p.sC1 + b2 * p.sC2;
+        if (p.flags & (MXL_GEMM_OUT_F32 | MXL_GEMM_OUT_F32_ATOMIC)) p.C = reinterpret_cast<float*>(p.C) + co;
+        else p.C = reinterpret_cast<bf16_t*>(p.C) + co;
     }
     const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -232,10 +243,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
 
 }  // namespace
 
-extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                             int transA, int transB, int flags, float alpha, const float* bias,
-                             const void* aux, int ldaux, int ksplits,
-                             float drop_p, unsigned long long seed, unsigned site, void* stream) {
+static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int transA, int transB, int flags, float alpha, const float* bias,
+                       const void* aux, int ldaux, int ksplits,
+                       float drop_p, unsigned long long seed, unsigned site, void* stream,
+                       int batch, int bdiv, long long sA1, long long sA2, long long sB1, long long sB2,
+                       long long sC1, long long sC2) {
     MXL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
     MXL_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0);
     MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
@@ -263,7 +276,13 @@ extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, 1, ksplits), block(256);
+    MXL_CHECK_ARG(batch >= 1 && bdiv >= 1);
+    if (batch > 1) {
+        MXL_CHECK_ARG((sA1 % 8) == 0 && (sA2 % 8) == 0 && (sB1 % 8) == 0 && (sB2 % 8) == 0);
+        MXL_CHECK_ARG(!(flags & (MXL_GEMM_RELU_BWD)));
+    }
+    p.bdiv = bdiv; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2;
+    dim3 grid(p.tiles_m * p.tiles_n, batch, ksplits), block(256);
     const size_t shm = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
     if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, shm, s, p);
@@ -272,4 +291,20 @@ extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, shm, s, p);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
+}
+
+extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int transA, int transB, int flags, float alpha, const float* bias,
+                             const void* aux, int ldaux, int ksplits,
+                             float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, flags, alpha, bias, aux, ldaux, ksplits, drop_p,
+                       seed, site, stream, 1, 1, 0, 0, 0, 0, 0, 0);
+}
+
+extern "C" int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                                     int ldc, int transA, int transB, int flags, float alpha, int ksplits, int batch,
+                                     int bdiv, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
+                                     long long sC2, void* stream) {
+    return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, flags, alpha, nullptr, nullptr, 0, ksplits, 0.f, 0,
+                       0, stream, batch, bdiv, sA1, sA2, sB1, sB2, sC1, sC2);
 }

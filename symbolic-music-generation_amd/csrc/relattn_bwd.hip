@@ -1,0 +1,697 @@
+// K4 backward: gradients of the banded relative-position attention (see relattn_fwd.hip for the forward statement).
+//
+// With raw = AC + BD, s = raw * scale, P = exp(s - lse), dP[i,p] = dO_i . v_p, delta_i = dO_i . O_i:
+//     dSr = scale * P * (dP - delta)                        (gradient w.r.t. raw scores)
+//     dQw_i = sum_p dSr[i,p] k_p          dk_p = sum_i dSr[i,p] (q_i + r_w_bias)        dv_p = sum_i P[i,p] dO_i
+//     dQr_i = sum_d dG[i,d] Rd[d]         dRd[d] = sum_i dG[i,d] (q_i + r_r_bias)       dG[i,d] = dSr[i, i-d]
+//     dq = dQw + dQr,  d r_w_bias = sum_i dQw_i,  d r_r_bias = sum_i dQr_i
+//
+// Three launches, owner-computes, no atomics on the big tensors (deterministic):
+//   relattn_bwd_delta : delta
+//   relattn_bwd_dq    : query-owner (lane = query, same structure as the forward).  Produces dq, the bias gradients and
+//                       dG (B,H,T,M) in bf16 -- the un-skewed score gradient -- which the host contracts with
+//                       (q + r_r_bias) by the batched TT GEMM to obtain dRd (a correlation along diagonals that neither a
+//                       query- nor a key-owner can accumulate on chip).
+//   relattn_bwd_dkv   : key-owner (lane = key): dk, dv.
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+struct BwdP {
+    const bf16_t *q, *k, *v, *rd, *o, *dout;
+    const float *rwb, *rrb, *lse, *delta;
+    bf16_t *dq, *dk, *dv, *dg;
+    float *d_rwb, *d_rrb;
+    float* delta_out;
+    int B, T, H, M, Kc;
+    long long q_bs, kv_bs, o_bs, dq_bs, dkv_bs;
+    int q_rs, kv_rs, rd_rs, o_rs, dq_rs, dkv_rs;
+    float scale, scale_log2e;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// delta[b,h,i] = sum_e dO[b,i,h,e] * O[b,i,h,e]        one wave per (b, i): lanes sweep the d = H*dh row
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relattn_bwd_delta_kernel(BwdP p, int dh) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B * p.T) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / p.T, i = row % p.T;
+    const bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)i * p.o_rs;
+    const bf16_t* dp = p.dout + (size_t)b * p.o_bs + (size_t)i * p.o_rs;
+    // each lane handles 8-element chunks; chunk c belongs to head (c*8)/dh
+    const int chunks = p.H * dh / 8;
+    const int cph = dh / 8;  // chunks per head (2, 4, 8)
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        float s = 0.f;
+        if (c < chunks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(op + c * 8);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)d[j]);
+        }
+        // reduce groups of cph consecutive lanes
+        for (int off = 1; off < cph; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (c < chunks && (lane % cph) == 0) {
+            const int h = c / cph;
+            p.delta_out[((size_t)b * p.H + h) * p.T + i] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// query-owner kernel
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int QB = 128, KT = 64;
+constexpr int GRS = 132;   // fp32 skew ring stride (floats)
+constexpr int DGS = 136;   // bf16 un-skew ring stride (elements): 272 B rows keep ds_read_b128 aligned
+
+template <int DH> struct GeoQ {
+    static constexpr int KS = DH / 16;
+    static constexpr int EB = (DH + 31) / 32;
+    static constexpr int ROWB = DH * 2;
+    static constexpr int CH = DH / 8;
+    static constexpr int K_BYTES = KT * ROWB;
+    static constexpr int R_BYTES = 256 * ROWB;
+    static constexpr int G_BYTES = 4 * 32 * GRS * 4;
+    static constexpr int DG_BYTES = 4 * 32 * DGS * 2;
+    static constexpr int SMEM = 2 * K_BYTES + R_BYTES + G_BYTES + DG_BYTES;
+    static constexpr int NLD = (KT * CH + 255) / 256;
+    __device__ static __forceinline__ int koff(int row, int ch) {
+        if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        return row * ROWB + (ch << 4);
+    }
+    // byte offset of element e (multiple of 4) of a row, for 8-byte transposed reads out of the same image
+    __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
+    using G = GeoQ<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                       // [64][DH]
+    char* sV = sK + G::K_BYTES;            // [64][DH]  (row reads only here)
+    char* sR = sV + G::K_BYTES;            // ring [256][DH]
+    float* sG = reinterpret_cast<float*>(sR + G::R_BYTES);                       // [4][32][GRS] f32
+    bf16_t* sDG = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sG) + G::G_BYTES);  // [4][32][DGS] bf16
+
+    const int tid = threadIdx.x;
+    const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * QB;
+    const int iw0 = i0 + 32 * wid;
+    const int T = p.T, M = p.M;
+    const int p0 = T - p.Kc;
+    float* myG = sG + wid * 32 * GRS + r * GRS;
+    bf16_t* myDG = sDG + wid * 32 * DGS + r * DGS;
+
+    const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* rbase = p.rd + (size_t)h * DH;
+    const int qi = iw0 + r;
+    const bool qok = qi < T;
+
+    bf16x8 qw[KS], qr[KS], dof[KS];
+    {
+        const size_t qrow = (size_t)(qok ? qi : 0);
+        const bf16_t* qp = p.q + (size_t)b * p.q_bs + qrow * p.q_rs + (size_t)h * DH;
+        const bf16_t* dop = p.dout + (size_t)b * p.o_bs + qrow * p.o_rs + (size_t)h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int e0 = 16 * ks + 8 * hh;
+            const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + e0);
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dop + e0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float qf = qok ? bf2f((bf16_t)qv[j]) : 0.f;
+                qw[ks][j] = (short)f2bf(qf + p.rwb[h * DH + e0 + j]);
+                qr[ks][j] = (short)f2bf(qf + p.rrb[h * DH + e0 + j]);
+                dof[ks][j] = qok ? dv[j] : (short)0;
+            }
+        }
+    }
+    const size_t sidx = ((size_t)b * p.H + h) * T + (qok ? qi : 0);
+    const float lse2 = qok ? p.lse[sidx] * LOG2E : 0.f;
+    const float dlt = qok ? p.delta[sidx] : 0.f;
+
+    // zero this wave's un-skew ring: never-written cells must read as 0
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(sDG + wid * 32 * DGS);
+        for (int i = l; i < 32 * DGS / 2; i += 64) z[i] = 0u;
+    }
+
+    const int p_lo = i0 - M + 1;
+    const int p_hi = min(i0 + QB - 1, T - 1);
+    const int kt_lo = floordiv(p_lo, KT), kt_hi = floordiv(p_hi, KT);
+
+    u32x4 rk[G::NLD], rv[G::NLD], rr[G::NLD];
+    auto load_kv = [&](int kt) {
+        const int P = kt * KT;
+#pragma unroll
+        for (int n = 0; n < G::NLD; n++) {
+            const int c = tid + n * 256;
+            const int row = c / G::CH, ch = c % G::CH;
+            const int srow = P + row - p0;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            const bool ok = (c < KT * G::CH) && (srow >= 0) && (srow < p.Kc);
+            rk[n] = ok ? *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+            rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int n = 0; n < G::NLD; n++) {
+            const int c = tid + n * 256;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = rk[n];
+                *reinterpret_cast<u32x4*>(sV + G::koff(row, ch)) = rv[n];
+            }
+        }
+    };
+    auto load_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < G::NLD; n++) {
+            const int c = tid + n * 256;
+            const int row = c / G::CH, ch = c % G::CH;
+            int d = dbase + row;
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rr[n] = (c < KT * G::CH) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8) : z;
+        }
+    };
+    auto store_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < G::NLD; n++) {
+            const int c = tid + n * 256;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                *reinterpret_cast<u32x4*>(sR + G::koff((dbase + row) & 255, ch)) = rr[n];
+            }
+        }
+    };
+
+    {
+        const int P0 = kt_lo * KT;
+        load_kv(kt_lo);
+        store_kv();
+#pragma unroll 1
+        for (int q4 = 0; q4 < 3; q4++) {
+            const int dbase = i0 - P0 - 64 + 64 * q4;
+            load_r(dbase);
+            store_r(dbase);
+        }
+    }
+    __syncthreads();
+
+    f32x16 aw[EB], ar[EB];  // dQw^T, dQr^T : [e][query]
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { aw[e][j] = 0.f; ar[e][j] = 0.f; }
+    bool have_ring = false;
+    bf16_t* dgrow = p.dg ? p.dg + (((size_t)b * p.H + h) * T + (qok ? qi : 0)) * (size_t)M : nullptr;
+
+#pragma unroll 1
+    for (int kt = kt_lo; kt <= kt_hi; kt++) {
+        const int P = kt * KT;
+        const bool more = kt < kt_hi;
+        if (more) {
+            load_kv(kt + 1);
+            load_r(i0 - (P + KT) - 64);
+        }
+        const int dmin_w = iw0 - P - (KT - 1), dmax_w = iw0 + 31 - P;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);
+        if (active) {
+            const int dlo = iw0 - P - 64;
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) { s[kb][j] = 0.f; dp[kb][j] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + G::koff(32 * kb + r, 2 * ks + hh));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sV + G::koff(32 * kb + r, 2 * ks + hh));
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
+                                                                     __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp[kb], 0, 0, 0);
+                }
+            }
+            const int nb = have_ring ? 2 : 3;
+#pragma unroll 1
+            for (int gb = 0; gb < nb; gb++) {
+                f32x16 g;
+#pragma unroll
+                for (int j = 0; j < 16; j++) g[j] = 0.f;
+                const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const int d = dlo + 32 * gb + 8 * grp + 4 * hh;
+                    *reinterpret_cast<f32x4*>(myG + (d & 127)) = f32x4{g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                }
+            }
+            have_ring = true;
+            // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127
+            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T);
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const int d = qi - P - jj;
+                    const float bd = myG[d & 127];
+                    const float val = (s[kb][j] + bd) * p.scale_log2e - lse2;
+                    float pv = __builtin_amdgcn_exp2f(val);
+                    if (!full) {
+                        const bool valid = (d >= 0) && (d <= M - 1) && qok;
+                        pv = valid ? pv : 0.f;
+                    }
+                    const float ds = p.scale * pv * (dp[kb][j] - dlt);
+                    s[kb][j] = ds;
+                    myDG[d & 127] = f2bf(ds);
+                }
+            }
+            // dQw^T += K^T . dSr^T   (A = K^T through transposed reads of the K image, accumulator-permuted k order)
+            const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const uint32_t w = pack2bf(s[kb][8 * st + j], s[kb][8 * st + j + 1]);
+                        pf[j] = (short)(w & 0xffff);
+                        pf[j + 1] = (short)(w >> 16);
+                    }
+#pragma unroll
+                    for (int e = 0; e < EB; e++) {
+                        const int key = 32 * kb + 16 * st + 4 * hh + q4;
+                        const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                        bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (ecol < DH) {
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key, ecol)));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key + 8, ecol)));
+                            a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+                        aw[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                        __builtin_bit_cast(mfma_bf16x8, pf), aw[e], 0, 0, 0);
+                    }
+                }
+            }
+            // completed distance blocks 1 and 2 of the window: d in [dlo+32, dlo+95]
+#pragma unroll
+            for (int blk = 1; blk < 3; blk++) {
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ks2++) {
+                    const int d8 = dlo + 32 * blk + 16 * ks2 + 8 * hh;  // 8 consecutive distances (natural k order)
+                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(myDG + (d8 & 127));
+                    if (dgrow && qok && d8 >= 0 && d8 + 7 <= M - 1)
+                        *reinterpret_cast<bf16x8*>(dgrow + d8) = bfrag;
+#pragma unroll
+                    for (int e = 0; e < EB; e++) {
+                        const int dist = dlo + 32 * blk + 16 * ks2 + 8 * (gq >> 1) + q4;
+                        const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                        bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (ecol < DH) {
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff(dist & 255, ecol)));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff((dist + 4) & 255, ecol)));
+                            a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+                        ar[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                        __builtin_bit_cast(mfma_bf16x8, bfrag), ar[e], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_kv();
+            store_r(i0 - (P + KT) - 64);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: dq = dQw + dQr (lane = query); bias gradients = sums over the wave's queries
+    if (qok) {
+        bf16_t* dqp = p.dq + (size_t)b * p.dq_bs + (size_t)qi * p.dq_rs + (size_t)h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    u32x2 w = {pack2bf(aw[e][4 * grp] + ar[e][4 * grp], aw[e][4 * grp + 1] + ar[e][4 * grp + 1]),
+                               pack2bf(aw[e][4 * grp + 2] + ar[e][4 * grp + 2], aw[e][4 * grp + 3] + ar[e][4 * grp + 3])};
+                    *reinterpret_cast<u32x2*>(dqp + e0) = w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float a = qok ? aw[e][j] : 0.f, c = qok ? ar[e][j] : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); c += __shfl_xor(c, off, 64); }
+            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (r == 0 && ee < DH) {
+                atomicAdd(p.d_rwb + h * DH + ee, a);
+                atomicAdd(p.d_rrb + h * DH + ee, c);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// key-owner kernel: wave owns 32 keys (lane = key), workgroup 128 keys; streams 32-query tiles
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KB = 128, QT = 32;
+constexpr int SKS = 68;  // fp32 skew row stride
+
+template <int DH> struct GeoK {
+    static constexpr int KS = DH / 16;
+    static constexpr int EB = (DH + 31) / 32;
+    static constexpr int ROWB = DH * 2;
+    static constexpr int CH = DH / 8;
+    static constexpr int Q_BYTES = QT * ROWB;          // one 32-row tile image
+    static constexpr int R_BYTES = 256 * ROWB;
+    static constexpr int S_BYTES = 4 * 32 * SKS * 4;
+    static constexpr int SMEM = 3 * Q_BYTES + 2 * QT * 4 + R_BYTES + S_BYTES;
+    __device__ static __forceinline__ int koff(int row, int ch) {
+        if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        return row * ROWB + (ch << 4);
+    }
+    __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(BwdP p) {
+    using G = GeoK<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQw = smem;
+    char* sQr = sQw + G::Q_BYTES;
+    char* sDO = sQr + G::Q_BYTES;
+    float* sLse = reinterpret_cast<float*>(sDO + G::Q_BYTES);  // [32] (log2 units)
+    float* sDl = sLse + QT;                                     // [32]
+    char* sR = reinterpret_cast<char*>(sDl + QT);               // ring [256][DH]
+    float* sS = reinterpret_cast<float*>(sR + G::R_BYTES);      // [4][32][SKS]
+
+    const int tid = threadIdx.x;
+    const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int T = p.T, M = p.M;
+    const int p0 = T - p.Kc;
+    const int P0 = p0 + blockIdx.x * KB;   // first key position of the workgroup
+    const int Pw = P0 + 32 * wid;
+    const int pk = Pw + r;                 // this lane's key position
+    const bool kok = pk < T;               // pk >= p0 always
+    float* myS = sS + wid * 32 * SKS;
+
+    const bf16_t* qbase = p.q + (size_t)b * p.q_bs + (size_t)h * DH;
+    const bf16_t* dobase = p.dout + (size_t)b * p.o_bs + (size_t)h * DH;
+    const bf16_t* rbase = p.rd + (size_t)h * DH;
+
+    // K, V fragments (B operands: lane = key, k = 16ks + 8hh + j)
+    bf16x8 kf[KS], vf[KS];
+    {
+        const size_t srow = (size_t)(kok ? pk - p0 : 0);
+        const bf16_t* kp = p.k + (size_t)b * p.kv_bs + srow * p.kv_rs + (size_t)h * DH;
+        const bf16_t* vp = p.v + (size_t)b * p.kv_bs + srow * p.kv_rs + (size_t)h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int e0 = 16 * ks + 8 * hh;
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kp + e0);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vp + e0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { kf[ks][j] = kok ? kv[j] : (short)0; vf[ks][j] = kok ? vv[j] : (short)0; }
+        }
+    }
+
+    // queries that can see any key of this workgroup: i in [P0, P0 + KB - 1 + M - 1], clipped to [0, T)
+    const int i_lo = max(P0, 0), i_hi = min(P0 + KB - 1 + M - 1, T - 1);
+    const int it_lo = i_lo / QT, it_hi = i_hi / QT;
+
+    // staging: thread t < 32*CH handles one 16-byte chunk of each of the three tiles
+    u32x4 tq, tdo, rr;
+    float tl = 0.f, tdl = 0.f;
+    auto load_q = [&](int it) {
+        const int I = it * QT;
+        const int row = tid / G::CH, ch = tid % G::CH;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        const bool ok = (tid < QT * G::CH) && (I + row < T);
+        tq = ok ? *reinterpret_cast<const u32x4*>(qbase + (size_t)(I + row) * p.q_rs + ch * 8) : z;
+        tdo = ok ? *reinterpret_cast<const u32x4*>(dobase + (size_t)(I + row) * p.o_rs + ch * 8) : z;
+        if (tid < QT) {
+            const bool ok2 = I + tid < T;
+            const size_t sidx = ((size_t)b * p.H + h) * T + (ok2 ? I + tid : 0);
+            tl = ok2 ? p.lse[sidx] * LOG2E : 0.f;
+            tdl = ok2 ? p.delta[sidx] : 0.f;
+        }
+    };
+    auto store_q = [&]() {
+        if (tid < QT * G::CH) {
+            const int row = tid / G::CH, ch = tid % G::CH;
+            u32x4 w, rq;
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
+            bf16_t* dw = reinterpret_cast<bf16_t*>(&w);
+            bf16_t* dr = reinterpret_cast<bf16_t*>(&rq);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float qf = bf2f(src[j]);
+                dw[j] = f2bf(qf + p.rwb[h * DH + ch * 8 + j]);
+                dr[j] = f2bf(qf + p.rrb[h * DH + ch * 8 + j]);
+            }
+            *reinterpret_cast<u32x4*>(sQw + G::koff(row, ch)) = w;
+            *reinterpret_cast<u32x4*>(sQr + G::koff(row, ch)) = rq;
+            *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = tdo;
+        }
+        if (tid < QT) { sLse[tid] = tl; sDl[tid] = tdl; }
+    };
+    // 32 Rd rows [dbase, dbase+32)
+    auto load_r = [&](int dbase) {
+        const int row = tid / G::CH, ch = tid % G::CH;
+        int d = dbase + row;
+        d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+        u32x4 z = {0u, 0u, 0u, 0u};
+        rr = (tid < 32 * G::CH) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8) : z;
+    };
+    auto store_r = [&](int dbase) {
+        if (tid < 32 * G::CH) {
+            const int row = tid / G::CH, ch = tid % G::CH;
+            *reinterpret_cast<u32x4*>(sR + G::koff((dbase + row) & 255, ch)) = rr;
+        }
+    };
+
+    // prologue: first query tile and its distance window [I - P0 - 128, I - P0 + 31]
+    {
+        const int I = it_lo * QT;
+        load_q(it_lo);
+        store_q();
+#pragma unroll 1
+        for (int c5 = 0; c5 < 5; c5++) {
+            const int dbase = I - P0 - 128 + 32 * c5;
+            load_r(dbase);
+            store_r(dbase);
+        }
+    }
+    __syncthreads();
+
+    f32x16 ak[EB], av[EB];  // dK^T, dV^T : [e][key]
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; }
+
+#pragma unroll 1
+    for (int it = it_lo; it <= it_hi; it++) {
+        const int I = it * QT;
+        const bool more = it < it_hi;
+        if (more) {
+            load_q(it + 1);
+            load_r(I + QT - P0);  // next window's 32 new (highest) distances: [I+32-P0, I+63-P0]
+        }
+        const int dmin_w = I - Pw - 31, dmax_w = I + 31 - Pw;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pw < T);
+        if (active) {
+            const int dlo = I - Pw - 32;
+            // S = Qw . K^T and dP = dO . V^T  (rows = queries, lane = key)
+            f32x16 s, dp;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { s[j] = 0.f; dp[j] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQw + G::koff(r, 2 * ks + hh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                            __builtin_bit_cast(mfma_bf16x8, kf[ks]), s, 0, 0, 0);
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sDO + G::koff(r, 2 * ks + hh));
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ad),
+                                                             __builtin_bit_cast(mfma_bf16x8, vf[ks]), dp, 0, 0, 0);
+            }
+            // G = Qr . Rd^T over the 64-distance window (lane = distance), skewed through LDS to lane = key
+#pragma unroll 1
+            for (int gb = 0; gb < 2; gb++) {
+                f32x16 g;
+#pragma unroll
+                for (int j = 0; j < 16; j++) g[j] = 0.f;
+                const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQr + G::koff(r, 2 * ks + hh));
+                    const bf16x8 bb = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, bb), g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    myS[ii * SKS + 32 * gb + r] = g[j];
+                }
+            }
+            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (I + 31 < T);
+            f32x16 pr;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                const int d = I + ii - pk;             // = dlo + (ii - r + 32)
+                const float bd = myS[ii * SKS + (ii - r + 32)];
+                const float val = (s[j] + bd) * p.scale_log2e - sLse[ii];
+                float pv = __builtin_amdgcn_exp2f(val);
+                if (!full) {
+                    const bool valid = (d >= 0) && (d <= M - 1) && (I + ii < T);
+                    pv = valid ? pv : 0.f;
+                }
+                pr[j] = pv;
+                s[j] = p.scale * pv * (dp[j] - sDl[ii]);
+            }
+            // dV^T += dO^T . P ; dK^T += Qw^T . dSr   (A through transposed reads, accumulator-permuted k order)
+            const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t w = pack2bf(pr[8 * st + j], pr[8 * st + j + 1]);
+                    pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
+                    const uint32_t w2 = pack2bf(s[8 * st + j], s[8 * st + j + 1]);
+                    df[j] = (short)(w2 & 0xffff); df[j + 1] = (short)(w2 >> 16);
+                }
+#pragma unroll
+                for (int e = 0; e < EB; e++) {
+                    const int qrow = 16 * st + 4 * hh + q4;
+                    const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                    bf16x8 a1 = {0, 0, 0, 0, 0, 0, 0, 0}, a2 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ecol < DH) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sDO + G::eoff(qrow, ecol)));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sDO + G::eoff(qrow + 8, ecol)));
+                        a1 = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sQw + G::eoff(qrow, ecol)));
+                        const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sQw + G::eoff(qrow + 8, ecol)));
+                        a2 = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                    }
+                    av[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a1),
+                                                                    __builtin_bit_cast(mfma_bf16x8, pf), av[e], 0, 0, 0);
+                    ak[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a2),
+                                                                    __builtin_bit_cast(mfma_bf16x8, df), ak[e], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_q();
+            store_r(I + QT - P0);
+        }
+        __syncthreads();
+    }
+
+    if (kok) {
+        const size_t srow = (size_t)(pk - p0);
+        bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * DH;
+        bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    u32x2 wk = {pack2bf(ak[e][4 * grp], ak[e][4 * grp + 1]), pack2bf(ak[e][4 * grp + 2], ak[e][4 * grp + 3])};
+                    u32x2 wv = {pack2bf(av[e][4 * grp], av[e][4 * grp + 1]), pack2bf(av[e][4 * grp + 2], av[e][4 * grp + 3])};
+                    *reinterpret_cast<u32x2*>(dkp + e0) = wk;
+                    *reinterpret_cast<u32x2*>(dvp + e0) = wv;
+                }
+            }
+        }
+    }
+}
+
+template <int DH>
+int launch_bwd(const BwdP& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dq_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GeoQ<DH>::SMEM);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dkv_kernel<DH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GeoK<DH>::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(relattn_bwd_delta_kernel, dim3((p.B * p.T + 3) / 4), dim3(256), 0, s, p, DH);
+    hipLaunchKernelGGL((relattn_bwd_dq_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(256), GeoQ<DH>::SMEM, s, p);
+    hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+}  // namespace
+
+extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                               const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
+                               int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                               long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
+                               float scale, void* stream) {
+    MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv);
+    MXL_CHECK_ARG(d_r_w_bias && d_r_r_bias);
+    MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && (M % 8) == 0 && Kc >= T && Kc <= M + T);
+    MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 8) == 0 && (dq_rs % 4) == 0 && (dkv_rs % 4) == 0);
+    MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 8) == 0 && (dq_bs % 4) == 0 && (dkv_bs % 4) == 0);
+    BwdP p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.rd = (const bf16_t*)rd;
+    p.o = (const bf16_t*)out; p.dout = (const bf16_t*)dout;
+    p.rwb = r_w_bias; p.rrb = r_r_bias; p.lse = lse; p.delta = delta; p.delta_out = delta;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dg = (bf16_t*)dg;
+    p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
+    p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
+    p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.dq_bs = dq_bs; p.dkv_bs = dkv_bs;
+    p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dq_rs = dq_rs; p.dkv_rs = dkv_rs;
+    p.scale = scale; p.scale_log2e = scale * LOG2E;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 16: return launch_bwd<16>(p, s);
+        case 32: return launch_bwd<32>(p, s);
+        case 64: return launch_bwd<64>(p, s);
+        default: return MXL_EUNSUPPORTED;
+    }
+}

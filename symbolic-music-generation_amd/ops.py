@@ -173,3 +173,34 @@ def adamw_step(p, g, m, v, w16, n_decay, lr, beta1, beta2, eps, weight_decay, st
 def cast_bf16(x: torch.Tensor, y: torch.Tensor):
     check(lib().mxl_cast_f32_bf16(_p(x), _p(y), x.numel(), _stream()), 'mxl_cast_f32_bf16')
     return y
+
+
+def gemm_batched(a, b, c, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=False, flags=0, alpha=1.0, ksplits=1,
+                 batch=1, bdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+    check(lib().mxl_gemm_bf16_batched(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,
+                                      float(alpha), ksplits, batch, bdiv, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+                                      _stream()), 'mxl_gemm_bf16_batched')
+    return c
+
+
+def add_rowbias(x, x_bs, x_rs, bias, out, B, T, n):
+    check(lib().mxl_add_rowbias_bf16(_p(x), x_bs, x_rs, _p(bias), _p(out), B, T, n, _stream()), 'mxl_add_rowbias_bf16')
+    return out
+
+
+def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_rwb, d_rrb, *, B, T, H, dh, M,
+                Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale=None,
+                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None):
+    """Backward of relattn_fwd.  If `d_rd` (M, H*dh) f32 is given, also contracts dG with (q + r_r_bias):
+    d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf)."""
+    scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    check(lib().mxl_relattn_bwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse),
+                                _p(delta), _p(dq), _p(dk), _p(dv), _p(dg), _p(d_rwb), _p(d_rrb), B, T, H, dh, M, Kc,
+                                q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale),
+                                _stream()), 'mxl_relattn_bwd')
+    if d_rd is not None:
+        d = H * dh
+        add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
+        # per (b, h): d_rd[:, h*dh:(h+1)*dh] (M x dh) += dG[b,h]^T (M x T) @ qr[b,:,h,:] (T x dh)
+        gemm_batched(dg, qr_buf, d_rd, M, dh, T, lda=M, ldb=d, ldc=d, trans_a=True, trans_b=True,
+                     flags=GEMM_OUT_F32_ATOMIC, batch=B * H, bdiv=H, sA=(H * T * M, T * M), sB=(T * d, dh), sC=(0, dh))

@@ -281,3 +281,64 @@ def test_relattn_fwd(dev, B, T, H, dh, M, Kc, name):
     # scores have |s| ~ 10 with bf16-rounded (q+bias) and P: 3e-2 abs on O(1) outputs, 5e-2 on lse
     assert err < 4e-2, f'{name}: out err {err}'
     assert lerr < 6e-2, f'{name}: lse err {lerr}'
+
+
+BWD_CASES = [
+    (2, 128, 2, 64, 128, 128, 'square-nomem'),
+    (1, 256, 2, 64, 128, 256 + 128, 'with-mem'),
+    (2, 200, 3, 64, 64, 200, 'ragged-T'),
+    (1, 320, 1, 64, 256, 320 + 256, 'multi-block-mem'),
+    (2, 256, 8, 16, 256, 256, 'C1-shape dh16'),
+    (1, 160, 4, 32, 128, 160 + 40, 'dh32 partial mem'),
+    (1, 70, 2, 64, 320, 70, 'T<M nomem'),
+]
+
+
+@pytest.mark.parametrize('B,T,H,dh,M,Kc,name', BWD_CASES)
+def test_relattn_bwd(dev, B, T, H, dh, M, Kc, name):
+    from symbolic_music_generation_amd import ops
+    from oracle.relattn_ref import relattn_dense
+    torch.manual_seed(T * 3 + M)
+    d = H * dh
+    qkv = bf(torch.randn(B, Kc, 3 * d) * 0.8)
+    rd = bf(torch.randn(M, d) * 0.8)
+    rwb, rrb = torch.randn(H, dh) * 0.5, torch.randn(H, dh) * 0.5
+    dout = bf(torch.randn(B, T, d))
+    # fp32 autograd reference on the bf16-rounded inputs
+    q = qkv[:, Kc - T:, :d].float().view(B, T, H, dh).clone().requires_grad_(True)
+    k = qkv[:, :, d:2 * d].float().view(B, Kc, H, dh).clone().requires_grad_(True)
+    v = qkv[:, :, 2 * d:].float().view(B, Kc, H, dh).clone().requires_grad_(True)
+    rdr = rd.float().view(M, H, dh).clone().requires_grad_(True)
+    rwbr, rrbr = rwb.clone().requires_grad_(True), rrb.clone().requires_grad_(True)
+    ref_out, _ = relattn_dense(q, k, v, rdr, rwbr, rrbr, M)
+    ref_out.backward(dout.float().view(B, T, H, dh))
+
+    qkv_d, rd_d, do_d = qkv.to(dev), rd.to(dev), dout.to(dev)
+    rwb_d, rrb_d = rwb.to(dev), rrb.to(dev)
+    out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=dev)
+    st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+              o_bs=T * d, o_rs=d)
+    qv, kv, vv = qkv_d[:, Kc - T:, :d], qkv_d[:, :, d:2 * d], qkv_d[:, :, 2 * d:]
+    ops.relattn_fwd(qv, kv, vv, rd_d, rwb_d, rrb_d, out, lse, **st)
+    dqkv = torch.zeros(B, Kc, 3 * d, device=dev, dtype=torch.bfloat16)
+    delta = torch.zeros(B, H, T, device=dev)
+    dg = torch.full((B, H, T, M), float('nan'), device=dev, dtype=torch.bfloat16)
+    d_rwb, d_rrb = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
+    d_rd = torch.zeros(M, d, device=dev)
+    qr_buf = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
+    ops.relattn_bwd(qv, kv, vv, rd_d, rwb_d, rrb_d, out, do_d, lse, delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d],
+                    dqkv[:, :, 2 * d:], dg, d_rwb, d_rrb, dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
+                    d_rd=d_rd, qr_buf=qr_buf, **st)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dg.float()).any(), f'{name}: dG not fully written'
+    got_dq = dqkv[:, Kc - T:, :d].float().cpu().view(B, T, H, dh)
+    got_dk = dqkv[:, :, d:2 * d].float().cpu().view(B, Kc, H, dh)
+    got_dv = dqkv[:, :, 2 * d:].float().cpu().view(B, Kc, H, dh)
+    # bf16 P / dS operands and bf16 outputs: 2e-2 relative (Frobenius) per tensor
+    errs = {}
+    for nm, got, ref in [('dq', got_dq, q.grad), ('dk', got_dk, k.grad), ('dv', got_dv, v.grad),
+                         ('d_rd', d_rd.cpu().view(M, H, dh), rdr.grad), ('d_rwb', d_rwb.cpu(), rwbr.grad),
+                         ('d_rrb', d_rrb.cpu(), rrbr.grad)]:
+        errs[nm] = rel_err(got, ref)
+    assert all(e < 2e-2 for e in errs.values()), f'{name}: {errs}'
