@@ -87,9 +87,12 @@ int mxl_sinusoid_table(void* out, int M, int d, int clamp_len, float drop_p, uns
 /* upstream AdaptiveEmbedding (div_val=1) + drop: out[n] = drop(E[ids[n]] * scale); ids int64, E (V,d) bf16 */
 int mxl_embed_fwd(const void* ids, const void* E, void* out, int N, int d, int V, float scale, float drop_p,
                   unsigned long long seed, unsigned site, void* stream);
-/* its backward: dE[ids[n]] += keep * scale * dout[n]  (f32 atomics) */
-int mxl_embed_bwd(const void* ids, const void* dout, float* dE, int N, int d, int V, float scale, float drop_p,
-                  unsigned long long seed, unsigned site, void* stream);
+/* its backward: dE[ids[n]] += keep * scale * (dout[n] + dout2[n])  (f32 atomics; dout2 may be NULL) */
+int mxl_embed_bwd(const void* ids, const void* dout, const void* dout2, float* dE, int N, int d, int V, float scale,
+                  float drop_p, unsigned long long seed, unsigned site, void* stream);
+/* y = keep * x / (1-p): the final drop(core_out) of TransfoXLModel.forward (and its backward with x := dy); n % 8 == 0 */
+int mxl_dropout_bf16(const void* x, void* y, long long n, float drop_p, unsigned long long seed, unsigned site,
+                     void* stream);
 /* y = LayerNorm(res + drop(x)) * gamma + beta  (post-LN of dec_attn / pos_ff); z (pre-norm sum), mean, rstd saved
  * for the backward (any of z/mean/rstd/res may be NULL).  x,res,y,z (N,d) bf16; d % 8 == 0, d <= 2048 */
 int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z,

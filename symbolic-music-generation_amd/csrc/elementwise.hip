@@ -52,14 +52,16 @@ __global__ void embed_fwd_kernel(const long long* ids, const bf16_t* E, bf16_t* 
 }
 
 // dE[ids[n]][:] += dout[n][:] * scale * keep   (fp32 atomics; rows are 4*d contiguous bytes per wave-instruction)
-__global__ void embed_bwd_kernel(const long long* ids, const bf16_t* dout, float* dE, int N, int d, int V, float scale,
+__global__ void embed_bwd_kernel(const long long* ids, const bf16_t* dout, const bf16_t* dout2, float* dE, int N, int d, int V, float scale,
                                  unsigned thresh, float dscale, unsigned long long seed, unsigned site) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)N * d) return;
     const int n = (int)(gid / d), k = (int)(gid % d);
     const long long id = ids[n];
     if (id < 0 || id >= V) return;
-    float g = bf2f(dout[(size_t)n * d + k]) * scale;
+    float g = bf2f(dout[(size_t)n * d + k]);
+    if (dout2) g += bf2f(dout2[(size_t)n * d + k]);
+    g *= scale;
     if (thresh) g = dropout_keep(seed, site, (uint64_t)n * d + k, thresh) ? g * dscale : 0.f;
     atomicAdd(dE + (size_t)id * d + k, g);
 }
@@ -258,7 +260,32 @@ __global__ void add_rowbias_kernel(const bf16_t* x, long long x_bs, int x_rs, co
     *reinterpret_cast<u32x4*>(out + row * n + c * 8) = w;
 }
 
+// y = keep * x / (1 - p)   (final `drop(core_out)` of TransfoXLModel.forward; its own backward with x := dy)
+__global__ void dropout_kernel(const bf16_t* x, bf16_t* y, long long n8, unsigned thresh, float dscale,
+                               unsigned long long seed, unsigned site) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            o[j] = dropout_keep(seed, site, (uint64_t)i * 8 + j, thresh) ? bf2f((bf16_t)v[j]) * dscale : 0.f;
+        u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(y + i * 8) = w;
+    }
+}
+
 }  // namespace
+
+extern "C" int mxl_dropout_bf16(const void* x, void* y, long long n, float drop_p, unsigned long long seed, unsigned site,
+                                void* stream) {
+    MXL_CHECK_ARG(x && y && n > 0 && (n % 8) == 0 && drop_p > 0.f && drop_p < 1.f);
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, n / 8, dropout_thresh(drop_p), 1.f / (1.f - drop_p), seed, site);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
 
 extern "C" int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* bias, void* out, int B, int T,
                                     int n, void* stream) {
@@ -291,12 +318,12 @@ extern "C" int mxl_embed_fwd(const void* ids, const void* E, void* out, int N, i
     return MXL_OK;
 }
 
-extern "C" int mxl_embed_bwd(const void* ids, const void* dout, float* dE, int N, int d, int V, float scale,
-                             float drop_p, unsigned long long seed, unsigned site, void* stream) {
+extern "C" int mxl_embed_bwd(const void* ids, const void* dout, const void* dout2, float* dE, int N, int d, int V,
+                             float scale, float drop_p, unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(ids && dout && dE && N > 0 && d > 0 && V > 0);
     const long long n = (long long)N * d;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)ids, (const bf16_t*)dout, dE, N, d, V, scale, dropout_thresh(drop_p),
+                       (const long long*)ids, (const bf16_t*)dout, (const bf16_t*)dout2, dE, N, d, V, scale, dropout_thresh(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
     MXL_LAUNCH_CHECK();
     return MXL_OK;

@@ -84,12 +84,18 @@ def embed_fwd(ids: torch.Tensor, E: torch.Tensor, out: torch.Tensor, scale: floa
     return out
 
 
-def embed_bwd(ids: torch.Tensor, dout: torch.Tensor, dE: torch.Tensor, scale: float, drop_p=0.0, seed=0, site=0):
+def embed_bwd(ids: torch.Tensor, dout: torch.Tensor, dE: torch.Tensor, scale: float, drop_p=0.0, seed=0, site=0,
+              dout2: Optional[torch.Tensor] = None):
     _req(ids, torch.int64, 'ids'); _req(dout, torch.bfloat16, 'dout'); _req(dE, torch.float32, 'dE')
     N, d = ids.numel(), dE.shape[1]
-    check(lib().mxl_embed_bwd(_p(ids), _p(dout), _p(dE), N, d, dE.shape[0], float(scale), float(drop_p), seed, site,
-                              _stream()), 'mxl_embed_bwd')
+    check(lib().mxl_embed_bwd(_p(ids), _p(dout), _p(dout2), _p(dE), N, d, dE.shape[0], float(scale), float(drop_p), seed,
+                              site, _stream()), 'mxl_embed_bwd')
     return dE
+
+
+def dropout(x: torch.Tensor, y: torch.Tensor, drop_p: float, seed=0, site=0):
+    check(lib().mxl_dropout_bf16(_p(x), _p(y), x.numel(), float(drop_p), seed, site, _stream()), 'mxl_dropout_bf16')
+    return y
 
 
 def ln_residual_fwd(x, res, gamma, beta, y, z=None, mean=None, rstd=None, eps=1e-5, drop_p=0.0, seed=0, site=0):

@@ -1,0 +1,421 @@
+"""Transformer-XL execution engine: one flat parameter buffer, an explicit layer loop that enqueues the HIP kernels of
+libmusicxl (no autograd tape, no tracing), saved activations in a pre-allocated workspace.
+
+Semantics follow upstream `TransfoXLModel` / `TransfoXLLMHeadModel` of transformers==4.25.1 as wrapped by
+musicnlp/models/transformer_xl.py:127-241: post-LN layers, same_length window of `mem_len` keys,
+zero initial mems, tied embedding/softmax weight with own bias, adaptive softmax with optional cutoffs,
+loss = mean over non-zero per-token NLLs.  Internal layout is batch-major (B, T, d) instead of upstream's (T, B, d).
+
+Precision: bf16 storage / MFMA operands with fp32 accumulation; fp32 master weights, gradients and Adam moments.
+"""
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._lib import MusicXLError
+
+F = ops  # flags live there
+
+
+def _r8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class ParamLayout:
+    """Flat layout: [decay segment | no-decay segment]; every tensor starts at a multiple of 8 elements.
+    HF Trainer decays everything except names containing 'bias' and LayerNorm weights (trainer.py create_optimizer)."""
+
+    def __init__(self, cfg):
+        d, Fi, H, dh, V, L = cfg.d_model, cfg.d_inner, cfg.n_head, cfg.d_head, cfg.vocab_size, cfg.n_layer
+        ncl = len(cfg.cutoffs)
+        self.n_head_rows = V + ncl
+        self.head_rows_padded = _r8(V + ncl)
+        decay: List[Tuple[str, Tuple[int, ...]]] = [('transformer.word_emb.emb_layers.0.weight', (V, d))]
+        if ncl:
+            decay.append(('crit.cluster_weight', (ncl, d)))
+        if self.head_rows_padded > V + ncl:
+            decay.append(('_pad.head_rows', (self.head_rows_padded - V - ncl, d)))
+        nodecay: List[Tuple[str, Tuple[int, ...]]] = [('crit.out_layers.0.bias', (V,))]
+        if ncl:
+            nodecay.append(('crit.cluster_bias', (ncl,)))
+        for l in range(L):
+            p = f'transformer.layers.{l}.'
+            decay += [(p + 'dec_attn.qkv_net.weight', (3 * H * dh, d)), (p + 'dec_attn.r_net.weight', (H * dh, d)),
+                      (p + 'dec_attn.o_net.weight', (d, H * dh)), (p + 'pos_ff.CoreNet.0.weight', (Fi, d)),
+                      (p + 'pos_ff.CoreNet.3.weight', (d, Fi))]
+            nodecay += [(p + 'dec_attn.r_r_bias', (H, dh)), (p + 'dec_attn.r_w_bias', (H, dh)),
+                        (p + 'dec_attn.layer_norm.weight', (d,)), (p + 'dec_attn.layer_norm.bias', (d,)),
+                        (p + 'pos_ff.CoreNet.0.bias', (Fi,)), (p + 'pos_ff.CoreNet.3.bias', (d,)),
+                        (p + 'pos_ff.layer_norm.weight', (d,)), (p + 'pos_ff.layer_norm.bias', (d,))]
+        self.entries: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        for name, shape in decay:
+            self.entries[name] = (off, shape)
+            n = math.prod(shape)
+            # the head rows [E ; cluster_weight ; pad] must stay contiguous: no padding between them
+            off += n if name in ('transformer.word_emb.emb_layers.0.weight', 'crit.cluster_weight') else _r8(n)
+        off = _r8(off)
+        self.n_decay = off
+        for name, shape in nodecay:
+            self.entries[name] = (off, shape)
+            n = math.prod(shape)
+            off += n if name == 'crit.out_layers.0.bias' and ncl else _r8(n)
+        self.total = _r8(off)
+
+    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.entries[name]
+        return buf[off:off + math.prod(shape)].view(*shape)
+
+    def real_names(self):
+        return [n for n in self.entries if not n.startswith('_pad.')]
+
+
+class _WS:
+    pass
+
+
+class XLEngine:
+    SITE_EMB, SITE_POS, SITE_FINAL = 0, 1, 2
+
+    def __init__(self, cfg, device, seed: int = 77):
+        if not torch.cuda.is_available():
+            raise MusicXLError('XLEngine needs a GPU: the product path has no CPU fallback')
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        assert cfg.d_model % 8 == 0 and cfg.d_inner % 8 == 0 and cfg.n_head * cfg.d_head == cfg.d_model
+        assert cfg.d_head in (16, 32, 64), 'HIP attention kernels cover d_head 16/32/64 (all reference presets)'
+        assert cfg.mem_len % 8 == 0 and cfg.mem_len > 0
+        assert cfg.same_length and cfg.div_val == 1 and cfg.d_embed == cfg.d_model
+        self.layout = ParamLayout(cfg)
+        n = self.layout.total
+        self.P = torch.zeros(n, device=self.dev, dtype=torch.float32)      # master weights
+        self.W = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)     # MFMA operands
+        self.G: Optional[torch.Tensor] = None                              # grads (allocated on first train step)
+        self.m: Optional[torch.Tensor] = None
+        self.v: Optional[torch.Tensor] = None
+        self.step_count = 0
+        self.base_seed = seed
+        self._ws: Dict[Tuple, _WS] = {}
+        self._sumsq = torch.zeros(1, device=self.dev)
+        self.init_weights(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def p32(self, name):
+        return self.layout.view(self.P, name)
+
+    def w16(self, name):
+        return self.layout.view(self.W, name)
+
+    def g32(self, name):
+        return self.layout.view(self.G, name)
+
+    def _lw(self, l, suffix, buf=None):
+        return self.layout.view(self.W if buf is None else buf, f'transformer.layers.{l}.{suffix}')
+
+    def init_weights(self, seed: int):
+        """upstream `_init_weights`: N(0, init_std) linears / embedding / r_*_bias / cluster_weight, LayerNorm weight
+        N(1, init_std), biases 0."""
+        g = torch.Generator().manual_seed(seed)
+        std = self.cfg.init_std
+        host = torch.zeros(self.layout.total)
+        for name in self.layout.real_names():
+            off, shape = self.layout.entries[name]
+            n = math.prod(shape)
+            if name.endswith('layer_norm.weight'):
+                host[off:off + n] = 1.0 + std * torch.randn(n, generator=g)
+            elif name.endswith('.bias') and 'r_r_bias' not in name and 'r_w_bias' not in name:
+                pass
+            elif name.endswith('cluster_bias'):
+                pass
+            else:
+                host[off:off + n] = std * torch.randn(n, generator=g)
+        self.P.copy_(host)
+        self.sync_weights()
+
+    def sync_weights(self):
+        ops.cast_bf16(self.P, self.W)
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        sd = OrderedDict()
+        for name in self.layout.real_names():
+            sd[name] = self.p32(name).detach().cpu().clone()
+        sd['crit.out_layers.0.weight'] = sd['transformer.word_emb.emb_layers.0.weight']  # tied
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        missing = []
+        for name in self.layout.real_names():
+            if name in sd:
+                self.p32(name).copy_(sd[name].to(torch.float32).reshape(self.layout.entries[name][1]))
+            else:
+                missing.append(name)
+        if strict and missing:
+            raise KeyError(f'missing parameters: {missing[:4]}...')
+        self.sync_weights()
+
+    def num_parameters(self) -> int:
+        return sum(math.prod(self.layout.entries[n][1]) for n in self.layout.real_names())
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, T, Kc, train) -> _WS:
+        key = (B, T, Kc, train)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        c, dev = self.cfg, self.dev
+        d, Fi, H, L, M = c.d_model, c.d_inner, c.n_head, c.n_layer, c.mem_len
+        N = B * T
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        ws = _WS()
+        keep = L if train else 1   # eval reuses one slot per activation kind
+        ws.phi = torch.empty(M, d, **bf)
+        ws.h = [torch.empty(N, d, **bf) for _ in range(L + 1)] if train else [torch.empty(N, d, **bf) for _ in range(2)]
+        ws.cat = [torch.empty(B, Kc, d, **bf) for _ in range(keep)] if Kc > T else None
+        ws.qkv = [torch.empty(B, Kc, 3 * d, **bf) for _ in range(keep)]
+        ws.rd = [torch.empty(M, d, **bf) for _ in range(keep)]
+        ws.av = [torch.empty(N, d, **bf) for _ in range(keep)]
+        ws.lse = [torch.empty(B, H, T, **f32) for _ in range(keep)]
+        ws.tmp = torch.empty(N, d, **bf)
+        ws.h1 = [torch.empty(N, d, **bf) for _ in range(keep)]
+        ws.a = [torch.empty(N, Fi, **bf) for _ in range(keep)]
+        if train:
+            ws.z1 = [torch.empty(N, d, **bf) for _ in range(L)]
+            ws.z2 = [torch.empty(N, d, **bf) for _ in range(L)]
+            ws.st1 = [torch.empty(2, N, **f32) for _ in range(L)]
+            ws.st2 = [torch.empty(2, N, **f32) for _ in range(L)]
+            ws.hid_d = torch.empty(N, d, **bf)
+            # backward scratch
+            ws.dA = torch.empty(N, d, **bf)      # gradient stream a (residual path)
+            ws.dB = torch.empty(N, d, **bf)      # gradient stream b (GEMM path)
+            ws.dC = torch.empty(N, d, **bf)
+            ws.dD = torch.empty(N, d, **bf)
+            ws.dF = torch.empty(N, Fi, **bf)
+            ws.dqkv = torch.empty(B, Kc, 3 * d, **bf)
+            ws.delta = torch.empty(B, H, T, **f32)
+            ws.dg = torch.empty(B, H, T, M, **bf)
+            ws.qr = torch.empty(B, T, d, **bf)
+            ws.d_rd = torch.empty(M, d, **f32)
+            ws.d_rd16 = torch.empty(M, d, **bf)
+            ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
+        ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32)
+        ws.nll = torch.empty(B, max(T - 1, 1), **f32)
+        ws.hlse = torch.empty(N, 2, **f32)
+        ws.acc = torch.zeros(2, **f32)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _site(self, l, k):
+        return 8 + 8 * l + k
+
+    def forward(self, input_ids: torch.Tensor, mems: Optional[Sequence[torch.Tensor]] = None,
+                labels: Optional[torch.Tensor] = None, train: bool = False, want_logprobs: bool = True):
+        """input_ids (B, T) int64 on device; mems: list of L tensors (B, M, d) bf16 (batch-major) or None (= zero mems).
+        Returns dict(loss, losses, logprobs, mems).  In train mode activations are kept for `backward()`."""
+        c = self.cfg
+        B, T = input_ids.shape
+        d, H, dh, L, M, Fi = c.d_model, c.n_head, c.d_head, c.n_layer, c.mem_len, c.d_inner
+        V, cut = c.vocab_size, tuple(c.cutoffs)
+        N = B * T
+        has_mem = mems is not None
+        Kc = T + (M if has_mem else 0)
+        ws = self._workspace(B, T, Kc, train)
+        p = float(c.dropout) if train else 0.0
+        seed = (self.base_seed << 20) + self.step_count
+        ids = input_ids.contiguous()
+        ws.ids, ws.B, ws.T, ws.Kc, ws.p, ws.seed, ws.has_mem = ids, B, T, Kc, p, seed, has_mem
+
+        ops.sinusoid_table(M, d, c.clamp_len, self.dev, drop_p=p, seed=seed, site=self.SITE_POS, out=ws.phi)
+        E = self.w16('transformer.word_emb.emb_layers.0.weight')
+        ops.embed_fwd(ids, E, ws.h[0], math.sqrt(d), drop_p=p, seed=seed, site=self.SITE_EMB)
+        new_mems = [] if not train else None
+        st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+                  o_bs=T * d, o_rs=d)
+        for l in range(L):
+            s = l if train else 0
+            h_in = ws.h[l] if train else ws.h[l & 1]
+            h_out = ws.h[l + 1] if train else ws.h[(l + 1) & 1]
+            if has_mem:
+                cat = ws.cat[s]
+                cat[:, :M].copy_(mems[l])
+                cat[:, M:].copy_(h_in.view(B, T, d))
+                x_qkv = cat.view(B * Kc, d)
+            else:
+                x_qkv = h_in
+            if new_mems is not None:
+                if has_mem:
+                    new_mems.append(cat[:, Kc - M:].clone())
+                elif T >= M:
+                    new_mems.append(h_in.view(B, T, d)[:, T - M:].clone())
+                else:
+                    nm = torch.zeros(B, M, d, device=self.dev, dtype=torch.bfloat16)
+                    nm[:, M - T:].copy_(h_in.view(B, T, d))
+                    new_mems.append(nm)
+            qkv = ws.qkv[s]
+            ops.gemm(x_qkv, self._lw(l, 'dec_attn.qkv_net.weight'), qkv.view(B * Kc, 3 * d), B * Kc, 3 * d, d)
+            ops.gemm(ws.phi, self._lw(l, 'dec_attn.r_net.weight'), ws.rd[s], M, d, d)
+            ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[s],
+                            self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
+                            ws.av[s], ws.lse[s], **st)
+            ops.gemm(ws.av[s], self._lw(l, 'dec_attn.o_net.weight'), ws.tmp, N, d, d)
+            ops.ln_residual_fwd(ws.tmp, h_in, self._lw(l, 'dec_attn.layer_norm.weight', self.P),
+                                self._lw(l, 'dec_attn.layer_norm.bias', self.P), ws.h1[s],
+                                ws.z1[l] if train else None, ws.st1[l][0] if train else None,
+                                ws.st1[l][1] if train else None, eps=c.layer_norm_epsilon, drop_p=p, seed=seed,
+                                site=self._site(l, 0))
+            fl = F.GEMM_BIAS | F.GEMM_RELU | (F.GEMM_DROPOUT if p > 0 else 0)
+            ops.gemm(ws.h1[s], self._lw(l, 'pos_ff.CoreNet.0.weight'), ws.a[s], N, Fi, d, flags=fl,
+                     bias=self._lw(l, 'pos_ff.CoreNet.0.bias', self.P), drop_p=p, seed=seed, site=self._site(l, 1))
+            ops.gemm(ws.a[s], self._lw(l, 'pos_ff.CoreNet.3.weight'), ws.tmp, N, d, Fi, flags=F.GEMM_BIAS,
+                     bias=self._lw(l, 'pos_ff.CoreNet.3.bias', self.P))
+            ops.ln_residual_fwd(ws.tmp, ws.h1[s], self._lw(l, 'pos_ff.layer_norm.weight', self.P),
+                                self._lw(l, 'pos_ff.layer_norm.bias', self.P), h_out,
+                                ws.z2[l] if train else None, ws.st2[l][0] if train else None,
+                                ws.st2[l][1] if train else None, eps=c.layer_norm_epsilon, drop_p=p, seed=seed,
+                                site=self._site(l, 2))
+        hid = ws.h[L] if train else ws.h[L & 1]
+        if p > 0:
+            ops.dropout(hid, ws.hid_d, p, seed=seed, site=self.SITE_FINAL)
+            hid = ws.hid_d
+        ws.hid = hid
+        nrow = self.layout.n_head_rows
+        head_w = self.W[:self.layout.head_rows_padded * d].view(self.layout.head_rows_padded, d)
+        boff = self.layout.entries['crit.out_layers.0.bias'][0]
+        head_b = self.P[boff:boff + nrow]
+        ops.gemm(hid, head_w, ws.logits, N, nrow, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=head_b)
+        out = dict(loss=None, losses=None, logprobs=None, mems=new_mems)
+        if labels is not None:
+            lab = labels.contiguous().clone()
+            ops.label_guard(lab, c.eos_token_id)       # transformer_xl.py:176-182
+            ws.labels = lab
+            ws.acc.zero_()
+            ops.adaptive_nll_fwd(ws.logits, lab, ws.nll, ws.hlse, ws.acc, B, T, V, cut)
+            out['losses'] = ws.nll
+            out['loss'] = ws.acc[0] / ws.acc[1]        # mean over non-zero per-token losses (:200); stays on device
+        if want_logprobs and (labels is None or not train):
+            lp = torch.empty(N, V, device=self.dev, dtype=torch.float32)
+            ops.adaptive_logprob(ws.logits, lp, N, V, cut)
+            out['logprobs'] = lp.view(B, T, V)
+        self._last = ws
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def zero_grad(self):
+        if self.G is None:
+            self.G = torch.zeros_like(self.P)
+        else:
+            self.G.zero_()
+
+    @staticmethod
+    def _ks(m, n):
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        return max(1, min(16, 512 // max(tiles, 1)))
+
+    def backward(self, grad_scale: float = 1.0, layer_done=None):
+        """Gradients of `loss` from the last train-mode forward, accumulated (+=) into self.G.
+        `layer_done(name_prefix, lo, hi)` is called once a contiguous slice [lo, hi) of G is final (for overlap of the
+        data-parallel all-reduce with the rest of the backward)."""
+        ws, c = self._last, self.cfg
+        B, T, Kc, p, seed = ws.B, ws.T, ws.Kc, ws.p, ws.seed
+        d, H, dh, L, M, Fi = c.d_model, c.n_head, c.d_head, c.n_layer, c.mem_len, c.d_inner
+        V, cut = c.vocab_size, tuple(c.cutoffs)
+        N = B * T
+        G = self.G
+        nrow, nrow_p = self.layout.n_head_rows, self.layout.head_rows_padded
+        AT = F.GEMM_OUT_F32_ATOMIC
+        dscale = 1.0 / (1.0 - p) if p > 0 else 1.0
+
+        def gw(l, suffix):
+            return self._lw(l, suffix, G)
+
+        # ---- head
+        ops.adaptive_nll_bwd(ws.logits, ws.labels, ws.nll, ws.hlse, ws.acc, ws.dlogits, B, T, V, cut, grad_scale)
+        head_w = self.W[:nrow_p * d].view(nrow_p, d)
+        g_head_w = G[:nrow_p * d].view(nrow_p, d)
+        boff = self.layout.entries['crit.out_layers.0.bias'][0]
+        ops.colsum(ws.dlogits, G[boff:boff + nrow], N, nrow)
+        ops.gemm(ws.dlogits, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
+                 ksplits=self._ks(nrow_p, d))
+        dy, dy2 = ws.dA, None
+        ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True)
+        if p > 0:
+            ops.dropout(dy, dy, p, seed=seed, site=self.SITE_FINAL)
+        st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+                  o_bs=T * d, o_rs=d)
+        for l in reversed(range(L)):
+            h_in = ws.h[l]
+            # LN2 backward: dres -> dC (into h1 via residual), dx -> dD (into f_out)
+            ops.ln_residual_bwd(dy, dy2, ws.z2[l], ws.st2[l][0], ws.st2[l][1], self._lw(l, 'pos_ff.layer_norm.weight', self.P),
+                                ws.dC, ws.dD, gw(l, 'pos_ff.layer_norm.weight'), gw(l, 'pos_ff.layer_norm.bias'),
+                                drop_p=p, seed=seed, site=self._site(l, 2))
+            # FFN2
+            ops.colsum(ws.dD, gw(l, 'pos_ff.CoreNet.3.bias'), N, d)
+            ops.gemm(ws.dD, ws.a[l], gw(l, 'pos_ff.CoreNet.3.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(d, Fi))
+            ops.gemm(ws.dD, self._lw(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, trans_b=True, flags=F.GEMM_RELU_BWD,
+                     aux=ws.a[l], alpha=dscale)
+            # FFN1
+            ops.colsum(ws.dF, gw(l, 'pos_ff.CoreNet.0.bias'), N, Fi)
+            ops.gemm(ws.dF, ws.h1[l], gw(l, 'pos_ff.CoreNet.0.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(Fi, d))
+            ops.gemm(ws.dF, self._lw(l, 'pos_ff.CoreNet.0.weight'), ws.dD, N, d, Fi, trans_b=True)
+            # LN1 backward with both streams into h1: dC (residual) + dD (FFN1 dX)
+            ops.ln_residual_bwd(ws.dC, ws.dD, ws.z1[l], ws.st1[l][0], ws.st1[l][1],
+                                self._lw(l, 'dec_attn.layer_norm.weight', self.P), ws.dA, ws.dB,
+                                gw(l, 'dec_attn.layer_norm.weight'), gw(l, 'dec_attn.layer_norm.bias'), drop_p=p,
+                                seed=seed, site=self._site(l, 0))
+            # now dA = grad into h_in via residual, dB = grad into o_net output
+            ops.gemm(ws.dB, ws.av[l], gw(l, 'dec_attn.o_net.weight'), d, d, N, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(d, d))
+            ops.gemm(ws.dB, self._lw(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d, trans_b=True)   # d attn_vec
+            qkv, dqkv = ws.qkv[l], ws.dqkv
+            ws.d_rd.zero_()
+            ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
+                            self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
+                            ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
+                            ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
+                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr, **st)
+            # r_net: dW_r = d_rd^T . phi
+            ops.cast_bf16(ws.d_rd, ws.d_rd16)
+            ops.gemm(ws.d_rd16, ws.phi, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(d, d))
+            # qkv_net
+            if ws.has_mem:
+                dqkv[:, :M, :d].zero_()   # memory rows carry no query gradient
+                x_qkv = ws.cat[l].view(B * Kc, d)
+            else:
+                x_qkv = h_in
+            ops.gemm(dqkv.view(B * Kc, 3 * d), x_qkv, gw(l, 'dec_attn.qkv_net.weight'), 3 * d, d, B * Kc, trans_a=True,
+                     trans_b=True, flags=AT, ksplits=self._ks(3 * d, d))
+            if ws.has_mem:
+                # only the current rows receive gradient (mems are detached): per-batch GEMM on the last T rows
+                ops.gemm_batched(dqkv[:, M:], self._lw(l, 'dec_attn.qkv_net.weight'), ws.dB, T, d, 3 * d, lda=3 * d,
+                                 ldb=d, ldc=d, trans_b=True, batch=B, bdiv=1, sA=(Kc * 3 * d, 0), sB=(0, 0), sC=(T * d, 0))
+            else:
+                ops.gemm(dqkv.view(N, 3 * d), self._lw(l, 'dec_attn.qkv_net.weight'), ws.dB, N, d, 3 * d, trans_b=True)
+            dy, dy2 = ws.dA, ws.dB
+            if layer_done is not None:
+                layer_done(l)
+        E_g = self.layout.view(G, 'transformer.word_emb.emb_layers.0.weight')
+        ops.embed_bwd(ws.ids, dy, E_g, math.sqrt(d), drop_p=p, seed=seed, site=self.SITE_EMB, dout2=dy2)
+
+    # ------------------------------------------------------------------ optimiser
+    def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
+                       grad_scale: float = 1.0):
+        if self.m is None:
+            self.m = torch.zeros_like(self.P)
+            self.v = torch.zeros_like(self.P)
+        self.step_count += 1
+        self._sumsq.zero_()
+        if max_grad_norm and max_grad_norm > 0:
+            ops.sumsq(self.G, self._sumsq)
+        ops.adamw_step(self.P, self.G, self.m, self.v, self.W, self.layout.n_decay, lr, betas[0], betas[1], eps,
+                       weight_decay, self.step_count, self._sumsq if max_grad_norm else None, max_grad_norm or 0.0,
+                       grad_scale)
+
+    def grad_norm(self) -> torch.Tensor:
+        return self._sumsq.sqrt()
