@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Transformer-XL training throughput on synthetic token streams (BASELINE.json metric
+"train tokens/sec/GPU (TransfoXL seq2048 bf16)"), one process per GPU, data-parallel over RCCL.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = forward + backward + gradient all-reduce + clip + AdamW on one batch of (B, T) synthetic ids per GPU
+(weak scaling).  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline     -- the dominant kernel, timed live with HIP events on the launch stream
+  cpu_baseline -- the CPU oracle (oracle/transfoxl_ref.py, the reference-style dense fp32 path) on the host cores,
+                  rank 0 at N=1 only, on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[2] / SURVEY C3: the config the metric is quoted on (seq 2048); fits one GPU
+    'c3': dict(name='TransfoXL 12L/768d H12 dh64 F3072 T=2048 M=2048 V=1190 cutoffs=[] (SURVEY C3, mode R: fresh zero mems)',
+               size='base', n_layer=12, T=2048, M=2048, B=16),
+    # BASELINE.json configs[1] / SURVEY C2
+    'c2': dict(name='TransfoXL 6L/512d H8 dh64 F2048 T=1024 M=1024 V=1190 cutoffs=[] (SURVEY C2, mode R)',
+               size='small', n_layer=6, T=1024, M=1024, B=32),
+    'tiny': dict(name='debug 2L/128d T=256 M=256 (SURVEY C1 shape)', size='debug', n_layer=2, T=256, M=256, B=8),
+}
+V = 1190
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_token_fwd(L, d, T, M, Vv):
+    """SURVEY 8(d), mode R: each query has M visible slots (BD needs all of them: 2dM), AC and PV (2d each per key) only the
+    n_bar = (T+1)/2 real ones (T <= M); GEMMs 24 d^2; head 2 d V."""
+    nbar = (T + 1) / 2 if T <= M else M
+    return L * (24 * d * d + 4 * d * nbar + 2 * d * M) + 2 * d * Vv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c3', choices=list(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (sequences)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+    else:
+        dist = None
+
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    from symbolic_music_generation_amd.dist import GradSync
+    from symbolic_music_generation_amd import ops
+
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl['B']
+    T, M = wl['T'], wl['M']
+    cfg = MyTransfoXLConfig(wl['size'], max_length=T, vocab_size=V, n_layer=wl['n_layer'], mem_len=M, cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
+    eng = model.engine
+    sync = GradSync(eng)
+    gen = torch.Generator(device='cpu').manual_seed(77 + rank)          # musicnlp/util/config.json "random-seed": 77
+    ids = torch.randint(4, V, (B, T), generator=gen).to(dev)            # skip the special ids
+    labels = ids.clone()
+    # cosine schedule with warm-up, as TrainArgs defaults (train.py:165-190) -- lr value is irrelevant to throughput
+    lr, wd = 3e-4, 0.1
+
+    # ---- live roofline timing of the dominant kernel (relattn_bwd dkv+dq launches)
+    timed = {'on': False, 'ev': []}
+    orig_bwd = ops.relattn_bwd
+
+    def timed_relattn_bwd(*a, **k):
+        if timed['on']:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d_rd = k.pop('d_rd', None)
+            qr = k.pop('qr_buf', None)
+            s.record()
+            orig_bwd(*a, **k)          # the three attention-backward launches only
+            e.record()
+            timed['ev'].append((s, e))
+            if d_rd is not None:       # the dRd contraction, outside the bracket
+                H_, dh_, T_, M_, B_ = k['H'], k['dh'], k['T'], k['M'], k['B']
+                d_ = H_ * dh_
+                ops.add_rowbias(a[0], k['q_bs'], k['q_rs'], a[5].reshape(-1), qr, B_, T_, d_)
+                ops.gemm_batched(a[13], qr, d_rd, M_, dh_, T_, lda=M_, ldb=d_, ldc=d_, trans_a=True, trans_b=True,
+                                 flags=ops.GEMM_OUT_F32_ATOMIC, batch=B_ * H_, bdiv=H_, sA=(H_ * T_ * M_, T_ * M_),
+                                 sB=(T_ * d_, dh_), sC=(0, dh_))
+        else:
+            orig_bwd(*a, **k)
+
+    if not args.no_roofline:
+        ops.relattn_bwd = timed_relattn_bwd
+
+    def step():
+        eng.zero_grad()
+        model(input_ids=ids, labels=labels)
+        eng.backward(layer_done=sync.layer_done)
+        sync.finish()
+        eng.optimizer_step(lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_scale=1.0 / world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timed['on'] = not args.no_roofline
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timed['on'] = False
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = model(input_ids=ids, labels=labels).loss.item()
+
+    if rank == 0:
+        tokens = B * T * world * args.steps
+        d, L = cfg.d_model, cfg.n_layer
+        f_fwd = flops_per_token_fwd(L, d, T, M, V)
+        out = {
+            'metric': 'train tokens/sec (TransfoXL seq2048 bf16), whole job', 'value': tokens / dt, 'unit': 'tokens/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T, 'mem_len': M,
+                       'parallelism': f'dp{world}', 'dropout': cfg.dropout, 'final_loss': loss,
+                       'train_flops_per_token': 3 * f_fwd,
+                       'whole_step_mfma_frac': 3 * f_fwd * tokens / dt / world / (MFMA_BF16_PEAK_TFLOPS * 1e12)},
+        }
+        if not args.no_roofline and timed['ev']:
+            ms = sum(s.elapsed_time(e) for s, e in timed['ev']) / len(timed['ev'])
+            # algorithmic flops of ONE attention-backward call (one layer, this rank's batch): backward = 2 x forward of the
+            # banded attention core, forward = B*T*(4*d*n_bar + 2*d*M)
+            nbar = (T + 1) / 2 if T <= M else M
+            alg = 2 * B * T * (4 * d * nbar + 2 * d * M)
+            ach = alg / (ms * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'relattn_bwd (delta + dq + dkv launches, one layer)', 'bound': 'mfma', 'achieved': ach,
+                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS,
+                               'traffic': None, 'avg_launch_ms': ms, 'launches_timed': len(timed['ev'])}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl, T, M)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl, T, M):
+    """The oracle (reference-style dense fp32 TransfoXL, oracle/transfoxl_ref.py) on the host cores: train steps
+    (fwd + bwd + clip + AdamW) on a bounded sample: B=1 sequence of the same T/M and, to stay within ~30 s of CPU work,
+    at most 3 of the workload's layers (per-layer cost is identical; embedding + head are included once), scaled to the
+    full depth in `value`."""
+    from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
+    torch.manual_seed(77)
+    L_full = wl['n_layer']
+    L_s = min(L_full, 3)
+    c = RefXLConfig.from_preset(wl['size'], vocab_size=V, max_length=T, mem_len=M, cutoffs=[], n_layer=L_s)
+    m = RefTransfoXLLMHeadModel(c).train()
+    ids = torch.randint(4, V, (1, T))
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.1)
+    times = []
+    for i in range(2):
+        t = time.perf_counter()
+        o = m(ids, labels=ids)
+        o.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        times.append(time.perf_counter() - t)
+    t_full = times[-1] * L_full / L_s
+    return {'value': T / t_full, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 train step after 1 warm-up, B=1 x T={T} (M={M}), fp32, {L_s} of {L_full} layers timed '
+                      f'({times[-1]:.1f} s) and scaled x{L_full}/{L_s}'}
+
+
+if __name__ == '__main__':
+    main()
