@@ -1,0 +1,312 @@
+// Autoregressive decode step for Transformer-XL: everything a step needs lives on the device
+// (position counter, RNG counter, token buffer), so the whole step is capture-safe and replays as a hipGraph.
+//
+// Upstream recomputes K/V of all mem_len memory rows every step (cat(mems, h) through qkv_net).  Because qkv_net has no
+// bias, caching the *projected* K/V rows is numerically the same computation done once: a ring of M slots per layer,
+// slot = position mod M.  A query at position t sees distances d = 0..M-1 (same_length window); slots never written
+// are the zero mems of `init_mems` (k = v = 0): they still take softmax mass through the positional term, exactly as
+// upstream, because the cache is zero-initialised and BD is evaluated for all M distances.
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+// h0[b] = E[ids[b][t]] * scale          (t read from device memory)
+__global__ void decode_embed_kernel(const long long* ids, int ld_ids, const int* t_dev, const bf16_t* E, bf16_t* out, int B,
+                                    int d, int V, float scale) {
+    const int chunks = d >> 3;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * chunks) return;
+    const int b = gid / chunks, c = gid % chunks;
+    long long id = ids[(size_t)b * ld_ids + *t_dev];
+    if (id < 0 || id >= V) id = 0;
+    const bf16x8 e = *reinterpret_cast<const bf16x8*>(E + (size_t)id * d + c * 8);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = bf2f((bf16_t)e[j]) * scale;
+    u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(out + (size_t)b * d + c * 8) = o;
+}
+
+// cache[b][t mod M] = (k, v) of the current token (rows of the (B, 3d) qkv buffer)
+__global__ void kv_append_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, const int* t_dev, int B, int M, int d) {
+    const int chunks = d >> 3;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * chunks) return;
+    const int b = gid / chunks, c = gid % chunks;
+    const int slot = (*t_dev) % M;
+    const u32x4 k = *reinterpret_cast<const u32x4*>(qkv + (size_t)b * 3 * d + d + c * 8);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(qkv + (size_t)b * 3 * d + 2 * d + c * 8);
+    *reinterpret_cast<u32x4*>(kc + ((size_t)b * M + slot) * d + c * 8) = k;
+    *reinterpret_cast<u32x4*>(vc + ((size_t)b * M + slot) * d + c * 8) = v;
+}
+
+// bulk fill after the prompt forward: cache slots (p mod M) <- K/V rows of positions p in [max(0, T-M), T)
+__global__ void kv_fill_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, int B, int T, int M, int d) {
+    const int chunks = d >> 3;
+    const int keep = min(T, M);
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * keep * chunks) return;
+    const int c = (int)(gid % chunks);
+    const int r = (int)((gid / chunks) % keep);
+    const int b = (int)(gid / ((long long)chunks * keep));
+    const int pos = T - keep + r;
+    const int slot = pos % M;
+    const bf16_t* row = qkv + ((size_t)b * T + pos) * 3 * d;
+    *reinterpret_cast<u32x4*>(kc + ((size_t)b * M + slot) * d + c * 8) = *reinterpret_cast<const u32x4*>(row + d + c * 8);
+    *reinterpret_cast<u32x4*>(vc + ((size_t)b * M + slot) * d + c * 8) = *reinterpret_cast<const u32x4*>(row + 2 * d + c * 8);
+}
+
+// one workgroup per (head, batch row); dh = 8 * LPK, LPK lanes share one key row, 64/LPK keys per wave instruction
+template <int DH>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* kc, const bf16_t* vc,
+                                                          const bf16_t* rd, const float* rwb, const float* rrb,
+                                                          bf16_t* out, const int* t_dev, int B, int H, int M, float scale) {
+    constexpr int LPK = DH / 8;          // lanes per key row
+    constexpr int KPW = 64 / LPK;        // keys per wave per iteration
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);          // [M] scores -> probabilities
+    float* red = sc + M;                                 // [4][KPW... ] scratch: 4 * 64 * 8 floats max
+    __shared__ float wred[8];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int c8 = lane % LPK, ksub = lane / LPK;
+    const int d = H * DH;
+    const int t = *t_dev;
+    const int tm = t % M;
+
+    float qw[8], qr[8];
+    {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qkv + (size_t)b * 3 * d + h * DH + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float q = bf2f((bf16_t)qv[j]);
+            // mirror the training kernels: (q + bias) is rounded to bf16 before the contraction
+            qw[j] = bf2f(f2bf(q + rwb[h * DH + c8 * 8 + j]));
+            qr[j] = bf2f(f2bf(q + rrb[h * DH + c8 * 8 + j]));
+        }
+    }
+    const bf16_t* kb = kc + (size_t)b * M * d + h * DH + c8 * 8;
+    const bf16_t* vb = vc + (size_t)b * M * d + h * DH + c8 * 8;
+    const bf16_t* rb = rd + h * DH + c8 * 8;
+
+    // pass 1: scores
+    float mx = -1e30f;
+    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
+        const int s = s0 + ksub;
+        float acc = 0.f;
+        if (s < M) {
+            int dist = tm - s;
+            if (dist < 0) dist += M;
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (size_t)s * d);
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(rb + (size_t)dist * d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += qw[j] * bf2f((bf16_t)kv[j]) + qr[j] * bf2f((bf16_t)rv[j]);
+        }
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        acc *= scale;
+        if (s < M) {
+            if (c8 == 0) sc[s] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) wred[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float sum = 0.f;
+    for (int s = tid; s < M; s += 256) {
+        const float pv = __expf(sc[s] - mx);
+        sc[s] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) wred[4 + wid] = sum;
+    __syncthreads();
+    const float inv = 1.f / (wred[4] + wred[5] + wred[6] + wred[7]);
+
+    // pass 2: o = sum_s p_s v_s   (P rounded to bf16 like the training kernel's MFMA operand)
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = 0.f;
+    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
+        const int s = s0 + ksub;
+        if (s < M) {
+            const float pv = bf2f(f2bf(sc[s]));
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (size_t)s * d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vv[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) o[j] += __shfl_xor(o[j], off, 64);
+    }
+    if (ksub == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[wid * DH + c8 * 8 + j] = o[j];
+    }
+    __syncthreads();
+    if (tid < DH) {
+        const float v = (red[tid] + red[DH + tid] + red[2 * DH + tid] + red[3 * DH + tid]) * inv;
+        out[(size_t)b * d + h * DH + tid] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sampler: HF GenerationMixin.sample / greedy_search on log-probs (B, V): temperature -> top-k -> top-p ->
+// renormalise -> multinomial (musicnlp/trainer/eval.py:277-333 builds these arguments).  One workgroup per row;
+// bitonic sort of (value, index) in LDS (V <= 2048).  greedy = argmax (ties -> lowest index, like torch.argmax).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SORT_N = 2048;
+
+__global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl, int V, long long* ids, int ld_ids,
+                                                     const int* t_dev, unsigned long long* rng_ctr, unsigned long long seed,
+                                                     int do_sample, int top_k, float top_p, float temperature,
+                                                     float* out_probs) {
+    __shared__ float key[SORT_N];
+    __shared__ int idx[SORT_N];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logp + (size_t)b * ldl;
+    const float invt = 1.f / temperature;
+    for (int i = tid; i < SORT_N; i += 256) {
+        key[i] = i < V ? row[i] * invt : -INFINITY;
+        idx[i] = i;
+    }
+    __syncthreads();
+    // bitonic sort, descending by key, ties by ascending index
+    for (int k = 2; k <= SORT_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < SORT_N; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const float a = key[i], c = key[ixj];
+                    const int ia = idx[i], ic = idx[ixj];
+                    const bool a_first = (a > c) || (a == c && ia < ic);   // a should come before c in descending order
+                    if (up ? !a_first : a_first) {
+                        key[i] = c; key[ixj] = a; idx[i] = ic; idx[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int t = *t_dev;
+    long long* dst = ids + (size_t)b * ld_ids + t + 1;
+    if (!do_sample) {
+        if (tid == 0) *dst = idx[0];
+        return;
+    }
+    int keep = (top_k > 0 && top_k < V) ? top_k : V;
+    // softmax over the kept prefix (max is key[0]); serial prefix over <= V terms by one thread is negligible here
+    if (tid == 0) {
+        const float m = key[0];
+        float s = 0.f;
+        for (int i = 0; i < keep; i++) s += __expf(key[i] - m);
+        if (top_p > 0.f && top_p < 1.f) {
+            // HF TopPLogitsWarper: keep the smallest prefix whose cumulative probability exceeds top_p (>= 1 token)
+            float c = 0.f;
+            int kk = 0;
+            for (int i = 0; i < keep; i++) {
+                c += __expf(key[i] - m) / s;
+                kk = i + 1;
+                if (c >= top_p) break;
+            }
+            keep = kk;
+            s = 0.f;
+            for (int i = 0; i < keep; i++) s += __expf(key[i] - m);
+        }
+        // uniform in [0,1) from a counter-based hash (counter advanced by the advance kernel)
+        const unsigned long long ctr = *rng_ctr;
+        const uint32_t h1 = mxl_hash32((uint32_t)(ctr * 0x9E3779B97F4A7C15ULL >> 32) ^ mxl_hash32((uint32_t)b + 0x85ebca6bU * (uint32_t)seed));
+        const uint32_t h2 = mxl_hash32(h1 + (uint32_t)ctr + (uint32_t)(seed >> 32));
+        const float u = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+        float c = 0.f;
+        int pick = keep - 1;
+        for (int i = 0; i < keep; i++) {
+            c += __expf(key[i] - m) / s;
+            if (u < c) { pick = i; break; }
+        }
+        *dst = idx[pick];
+        if (out_probs) {   // diagnostic / test hook: renormalised probabilities of the kept support, in vocab order
+            for (int i = 0; i < V; i++) out_probs[(size_t)b * V + i] = 0.f;
+            for (int i = 0; i < keep; i++) out_probs[(size_t)b * V + idx[i]] = __expf(key[i] - m) / s;
+        }
+    }
+}
+
+__global__ void advance_kernel(int* t_dev, unsigned long long* rng_ctr) {
+    *t_dev += 1;
+    *rng_ctr += 1;
+}
+
+}  // namespace
+
+extern "C" int mxl_decode_embed(const void* ids, int ld_ids, const int* t_dev, const void* E, void* out, int B, int d,
+                                int V, float scale, void* stream) {
+    MXL_CHECK_ARG(ids && t_dev && E && out && B > 0 && (d % 8) == 0);
+    const int n = B * (d / 8);
+    hipLaunchKernelGGL(decode_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)ids,
+                       ld_ids, t_dev, (const bf16_t*)E, (bf16_t*)out, B, d, V, scale);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, void* stream) {
+    MXL_CHECK_ARG(qkv && kcache && vcache && t_dev && B > 0 && M > 0 && (d % 8) == 0);
+    const int n = B * (d / 8);
+    hipLaunchKernelGGL(kv_append_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)kcache, (bf16_t*)vcache, t_dev, B, M, d);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, void* stream) {
+    MXL_CHECK_ARG(qkv && kcache && vcache && B > 0 && T > 0 && M > 0 && (d % 8) == 0);
+    const long long n = (long long)B * (T < M ? T : M) * (d / 8);
+    hipLaunchKernelGGL(kv_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, T, M, d);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const void* rd,
+                                  const float* r_w_bias, const float* r_r_bias, void* out, const int* t_dev, int B, int H,
+                                  int dh, int M, float scale, void* stream) {
+    MXL_CHECK_ARG(qkv && kcache && vcache && rd && r_w_bias && r_r_bias && out && t_dev && B > 0 && H > 0 && M > 0);
+    const size_t shm = (size_t)M * 4 + 4 * 64 * 4;
+    MXL_CHECK_ARG(shm <= 64 * 1024);
+    dim3 grid(H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(DH) hipLaunchKernelGGL((decode_attn_kernel<DH>), grid, dim3(256), shm, s, (const bf16_t*)qkv, (const bf16_t*)kcache, \
+                                      (const bf16_t*)vcache, (const bf16_t*)rd, r_w_bias, r_r_bias, (bf16_t*)out, t_dev, B, H, M, scale)
+    switch (dh) {
+        case 16: LAUNCH(16); break;
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        default: return MXL_EUNSUPPORTED;
+    }
+#undef LAUNCH
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, const int* t_dev,
+                          unsigned long long* rng_ctr, unsigned long long seed, int B, int do_sample, int top_k, float top_p,
+                          float temperature, float* out_probs, void* stream) {
+    MXL_CHECK_ARG(logprobs && ids && t_dev && rng_ctr && B > 0 && V > 0 && V <= SORT_N && temperature > 0.f);
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logprobs, ldl, V, (long long*)ids, ld_ids,
+                       t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature, out_probs);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream) {
+    MXL_CHECK_ARG(t_dev && rng_ctr);
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_dev, rng_ctr);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

@@ -1,0 +1,162 @@
+"""Autoregressive generation for the TransfoXL engine: the on-device counterpart of `model.generate(...)` as the
+reference calls it (musicnlp/trainer/eval.py:277-333; HF 4.25.1 GenerationMixin.greedy_search / sample).
+
+    prompt forward (whole prompt, zero mems)  ->  K/V rings filled
+    loop:  [embed -> L x (qkv GEMM, kv append, ring attention, o GEMM, LN, FFN GEMMs, LN) -> head GEMM -> log-softmax
+            -> sampler -> advance]            one hipGraph replay per token, no host round trip
+
+Strategies mirrored from `MusicGenerator` (eval.py:277-326): greedy (do_sample=False) and sampling with
+`top_k`, `top_p`, `temperature` and renormalised logits.  `repetition_penalty` / `typical_p` / beam / contrastive search
+are accepted by the reference's argument checker but are out of this round's scope and raise.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import MusicXLError
+
+
+class XLDecoder:
+    def __init__(self, engine, batch: int, max_total_len: int, seed: int = 77):
+        self.eng = engine
+        c = engine.cfg
+        self.B, self.Tmax = batch, max_total_len
+        dev = engine.dev
+        d, M, L, Fi = c.d_model, c.mem_len, c.n_layer, c.d_inner
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        self.kc = [torch.zeros(batch, M, d, **bf) for _ in range(L)]
+        self.vc = [torch.zeros(batch, M, d, **bf) for _ in range(L)]
+        self.rd = None                                  # per-layer Rd tables (eval: no dropout on pos_emb)
+        self.ids = torch.zeros(batch, max_total_len + 1, device=dev, dtype=torch.int64)
+        self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.rng = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.seed = seed
+        self.h = [torch.empty(batch, d, **bf) for _ in range(2)]
+        self.qkv = torch.empty(batch, 3 * d, **bf)
+        self.av = torch.empty(batch, d, **bf)
+        self.tmp = torch.empty(batch, d, **bf)
+        self.h1 = torch.empty(batch, d, **bf)
+        self.a = torch.empty(batch, Fi, **bf)
+        self.logits = torch.empty(batch, engine.layout.head_rows_padded, device=dev, dtype=torch.float32)
+        self.logp = torch.empty(batch, c.vocab_size, device=dev, dtype=torch.float32)
+        self.graph = None
+        self._graph_key = None
+
+    def _tables(self):
+        if self.rd is None:
+            e, c = self.eng, self.eng.cfg
+            phi = ops.sinusoid_table(c.mem_len, c.d_model, c.clamp_len, e.dev)
+            self.rd = []
+            for l in range(c.n_layer):
+                rd = torch.empty(c.mem_len, c.d_model, device=e.dev, dtype=torch.bfloat16)
+                ops.gemm(phi, e._lw(l, 'dec_attn.r_net.weight'), rd, c.mem_len, c.d_model, c.d_model)
+                self.rd.append(rd)
+
+    def invalidate_tables(self):
+        """call after the weights change (r_net feeds the cached Rd tables)"""
+        self.rd = None
+        self.graph = None
+
+    # ---------------------------------------------------------------- prompt
+    def prefill(self, prompt: torch.Tensor, sampling: dict):
+        """Whole prompt through the training-shape kernels with zero mems (upstream first step), rings filled from the
+        per-layer qkv buffers, first new token sampled from the last position."""
+        e, c = self.eng, self.eng.cfg
+        B, Tp = prompt.shape
+        assert B == self.B and Tp + 1 <= self.Tmax + 1
+        self._tables()
+        for k in self.kc + self.vc:
+            k.zero_()
+        self.ids.zero_()
+        self.ids[:, :Tp].copy_(prompt)
+        sink_kc, sink_vc = self.kc, self.vc
+
+        def kv_sink(l, qkv):
+            ops.kv_fill(qkv, sink_kc[l], sink_vc[l], Tp)
+
+        out = e.forward(prompt.to(e.dev), mems=None, labels=None, train=False, want_logprobs=False, kv_sink=kv_sink)
+        ws = e._last
+        N = B * Tp
+        # log-probs of the last prompt position only
+        last = ws.logits.view(B, Tp, -1)[:, Tp - 1]
+        ops.adaptive_logprob(last, self.logp, B, c.vocab_size, tuple(c.cutoffs))
+        self.t_dev.fill_(Tp - 1)
+        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
+        ops.decode_advance(self.t_dev, self.rng)       # t = Tp: position of the token just sampled
+        return out
+
+    # ---------------------------------------------------------------- one token
+    def step(self, sampling: dict):
+        e, c = self.eng, self.eng.cfg
+        B, d, H, dh, M, Fi, L = self.B, c.d_model, c.n_head, c.d_head, c.mem_len, c.d_inner, c.n_layer
+        E = e.w16('transformer.word_emb.emb_layers.0.weight')
+        ops.decode_embed(self.ids, self.t_dev, E, self.h[0], math.sqrt(d))
+        for l in range(L):
+            h_in, h_out = self.h[l & 1], self.h[(l + 1) & 1]
+            ops.gemm(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
+            ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev)
+            ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
+                               e._lw(l, 'dec_attn.r_r_bias', e.P), self.av, self.t_dev, H, dh)
+            ops.gemm(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
+            ops.ln_residual_fwd(self.tmp, h_in, e._lw(l, 'dec_attn.layer_norm.weight', e.P),
+                                e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)
+            ops.gemm(self.h1, e._lw(l, 'pos_ff.CoreNet.0.weight'), self.a, B, Fi, d, flags=ops.GEMM_BIAS | ops.GEMM_RELU,
+                     bias=e._lw(l, 'pos_ff.CoreNet.0.bias', e.P))
+            ops.gemm(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.tmp, B, d, Fi, flags=ops.GEMM_BIAS,
+                     bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
+            ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
+                                e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
+        hid = self.h[L & 1]
+        nrow, nrow_p = e.layout.n_head_rows, e.layout.head_rows_padded
+        head_w = e.W[:nrow_p * d].view(nrow_p, d)
+        boff = e.layout.entries['crit.out_layers.0.bias'][0]
+        ops.gemm(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
+        ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
+        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
+        ops.decode_advance(self.t_dev, self.rng)
+
+    # ---------------------------------------------------------------- loop
+    def generate(self, prompt: torch.Tensor, max_length: int, do_sample: bool = False, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, temperature: float = 1.0, use_graph: bool = True) -> torch.Tensor:
+        """Returns (B, max_length) ids = prompt + continuation.  Like the reference (eos_token_id stays HF's default 0 =
+        [OMIT]) decoding runs to max_length."""
+        if max_length > self.Tmax:
+            raise MusicXLError(f'max_length {max_length} exceeds the decoder buffer {self.Tmax}')
+        sampling = dict(do_sample=do_sample, top_k=top_k or 0, top_p=top_p if top_p is not None else 1.0,
+                        temperature=temperature)
+        Tp = prompt.shape[1]
+        n_new = max_length - Tp
+        if n_new <= 0:
+            return prompt[:, :max_length]
+        self.prefill(prompt, sampling)
+        steps = n_new - 1
+        if steps > 0:
+            if use_graph:
+                key = tuple(sorted(sampling.items()))
+                if self.graph is None or self._graph_key != key:
+                    # warm-up on a side stream (first launches set function attributes), then capture one step
+                    state = (self.t_dev.clone(), self.rng.clone(), self.ids.clone(),
+                             [k.clone() for k in self.kc], [v.clone() for v in self.vc])
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self.step(sampling)
+                    torch.cuda.current_stream().wait_stream(s)
+                    self.graph = torch.cuda.CUDAGraph()       # hipGraph on ROCm
+                    with torch.cuda.graph(self.graph):
+                        self.step(sampling)
+                    self._graph_key = key
+                    # restore the state the two extra steps consumed
+                    self.t_dev.copy_(state[0]); self.rng.copy_(state[1]); self.ids.copy_(state[2])
+                    for a, b in zip(self.kc, state[3]):
+                        a.copy_(b)
+                    for a, b in zip(self.vc, state[4]):
+                        a.copy_(b)
+                for _ in range(steps):
+                    self.graph.replay()
+            else:
+                for _ in range(steps):
+                    self.step(sampling)
+        return self.ids[:, :max_length].clone()

@@ -210,3 +210,38 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
         # per (b, h): d_rd[:, h*dh:(h+1)*dh] (M x dh) += dG[b,h]^T (M x T) @ qr[b,:,h,:] (T x dh)
         gemm_batched(dg, qr_buf, d_rd, M, dh, T, lda=M, ldb=d, ldc=d, trans_a=True, trans_b=True,
                      flags=GEMM_OUT_F32_ATOMIC, batch=B * H, bdiv=H, sA=(H * T * M, T * M), sB=(T * d, dh), sC=(0, dh))
+
+
+# ------------------------------------------------------------------ decode
+def decode_embed(ids, t_dev, E, out, scale):
+    B, d = out.shape
+    check(lib().mxl_decode_embed(_p(ids), ids.stride(0), _p(t_dev), _p(E), _p(out), B, d, E.shape[0], float(scale),
+                                 _stream()), 'mxl_decode_embed')
+
+
+def kv_append(qkv, kc, vc, t_dev):
+    B, M, d = kc.shape
+    check(lib().mxl_kv_append(_p(qkv), _p(kc), _p(vc), _p(t_dev), B, M, d, _stream()), 'mxl_kv_append')
+
+
+def kv_fill(qkv, kc, vc, T):
+    B, M, d = kc.shape
+    check(lib().mxl_kv_fill(_p(qkv), _p(kc), _p(vc), B, T, M, d, _stream()), 'mxl_kv_fill')
+
+
+def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, scale=None):
+    B, M, d = kc.shape
+    scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(rd), _p(rwb), _p(rrb), _p(out), _p(t_dev), B, H, dh, M,
+                                   float(scale), _stream()), 'mxl_relattn_decode')
+
+
+def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=1.0, temperature=1.0, out_probs=None):
+    B, V = logprobs.shape
+    check(lib().mxl_sample(_p(logprobs), logprobs.stride(0), V, _p(ids), ids.stride(0), _p(t_dev), _p(rng_ctr), seed, B,
+                           int(do_sample), int(top_k or 0), float(top_p if top_p is not None else 1.0),
+                           float(temperature), _p(out_probs), _stream()), 'mxl_sample')
+
+
+def decode_advance(t_dev, rng_ctr):
+    check(lib().mxl_decode_advance(_p(t_dev), _p(rng_ctr), _stream()), 'mxl_decode_advance')

@@ -204,6 +204,25 @@ class MyTransfoXLLMHeadModel:
             inputs['input_ids'] = input_ids
         return inputs
 
+    def generate(self, input_ids: torch.Tensor = None, max_length: int = None, do_sample: bool = False,
+                 top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: float = 1.0, num_beams: int = 1,
+                 penalty_alpha=None, typical_p=None, repetition_penalty=None, early_stopping=None,
+                 renormalize_logits=None, use_graph: bool = True, seed: int = 77, **unused) -> torch.Tensor:
+        """`model.generate(**inputs, **args)` as called at musicnlp/trainer/eval.py:333 (greedy / sampling strategies)."""
+        from .generate import XLDecoder
+        if num_beams != 1 or penalty_alpha is not None:
+            raise NotImplementedError('beam / contrastive search are out of scope for the HIP decode path (SURVEY 8: A10)')
+        if typical_p is not None or (repetition_penalty not in (None, 1.0)):
+            raise NotImplementedError('typical_p / repetition_penalty are not implemented in the on-device sampler')
+        max_length = max_length or self.config.max_length_
+        B = input_ids.shape[0]
+        dec = getattr(self, '_decoder', None)
+        if dec is None or dec.B != B or dec.Tmax < max_length:
+            dec = self._decoder = XLDecoder(self.engine, B, max_length, seed=seed)
+        dec.invalidate_tables()
+        return dec.generate(input_ids.to(self.device), max_length, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                            temperature=temperature, use_graph=use_graph)
+
     # -- training hooks used by the trainer
     def backward(self, grad_scale: float = 1.0, layer_done=None):
         self.engine.backward(grad_scale=grad_scale, layer_done=layer_done)

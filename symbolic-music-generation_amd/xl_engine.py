@@ -213,7 +213,7 @@ class XLEngine:
         return 8 + 8 * l + k
 
     def forward(self, input_ids: torch.Tensor, mems: Optional[Sequence[torch.Tensor]] = None,
-                labels: Optional[torch.Tensor] = None, train: bool = False, want_logprobs: bool = True):
+                labels: Optional[torch.Tensor] = None, train: bool = False, want_logprobs: bool = True, kv_sink=None):
         """input_ids (B, T) int64 on device; mems: list of L tensors (B, M, d) bf16 (batch-major) or None (= zero mems).
         Returns dict(loss, losses, logprobs, mems).  In train mode activations are kept for `backward()`."""
         c = self.cfg
@@ -257,6 +257,8 @@ class XLEngine:
                     new_mems.append(nm)
             qkv = ws.qkv[s]
             ops.gemm(x_qkv, self._lw(l, 'dec_attn.qkv_net.weight'), qkv.view(B * Kc, 3 * d), B * Kc, 3 * d, d)
+            if kv_sink is not None:
+                kv_sink(l, qkv)   # decode prefill: projected K/V rows go to the per-layer rings
             ops.gemm(ws.phi, self._lw(l, 'dec_attn.r_net.weight'), ws.rd[s], M, d, d)
             ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[s],
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
