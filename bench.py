@@ -50,6 +50,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c3', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (sequences)')
+    ap.add_argument('--mode', default='train', choices=['train', 'decode'],
+                    help='train = headline metric; decode = AR decode tok/s (SURVEY C5), single GPU replicas')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -72,6 +74,8 @@ def main():
     from symbolic_music_generation_amd.dist import GradSync
     from symbolic_music_generation_amd import ops
 
+    if args.mode == 'decode':
+        return decode_bench(args, dev, rank, world)
     wl = WORKLOADS[args.workload]
     B = args.batch or wl['B']
     T, M = wl['T'], wl['M']
@@ -167,6 +171,47 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def decode_bench(args, dev, rank, world):
+    """TransfoXL 12L/768d cached-mem decode, batch 64 prompts x 256 tokens, top-k 8, generate to 2048,
+    one hipGraph replay per token.  A 'step' here = one generated token for the whole batch."""
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    from symbolic_music_generation_amd.generate import XLDecoder
+    B, Tp, M = args.batch or 64, 256, 2048
+    cfg = MyTransfoXLConfig('base', max_length=2048, vocab_size=V, mem_len=M, cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).eval()
+    dec = XLDecoder(model.engine, B, 2048, seed=77 + rank)
+    gen = torch.Generator(device='cpu').manual_seed(77 + rank)
+    prompt = torch.randint(4, V, (B, Tp), generator=gen).to(dev)
+    samp = dict(do_sample=True, top_k=8, top_p=1.0, temperature=1.0)
+    dec.prefill(prompt, samp)
+    for _ in range(max(args.warmup, 1)):
+        dec.step(samp)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dec.step(samp)
+    torch.cuda.synchronize()
+    steps = args.steps if args.steps != 10 else 512
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    d, L = cfg.d_model, cfg.n_layer
+    # algorithmic bytes per step (SURVEY 8d): weights once + projected K/V ring per sequence (+ Rd tables, L2-resident)
+    bytes_step = L * 12 * d * d * 2 + V * d * 2 + B * L * 2 * M * d * 2
+    if rank == 0:
+        out = {'metric': 'AR decode tokens/sec (TransfoXL 12L/768d, batch 64, cached mems, top-k 8, hipGraph step)',
+               'value': B * steps / dt, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup,
+               'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'bf16', 'data': 'synthetic',
+               'config': {'workload': 'SURVEY C5 decode: 12L/768d, M=2048, B=64 prompts x 256 tokens, top_k=8', 'batch': B},
+               'roofline': {'kernel': 'whole decode step (hipGraph replay)', 'bound': 'hbm',
+                            'achieved': bytes_step / (dt / steps) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': bytes_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                            'algorithmic_bytes_per_step': bytes_step}}
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(wl, T, M):

@@ -1,0 +1,231 @@
+"""Drop-in training surface for `musicnlp.trainer.train` (reference: musicnlp/trainer/train.py:31-368 and the
+`MyTrainer` of musicnlp/util/train/train_util_wrap.py:41-144).
+
+The reference drives HuggingFace `Trainer`; its optimisation semantics (AdamW beta 0.9/0.999 eps 1e-8, clip 1.0, cosine
+schedule with warm-up ratio or constant for the debug presets, per-size batch/lr/weight-decay presets, epoch eval + save,
+seed 77) are restated here around the HIP engine with explicit RCCL data parallelism.  No `Trainer`, no autograd.
+"""
+import json
+import math
+import os
+import time
+from collections import OrderedDict
+from typing import Callable, Dict, Iterable, List, Optional, Tuple, Union
+
+import torch
+
+from . import dist as mdist
+from .transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+from .vocab import MusicTokenizer
+
+PT_LOSS_PAD = -100  # musicnlp/util/train/train_util_wrap.py:22
+RANDOM_SEED = 77    # musicnlp/util/config.json "random-seed"
+
+
+def get_model_n_tokenizer(model_name: str, model_size: str, prec: int = 5, tokenize_scheme: str = 'vanilla',
+                          tokenizer_filename: Optional[str] = None, pitch_kind: str = None,
+                          tempo_bin: Union[bool, int] = None, model_config: Dict = None, device='cuda:0'):
+    """train.py:31-59.  Returns (tokenizer, model, model_meta)."""
+    if model_name not in ('transf-xl', 'reformer'):
+        raise ValueError(f'Model Name mismatch: {model_name!r} not in [transf-xl, reformer]')
+    if tokenize_scheme != 'vanilla':
+        raise NotImplementedError('wordpiece / pairmerge tokenizers need trained tokenizer files the reference does not '
+                                  'ship (SURVEY 2.1 #11)')
+    tokenizer = MusicTokenizer(precision=prec, pitch_kind=pitch_kind or 'midi', tempo_bin=tempo_bin)
+    assert tokenizer.precision == prec
+    if model_name == 'transf-xl':
+        cls_config, cls_model = MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    else:
+        from .reformer import MyReformerConfig, MyReformerModelWithLMHead
+        cls_config, cls_model = MyReformerConfig, MyReformerModelWithLMHead
+    config = cls_config(model_size=model_size, tokenizer=tokenizer, **(model_config or dict()))
+    tokenizer.model_max_length = max_length = config.max_length_
+    model_meta = OrderedDict({'model name': cls_model.cls_name, 'max length': max_length})
+    model_meta.update(config.model_meta)
+    return tokenizer, cls_model(config=config, device=device), model_meta
+
+
+class TrainArgs:
+    """train.py:62-228: per-size presets on top of the shared defaults."""
+    _big = dict(batch_size=32, learning_rate=3e-4, weight_decay=1e-2, lr_scheduler_type='cosine', num_train_epochs=64,
+                warmup_ratio=0.1)
+    model_name2preset = {
+        'transf-xl': {
+            'debug': dict(batch_size=2, learning_rate=1e-3, weight_decay=0, lr_scheduler_type='constant', num_train_epochs=64),
+            'debug-large': dict(batch_size=8, learning_rate=1e-3, weight_decay=0, lr_scheduler_type='constant', num_train_epochs=16),
+            'tiny': dict(_big), 'small': dict(_big), 'base': dict(_big), 'large': dict(_big),
+        },
+        'reformer': {
+            'debug': dict(batch_size=8, learning_rate=1e-3, weight_decay=0, lr_scheduler_type='constant', num_train_epochs=32),
+            'debug-large': dict(batch_size=8, learning_rate=1e-3, weight_decay=0, lr_scheduler_type='constant', num_train_epochs=32),
+            'tiny': dict(_big, num_train_epochs=32), 'small': dict(_big), 'base': dict(_big), 'large': dict(_big),
+        },
+    }
+
+    def __init__(self, model_name: str, model_size: str):
+        self.model_name, self.model_size = model_name, model_size
+
+    @staticmethod
+    def _get_default(model_name: str) -> Dict:  # train.py:165-190
+        return dict(do_train=True, do_eval=True, evaluation_strategy='epoch', adam_beta1=0.9, adam_beta2=0.999,
+                    adam_epsilon=1e-8, max_grad_norm=1, warmup_ratio=1e-2, logging_strategy='steps', logging_steps=1,
+                    save_strategy='epoch', bf16=True, gradient_accumulation_steps=1, load_best_model_at_end=True,
+                    metric_for_best_model='eval_loss', greater_is_better=False, output_dir=None)
+
+    def __call__(self, train_args: Dict = None, n_train: int = None) -> Dict:
+        args = self._get_default(self.model_name)
+        preset = dict(TrainArgs.model_name2preset[self.model_name][self.model_size])
+        if 'batch_size' in preset:
+            bsz = preset.pop('batch_size')
+            preset['per_device_train_batch_size'] = preset['per_device_eval_batch_size'] = bsz
+        args.update(preset)
+        if train_args:
+            args.update(train_args)
+        if n_train is not None:
+            bsz = args['per_device_train_batch_size'] * args.get('gradient_accumulation_steps', 1) * mdist.world_size()
+            args['steps_per_epoch'] = math.ceil(n_train / bsz)
+        return args
+
+
+def lr_at(step: int, total_steps: int, base_lr: float, scheduler: str, warmup_ratio: float) -> float:
+    """HF get_scheduler('cosine' | 'constant' | 'linear') with warm-up = ceil(total * ratio); `step` counts finished steps."""
+    warm = math.ceil(total_steps * warmup_ratio)
+    if scheduler == 'constant':
+        return base_lr
+    if step < warm:
+        return base_lr * step / max(1, warm)
+    prog = (step - warm) / max(1, total_steps - warm)
+    if scheduler == 'cosine':
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    if scheduler == 'linear':
+        return base_lr * max(0.0, 1.0 - prog)
+    raise ValueError(scheduler)
+
+
+def collate_clm(batch_ids: torch.Tensor, pad_token_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """DataCollatorForLanguageModeling(mlm=False) as configured at train.py:360: labels = input_ids, pad -> -100."""
+    labels = batch_ids.clone()
+    labels[labels == pad_token_id] = PT_LOSS_PAD
+    return batch_ids, labels
+
+
+def ntp_accuracy(pred_ids: torch.Tensor, labels: torch.Tensor) -> float:
+    """next-token accuracy over non-pad labels (train_util_wrap.py:115-121 / train.py:277-283)."""
+    preds, lab = pred_ids[:, :-1], labels[:, 1:]
+    msk = lab != PT_LOSS_PAD
+    return (preds[msk] == lab[msk]).float().mean().item() if msk.any() else float('nan')
+
+
+class MyTrainer:
+    """One optimisation step = fwd -> loss -> bwd -> (RCCL all-reduce overlapped with bwd) -> clip -> AdamW -> lr step.
+
+    `train_dataset` / `eval_dataset`: any sequence of equal-length int64 id tensors (already padded to max_length, the
+    contract of musicnlp/preprocess/dataset.py:361).  Under data parallelism each rank takes a strided shard.
+    """
+
+    def __init__(self, model, tokenizer: Optional[MusicTokenizer], train_dataset=None, eval_dataset=None,
+                 train_args: Dict = None, model_name: str = 'transf-xl', model_size: str = 'base',
+                 log_fn: Optional[Callable[[Dict], None]] = None, seed: int = RANDOM_SEED):
+        self.model, self.tokenizer = model, tokenizer
+        self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
+        n_train = len(train_dataset) if train_dataset is not None else None
+        self.args = TrainArgs(model_name, model_size)(train_args, n_train=n_train)
+        self.engine = model.engine
+        self.sync = mdist.GradSync(self.engine)
+        self.log_fn = log_fn or (lambda d: None)
+        self.seed = seed
+        self.global_step = 0
+        self.log_history: List[Dict] = []
+        self.pad_id = tokenizer.pad_token_id if tokenizer is not None else -1
+        self.best = (float('inf'), None)
+
+    # ---------------------------------------------------------------- one step
+    def training_step(self, input_ids: torch.Tensor, labels: torch.Tensor, lr: float) -> torch.Tensor:
+        a = self.args
+        self.model.train()
+        self.engine.zero_grad()
+        out = self.model(input_ids=input_ids, labels=labels)
+        self.engine.backward(layer_done=self.sync.layer_done)
+        self.sync.finish()
+        self.engine.optimizer_step(lr=lr, betas=(a['adam_beta1'], a['adam_beta2']), eps=a['adam_epsilon'],
+                                   weight_decay=a['weight_decay'], max_grad_norm=a['max_grad_norm'],
+                                   grad_scale=1.0 / mdist.world_size())
+        self.global_step += 1
+        return out.loss
+
+    def _shard(self, n: int, epoch: int, shuffle: bool) -> List[int]:
+        g = torch.Generator().manual_seed(self.seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
+        return idx[mdist.rank()::mdist.world_size()]
+
+    def _batches(self, ds, bsz: int, epoch: int, shuffle: bool):
+        idx = self._shard(len(ds), epoch, shuffle)
+        for i in range(0, len(idx) - bsz + 1 if shuffle else len(idx), bsz):
+            rows = [torch.as_tensor(ds[j]) for j in idx[i:i + bsz]]
+            if rows:
+                yield torch.stack(rows).to(self.model.device)
+
+    # ---------------------------------------------------------------- loops
+    def train(self, max_steps: Optional[int] = None) -> Dict:
+        a = self.args
+        bsz = a['per_device_train_batch_size']
+        spe = max(1, len(self.train_dataset) // (bsz * mdist.world_size()))
+        total = max_steps or spe * int(a['num_train_epochs'])
+        t0 = time.time()
+        done = False
+        for epoch in range(int(a['num_train_epochs'])):
+            for ids in self._batches(self.train_dataset, bsz, epoch, shuffle=True):
+                ids, labels = collate_clm(ids, self.pad_id)
+                lr = lr_at(self.global_step, total, a['learning_rate'], a['lr_scheduler_type'], a['warmup_ratio'])
+                loss = self.training_step(ids, labels, lr)
+                if self.global_step % a['logging_steps'] == 0:
+                    d = dict(step=self.global_step, epoch=epoch + self.global_step / spe % 1, learning_rate=lr,
+                             loss=loss.item())
+                    self.log_history.append(d)
+                    self.log_fn(d)
+                if self.global_step >= total:
+                    done = True
+                    break
+            if a['do_eval'] and self.eval_dataset is not None:
+                ev = self.evaluate()
+                ev.update(step=self.global_step, epoch=epoch + 1)
+                self.log_history.append(ev)
+                self.log_fn(ev)
+                if a['output_dir'] and mdist.rank() == 0:
+                    ck = os.path.join(a['output_dir'], f'checkpoint-{self.global_step}')
+                    self.save_model(ck)
+                    if ev['eval_loss'] < self.best[0]:
+                        self.best = (ev['eval_loss'], ck)
+            if done:
+                break
+        if a['load_best_model_at_end'] and self.best[1] is not None:
+            self.model.load_state_dict(torch.load(os.path.join(self.best[1], 'pytorch_model.bin'), map_location='cpu'))
+        return dict(train_runtime=time.time() - t0, global_step=self.global_step)
+
+    @torch.no_grad()
+    def evaluate(self) -> Dict:
+        """eval loss + next-token accuracy; argmax on device, only (B, T) ids cross ranks (the reference gathers the full
+        (B, T, V) logits: trainer_eval_wrap.py:310-314)."""
+        self.model.eval()
+        bsz = self.args['per_device_eval_batch_size']
+        tot_loss, tot_n, hit, cnt = 0.0, 0, 0.0, 0.0
+        for ids in self._batches(self.eval_dataset, bsz, 0, shuffle=False):
+            ids, labels = collate_clm(ids, self.pad_id)
+            out = self.model(input_ids=ids, labels=labels)
+            preds = out.logits.argmax(-1)
+            msk = labels[:, 1:] != PT_LOSS_PAD
+            hit += (preds[:, :-1][msk] == labels[:, 1:][msk]).float().sum().item()
+            cnt += msk.sum().item()
+            tot_loss += out.loss.item() * ids.shape[0]
+            tot_n += ids.shape[0]
+        stats = torch.tensor([tot_loss, tot_n, hit, cnt], dtype=torch.float64, device=self.model.device)
+        if mdist.is_dist():
+            torch.distributed.all_reduce(stats)
+        s = stats.tolist()
+        self.model.train()
+        return dict(eval_loss=s[0] / max(s[1], 1), eval_ntp_acc=s[2] / max(s[3], 1))
+
+    def save_model(self, path: str):
+        self.model.save_pretrained(path)
+        with open(os.path.join(path, 'trainer_state.json'), 'w') as f:
+            json.dump(dict(global_step=self.global_step, log_history=self.log_history[-50:]), f)

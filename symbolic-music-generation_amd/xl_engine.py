@@ -56,13 +56,14 @@ class ParamLayout:
             self.entries[name] = (off, shape)
             n = math.prod(shape)
             # the head rows [E ; cluster_weight ; pad] must stay contiguous: no padding between them
-            off += n if name in ('transformer.word_emb.emb_layers.0.weight', 'crit.cluster_weight') else _r8(n)
+            contiguous_next = name in ('transformer.word_emb.emb_layers.0.weight', 'crit.cluster_weight')
+            off = off + n if contiguous_next else _r8(off + n)
         off = _r8(off)
         self.n_decay = off
         for name, shape in nodecay:
             self.entries[name] = (off, shape)
             n = math.prod(shape)
-            off += n if name == 'crit.out_layers.0.bias' and ncl else _r8(n)
+            off = off + n if (name == 'crit.out_layers.0.bias' and ncl) else _r8(off + n)
         self.total = _r8(off)
 
     def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:

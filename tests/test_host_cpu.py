@@ -1,0 +1,172 @@
+"""CPU-side tests: C-ABI surface, host logic (config presets, parameter layout, vocabulary, schedules), and the
+data-parallel gradient exchange over gloo with world_size 2.  No GPU compute."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from symbolic_music_generation_amd import _lib
+    decl = _lib.declared_functions()
+    assert len(decl) >= 25 and 'mxl_relattn_fwd' in decl and 'mxl_gemm_bf16' in decl
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decl:
+        assert hasattr(lib, name), f'{name} declared in include/musicxl.h but not exported'
+    assert _lib.lib().mxl_abi_version() == 1
+    assert b'invalid argument' in _lib.lib().mxl_error_string(-1)
+
+
+def test_cabi_argument_errors_without_gpu():
+    """argument validation happens before any launch: callable on a CPU-only box."""
+    from symbolic_music_generation_amd import _lib
+    L = _lib.lib()
+    assert L.mxl_gemm_bf16(None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 1.0, None, None, 0, 1, 0.0, 0, 0, None) == -1
+    assert L.mxl_relattn_fwd(*([None] * 8), 1, 1, 1, 64, 64, 1, 0, 0, 0, 0, 0, 0, 0, 1.0, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    from symbolic_music_generation_amd._lib import MusicXLError
+    with pytest.raises(MusicXLError):
+        MyTransfoXLLMHeadModel(MyTransfoXLConfig('debug', vocab_size=100, cutoffs=[]))
+
+
+def test_no_oracle_import_in_product_package():
+    pkg = os.path.join(ROOT, 'symbolic-music-generation_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py') and fn != 'smoke.py':
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f'{fn} imports the oracle'
+
+
+def test_config_presets_match_reference():
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig
+    from symbolic_music_generation_amd.vocab import MusicTokenizer
+    c = MyTransfoXLConfig('base')
+    assert (c.d_model, c.n_head, c.n_layer, c.d_head, c.d_inner, c.mem_len, c.clamp_len) == (768, 12, 12, 64, 3072, 256, 1024)
+    assert c.max_length_ == 2048 and c.same_length and c.div_val == 1 and c.eos_token_id == 0
+    d = MyTransfoXLConfig('debug')
+    assert (d.d_model, d.d_head, d.mem_len, d.clamp_len, d.max_length_) == (128, 16, 64, 64, 64)
+    tok = MusicTokenizer(pitch_kind='degree')
+    assert MyTransfoXLConfig('small', tokenizer=tok).cutoffs == [1000]
+    assert MyTransfoXLConfig('small', tokenizer=tok, cutoffs=[]).cutoffs == []      # kwargs override (train.py:526)
+    assert MyTransfoXLConfig('small', tokenizer=MusicTokenizer(pitch_kind='midi')).cutoffs == []
+    assert c.model_meta == dict(n_layer=12, hidden_size=768, ff_size=3072, seg_len=256, max_len=2048, vocab_size=c.vocab_size)
+
+
+def test_param_layout_counts_and_alignment():
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig
+    from symbolic_music_generation_amd.xl_engine import ParamLayout
+    lay = ParamLayout(MyTransfoXLConfig('base', vocab_size=418, cutoffs=[]))
+    n = sum(math.prod(lay.entries[k][1]) for k in lay.real_names())
+    assert n == 92_435_362                        # notebook/train/transformer-xl.ipynb:491 (92.4 M)
+    for k, (off, shape) in lay.entries.items():
+        if k not in ('crit.cluster_weight', 'crit.cluster_bias', '_pad.head_rows'):
+            assert off % 8 == 0, k
+    lay2 = ParamLayout(MyTransfoXLConfig('debug', vocab_size=1190, cutoffs=[1000]))
+    e, cw = lay2.entries['transformer.word_emb.emb_layers.0.weight'], lay2.entries['crit.cluster_weight']
+    assert cw[0] == e[0] + 1190 * 128 and lay2.head_rows_padded == 1192
+    # weight-decay split: biases and LayerNorm weights live past n_decay
+    for k, (off, _) in lay2.entries.items():
+        nodecay = ('bias' in k) or ('layer_norm' in k)
+        assert (off >= lay2.n_decay) == nodecay, k
+
+
+def test_vocab_sizes_and_golden_ids():
+    from symbolic_music_generation_amd.vocab import MusicTokenizer, MusicVocabulary
+    assert [len(MusicVocabulary(pitch_kind=k)) for k in ('midi', 'step', 'degree')] == [422, 560, 1190]
+    v = MusicVocabulary(pitch_kind='degree')
+    assert [v.tok2id[t] for t in ('[OMIT]', '[PAD]', '<bar>', '</s>', '<melody>', '<bass>', '<tup>', '</tup>')] == list(range(8))
+    assert v.toks['time_sig'] == ['TimeSig_rare', 'TimeSig_2/2', 'TimeSig_2/4', 'TimeSig_3/4', 'TimeSig_4/4', 'TimeSig_5/4',
+                                  'TimeSig_6/8', 'TimeSig_12/8']
+    assert len(v.toks['tempo']) == 203 and len(v.toks['key']) == 24 and len(v.toks['duration']) == 49
+    assert v.toks['duration'][:4] == ['d_rare', 'd_1/8', 'd_1/4', 'd_3/8'] and v.toks['duration'][-1] == 'd_6'
+    assert v.t2i('Tempo_20') == v.tok2id['Tempo_low'] and v.t2i('Tempo_300') == v.tok2id['Tempo_high']
+    assert v.t2i('d_13') == v.tok2id['d_rare'] and v.t2i('TimeSig_7/8') == v.tok2id['TimeSig_rare']
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample_score_ids.npz'))
+    assert {k: len(g[k]) for k in g.files} == dict(sample_full_midi=2512, sample_full_step=4291, sample_full_degree=3226,
+                                                   gen_broken=957)
+    for name, kind in [('sample_full_midi', 'midi'), ('sample_full_step', 'step'), ('sample_full_degree', 'degree'),
+                       ('gen_broken', 'degree')]:
+        tok = MusicTokenizer(pitch_kind=kind)
+        ids = g[name].astype(np.int64)
+        assert ids.min() >= 0 and ids.max() < tok.vocab_size
+        toks = tok.decode(ids).split()
+        assert tok.encode(' '.join(toks)) == ids.tolist()                 # round trip
+        # grammar: TimeSig Tempo [Key] ... pieces end with </s> except the broken generation (no EOS)
+        assert toks[0].startswith('TimeSig_') and toks[1].startswith('Tempo_')
+        assert (toks[-1] == '</s>') == (name != 'gen_broken')
+    enc = MusicTokenizer(pitch_kind='midi')('TimeSig_4/4 Tempo_120 <bar> p_1/4 d_1', padding='max_length', truncation=True,
+                                            max_length=8, return_tensors='pt')
+    assert list(enc.keys()) == ['input_ids'] and enc['input_ids'].shape == (1, 8) and enc['input_ids'][0, -1].item() == 1
+
+
+def test_schedule_and_trainargs():
+    from symbolic_music_generation_amd.trainer import TrainArgs, lr_at, collate_clm, ntp_accuracy
+    a = TrainArgs('transf-xl', 'base')()
+    assert a['per_device_train_batch_size'] == 32 and a['learning_rate'] == 3e-4 and a['weight_decay'] == 1e-2
+    assert a['lr_scheduler_type'] == 'cosine' and a['warmup_ratio'] == 0.1 and a['max_grad_norm'] == 1
+    assert TrainArgs('transf-xl', 'debug')()['lr_scheduler_type'] == 'constant'
+    ref = torch.optim.lr_scheduler.LambdaLR  # HF cosine-with-warmup closed form
+    tot, base = 100, 3e-4
+    for s in (0, 5, 10, 55, 99):
+        warm = 10
+        want = base * s / warm if s < warm else base * 0.5 * (1 + math.cos(math.pi * (s - warm) / (tot - warm)))
+        assert abs(lr_at(s, tot, base, 'cosine', 0.1) - want) < 1e-12
+    ids = torch.tensor([[5, 6, 1, 1]])
+    _, lab = collate_clm(ids, pad_token_id=1)
+    assert lab.tolist() == [[5, 6, -100, -100]]
+    assert ntp_accuracy(torch.tensor([[6, 9, 9, 9]]), lab) == 1.0
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from symbolic_music_generation_amd.dist import GradSync, layer_buckets
+from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig
+from symbolic_music_generation_amd.xl_engine import ParamLayout
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+cfg = MyTransfoXLConfig('debug', vocab_size=1190, cutoffs=[1000], n_layer=3)
+class E: pass
+e = E(); e.cfg = cfg; e.layout = ParamLayout(cfg)
+r = dist.get_rank()
+e.G = torch.arange(e.layout.total, dtype=torch.float32) * (r + 1)
+gs = GradSync(e)
+per_layer, rest = layer_buckets(e.layout, cfg.n_layer)
+cover = torch.zeros(e.layout.total)
+for sl in per_layer:
+    for lo, hi in sl: cover[lo:hi] += 1
+for lo, hi in rest: cover[lo:hi] += 1
+assert (cover == 1).all(), 'buckets must tile the flat buffer exactly once'
+for l in reversed(range(cfg.n_layer)): gs.layer_done(l)
+gs.finish()
+want = torch.arange(e.layout.total, dtype=torch.float32) * 3
+assert torch.equal(e.G, want), 'all-reduce(sum) over 2 ranks'
+dist.destroy_process_group()
+print('ok')
+'''
+
+
+def test_data_parallel_gradsync_gloo_world2(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(_DP_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)
