@@ -1,0 +1,280 @@
+"""
+ORACLE (test infrastructure, NOT product code) -- CPU fp32 restatement of the Reformer path of
+StefanHeng/Symbolic-Music-Generation: `MyReformerModelWithLMHead` (musicnlp/models/reformer.py:90-127) is a pure
+pass-through to HuggingFace `ReformerModelWithLMHead`, whose arithmetic is restated here in its own structure
+(line numbers `HF515:` refer to transformers 5.15 modeling_reformer.py, the importable copy).
+
+PINNED: `tests/golden/make_reformer_goldens.py` runs the real HF implementation in the build container (hash_seed set) and
+stores weights / ids / logits / loss / bucket ids / rotations; `tests/test_reformer_oracle_cpu.py` checks this restatement
+against those fixtures.  Version drift vs the reference's pinned transformers==4.25.1: 5.15's LM head never
+adds `lm_head.bias` (zero at init, so init-time parity is unaffected); this restatement adds it, like 4.25.1.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this file.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+
+PRESETS = {  # musicnlp/models/reformer.py:15-44
+    'debug': dict(max_position_embeddings=64, axial_pos_shape=(8, 8), hidden_size=128, num_attention_heads=8, n_pairs=3),
+    'debug-large': dict(max_position_embeddings=512, axial_pos_shape=(16, 32), hidden_size=128, num_attention_heads=8, n_pairs=3),
+    'tiny': dict(max_position_embeddings=1024, axial_pos_shape=(32, 32), hidden_size=256, num_attention_heads=8, n_pairs=3),
+    'small': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=512, num_attention_heads=8, n_pairs=3),
+    'base': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=768, num_attention_heads=12, n_pairs=6, num_hashes=2),
+    'large': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=1024, num_attention_heads=16, n_pairs=12, num_hashes=2),
+}
+
+
+@dataclass
+class RefReformerConfig:
+    vocab_size: int = 420
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    attention_head_size: int = 64
+    feed_forward_size: int = 3072
+    attn_layers: List[str] = field(default_factory=lambda: ['local', 'lsh'] * 6)
+    max_position_embeddings: int = 2048
+    axial_pos_shape: Tuple[int, int] = (32, 64)
+    axial_pos_embds_dim: Tuple[int, int] = (192, 576)
+    num_hashes: int = 1
+    num_buckets: Union[None, int, List[int]] = None
+    chunk_length: int = 64          # lsh_attn_chunk_length == local_attn_chunk_length == 64 (HF defaults, logged config)
+    layer_norm_eps: float = 1e-12
+    hidden_dropout_prob: float = 0.05
+    local_attention_probs_dropout_prob: float = 0.05
+    lsh_attention_probs_dropout_prob: float = 0.0
+    axial_norm_std: float = 1.0
+    initializer_range: float = 0.02
+    eos_token_id: int = 3
+    pad_token_id: int = 1
+
+    @staticmethod
+    def from_preset(model_size='base', vocab_size=None, **kwargs) -> 'RefReformerConfig':
+        p = dict(PRESETS[model_size])
+        hd, nh = p['hidden_size'], p['num_attention_heads']
+        assert hd % nh == 0 and hd % 4 == 0
+        n_pairs = p.pop('n_pairs')
+        p.update(attn_layers=['local', 'lsh'] * n_pairs, feed_forward_size=hd * 4, attention_head_size=hd // nh,
+                 axial_pos_embds_dim=(hd // 4, 3 * hd // 4))
+        if vocab_size is not None:
+            p['vocab_size'] = vocab_size
+        p.update(kwargs)
+        c = RefReformerConfig(**p)
+        assert len(c.axial_pos_shape) == 2 and c.axial_pos_shape[0] * c.axial_pos_shape[1] == c.max_position_embeddings
+        return c
+
+
+def auto_num_buckets(seq_len: int, chunk: int, max_pos: int):
+    """HF515:791-809"""
+    p2 = (2 * (seq_len // chunk)).bit_length() - 1
+    nb = 2 ** p2
+    limit = 2 * max(int((max_pos // chunk) ** 0.5), chunk)
+    if nb > limit:
+        return [2 ** (p2 // 2), 2 ** (p2 - p2 // 2)]
+    return nb
+
+
+def param_shapes(c: RefReformerConfig) -> "Dict[str, Tuple[int, ...]]":
+    d, Fi, V = c.hidden_size, c.feed_forward_size, c.vocab_size
+    hd = c.num_attention_heads * c.attention_head_size
+    sh = {'reformer.embeddings.word_embeddings.weight': (V, d),
+          'reformer.embeddings.position_embeddings.weights.0': (c.axial_pos_shape[0], 1, c.axial_pos_embds_dim[0]),
+          'reformer.embeddings.position_embeddings.weights.1': (1, c.axial_pos_shape[1], c.axial_pos_embds_dim[1])}
+    for i, kind in enumerate(c.attn_layers):
+        p = f'reformer.encoder.layers.{i}.'
+        sh[p + 'attention.layer_norm.weight'] = (d,)
+        sh[p + 'attention.layer_norm.bias'] = (d,)
+        if kind == 'local':
+            for n in ('query', 'key', 'value'):
+                sh[p + f'attention.self_attention.{n}.weight'] = (hd, d)
+        else:
+            for n in ('query_key', 'value'):
+                sh[p + f'attention.self_attention.{n}.weight'] = (hd, d)
+        sh[p + 'attention.output.dense.weight'] = (d, hd)
+        sh[p + 'feed_forward.layer_norm.weight'] = (d,)
+        sh[p + 'feed_forward.layer_norm.bias'] = (d,)
+        sh[p + 'feed_forward.dense.dense.weight'] = (Fi, d)
+        sh[p + 'feed_forward.dense.dense.bias'] = (Fi,)
+        sh[p + 'feed_forward.output.dense.weight'] = (d, Fi)
+        sh[p + 'feed_forward.output.dense.bias'] = (d,)
+    sh['reformer.encoder.layer_norm.weight'] = (2 * d,)
+    sh['reformer.encoder.layer_norm.bias'] = (2 * d,)
+    sh['lm_head.decoder.weight'] = (V, 2 * d)
+    sh['lm_head.bias'] = (V,)
+    return sh
+
+
+def init_params(c: RefReformerConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """HF `_init_weights`: Linear/Embedding N(0, initializer_range), biases 0, LayerNorm (1, 0), axial N(0, axial_norm_std)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for n, s in param_shapes(c).items():
+        if 'position_embeddings.weights' in n:
+            out[n] = torch.randn(s, generator=g) * c.axial_norm_std
+        elif n.endswith('layer_norm.weight'):
+            out[n] = torch.ones(s)
+        elif n.endswith('bias'):
+            out[n] = torch.zeros(s)
+        else:
+            out[n] = torch.randn(s, generator=g) * c.initializer_range
+    return out
+
+
+def _look_back(x, n_chunks_dim=2):
+    """keys/values of chunk c = [chunk c-1 (circular), chunk c]   (HF515:362-383 with num_chunks_before=1, after=0)"""
+    prev = torch.cat([x[:, :, -1:], x[:, :, :-1]], dim=n_chunks_dim)
+    return torch.cat([prev, x], dim=3)
+
+
+def lsh_buckets(qk, rotations, num_buckets):
+    """qk (B,H,T,dh), rotations (H, dh, n_h, rot/2) -> offset bucket ids (B,H,n_h*T)   (HF515:698-770, no padding mask)"""
+    rot = torch.einsum('bmtd,mdhr->bmhtr', qk.detach(), rotations)
+    n_h = rotations.shape[2]
+    if isinstance(num_buckets, int):
+        r = torch.cat([rot, -rot], dim=-1)
+        buckets = torch.argmax(r, dim=-1)
+        nb = num_buckets
+    else:
+        buckets, cur_sum, cur_prod = None, 0, 1
+        for f in num_buckets:
+            rf = rot[..., cur_sum:cur_sum + f // 2]
+            cur_sum += f // 2
+            a = torch.argmax(torch.cat([rf, -rf], dim=-1), dim=-1)
+            buckets = a if buckets is None else buckets + cur_prod * a
+            cur_prod *= f
+        nb = cur_prod
+    offsets = (torch.arange(n_h) * nb).view(1, 1, -1, 1)
+    return (buckets + offsets).flatten(2, 3)
+
+
+def chunked_attention(q, k, v, pos, chunk, self_mask: bool, drop_p=0.0):
+    """q,k,v (B,H,S,dh) already in (sorted) slot order, pos (B,H,S) original positions.  Returns out (B,H,S,dh), lse (B,H,S).
+    Causal mask on original positions with -1e9; optional self mask -1e5 applied after (HF515:852-890, 1257-1262)."""
+    B, H, S, dh = q.shape
+    nc = S // chunk
+    qc = q.view(B, H, nc, chunk, dh)
+    kc = _look_back(k.view(B, H, nc, chunk, dh))
+    vc = _look_back(v.view(B, H, nc, chunk, dh))
+    qp = pos.view(B, H, nc, chunk)
+    kp = _look_back(qp.unsqueeze(-1)).squeeze(-1)
+    dots = torch.matmul(qc, kc.transpose(-1, -2))
+    causal = qp.unsqueeze(-1) >= kp.unsqueeze(-2)
+    dots = torch.where(causal, dots, torch.tensor(-1e9))
+    if self_mask:
+        ne = qp.unsqueeze(-1) != kp.unsqueeze(-2)
+        dots = torch.where(ne, dots, torch.tensor(-1e5))
+    lse = torch.logsumexp(dots, dim=-1, keepdim=True)
+    probs = torch.exp(dots - lse)
+    probs = F.dropout(probs, p=drop_p, training=drop_p > 0)
+    out = torch.matmul(probs, vc)
+    return out.reshape(B, H, S, dh), lse.reshape(B, H, S)
+
+
+class RefReformer:
+    """Functional model over a parameter dict with HF state-dict names."""
+
+    def __init__(self, c: RefReformerConfig, params: Dict[str, torch.Tensor]):
+        self.c, self.p = c, params
+        self.num_buckets = c.num_buckets
+        self.last_buckets: Dict[int, torch.Tensor] = {}
+
+    def _split(self, x):
+        B, T, _ = x.shape
+        return x.view(B, T, self.c.num_attention_heads, self.c.attention_head_size).transpose(1, 2)
+
+    def _merge(self, x):
+        B, H, T, dh = x.shape
+        return x.transpose(1, 2).reshape(B, T, H * dh)
+
+    def embed(self, ids):
+        c, p = self.c, self.p
+        B, T = ids.shape
+        w0, w1 = p['reformer.embeddings.position_embeddings.weights.0'], p['reformer.embeddings.position_embeddings.weights.1']
+        A0, A1 = c.axial_pos_shape
+        pos = torch.cat([w0.expand(A0, A1, -1), w1.expand(A0, A1, -1)], dim=-1).reshape(A0 * A1, -1)[:T]
+        return p['reformer.embeddings.word_embeddings.weight'][ids] + pos
+
+    def local_attn(self, l, h):
+        c, p = self.c, self.p
+        pre = f'reformer.encoder.layers.{l}.attention.self_attention.'
+        q = self._split(h @ p[pre + 'query.weight'].t())
+        k = self._split(h @ p[pre + 'key.weight'].t()) / math.sqrt(c.attention_head_size)
+        v = self._split(h @ p[pre + 'value.weight'].t())
+        B, H, T, dh = q.shape
+        pos = torch.arange(T).view(1, 1, T).expand(B, H, T)
+        if T <= c.chunk_length:
+            dots = q @ k.transpose(-1, -2)
+            dots = torch.where(pos.unsqueeze(-1) >= pos.unsqueeze(-2), dots, torch.tensor(-1e9))
+            out = torch.softmax(dots, -1) @ v
+        else:
+            out, _ = chunked_attention(q, k, v, pos, c.chunk_length, self_mask=False)
+        return self._merge(out)
+
+    def lsh_attn(self, l, h, rotations):
+        c, p = self.c, self.p
+        pre = f'reformer.encoder.layers.{l}.attention.self_attention.'
+        qk = self._split(h @ p[pre + 'query_key.weight'].t())
+        v = self._split(h @ p[pre + 'value.weight'].t())
+        B, H, T, dh = qk.shape
+        key = qk * torch.rsqrt(torch.mean(qk ** 2, -1, keepdim=True) + 1e-6) / math.sqrt(dh)   # HF515:1052-1066
+        if T <= c.chunk_length:
+            pos = torch.arange(T).view(1, 1, T).expand(B, H, T)
+            dots = qk @ key.transpose(-1, -2)
+            dots = torch.where(pos.unsqueeze(-1) >= pos.unsqueeze(-2), dots, torch.tensor(-1e9))
+            dots = torch.where(pos.unsqueeze(-1) != pos.unsqueeze(-2), dots, torch.tensor(-1e5))
+            return self._merge(torch.softmax(dots, -1) @ v)
+        if self.num_buckets is None:
+            self.num_buckets = auto_num_buckets(T, c.chunk_length, c.max_position_embeddings)
+        n_h = rotations.shape[2]
+        buckets = lsh_buckets(qk, rotations, self.num_buckets)                       # (B,H,n_h*T)
+        self.last_buckets[l] = buckets
+        S = n_h * T
+        scaled = S * buckets + (torch.arange(S).view(1, 1, -1) % S)                  # HF515:151-157
+        sidx = torch.argsort(scaled, dim=-1)
+        spos = sidx % T
+        gather = spos.unsqueeze(-1).expand(-1, -1, -1, dh)
+        qs, ks, vs = qk.gather(2, gather), key.gather(2, gather), v.gather(2, gather)
+        out_s, lse_s = chunked_attention(qs, ks, vs, spos, c.chunk_length, self_mask=True)
+        undo = torch.empty_like(sidx)
+        undo.scatter_(-1, sidx, torch.arange(S).view(1, 1, -1).expand_as(sidx))
+        out = out_s.gather(2, undo.unsqueeze(-1).expand(-1, -1, -1, dh)).view(B, H, n_h, T, dh)
+        lse = lse_s.gather(2, undo).view(B, H, n_h, T, 1)
+        if n_h > 1:
+            w = torch.exp(lse - torch.logsumexp(lse, dim=2, keepdim=True))
+            out = (out * w).sum(2)
+        else:
+            out = out[:, :, 0]
+        return self._merge(out)
+
+    def rotations_shape(self, T: int):
+        c = self.c
+        nb = self.num_buckets if self.num_buckets is not None else auto_num_buckets(T, c.chunk_length, c.max_position_embeddings)
+        rot = nb if isinstance(nb, int) else sum(nb)
+        return (c.num_attention_heads, c.attention_head_size, c.num_hashes, rot // 2)
+
+    def forward(self, ids, rotations: Optional[Dict[int, torch.Tensor]] = None, labels=None):
+        """ids (B,T); rotations: {layer index -> (H, dh, n_h, rot/2)} for every LSH layer (explicit input: HF draws them
+        from the global RNG inside each layer, HF515:723-731).  Eval-mode semantics (no dropout)."""
+        c, p = self.c, self.p
+        d = c.hidden_size
+        x = self.embed(ids)
+        x1, x2 = x, x
+        for l, kind in enumerate(c.attn_layers):
+            pre = f'reformer.encoder.layers.{l}.'
+            h = F.layer_norm(x2, (d,), p[pre + 'attention.layer_norm.weight'], p[pre + 'attention.layer_norm.bias'], c.layer_norm_eps)
+            a = self.local_attn(l, h) if kind == 'local' else self.lsh_attn(l, h, (rotations or {}).get(l))
+            y1 = x1 + a @ p[pre + 'attention.output.dense.weight'].t()
+            h2 = F.layer_norm(y1, (d,), p[pre + 'feed_forward.layer_norm.weight'], p[pre + 'feed_forward.layer_norm.bias'], c.layer_norm_eps)
+            f = torch.relu(h2 @ p[pre + 'feed_forward.dense.dense.weight'].t() + p[pre + 'feed_forward.dense.dense.bias'])
+            y2 = x2 + f @ p[pre + 'feed_forward.output.dense.weight'].t() + p[pre + 'feed_forward.output.dense.bias']
+            x1, x2 = y1, y2
+        hcat = F.layer_norm(torch.cat([x1, x2], -1), (2 * d,), p['reformer.encoder.layer_norm.weight'],
+                            p['reformer.encoder.layer_norm.bias'], c.layer_norm_eps)
+        logits = hcat @ p['lm_head.decoder.weight'].t() + p['lm_head.bias']
+        loss = None
+        if labels is not None:
+            loss = F.cross_entropy(logits[:, :-1].reshape(-1, c.vocab_size), labels[:, 1:].reshape(-1), ignore_index=-100)
+        return logits, loss

@@ -1,0 +1,77 @@
+"""Generates tests/golden/reformer_*.pt in the BUILD container from the real HuggingFace Reformer (transformers 5.15, the
+importable copy of the implementation behind musicnlp/models/reformer.py).  Stored: config values, state_dict, input ids,
+logits, loss, per-LSH-layer bucket ids and the rotation tensors HF drew (re-drawn here with the same seed/shape).
+
+    python tests/golden/make_reformer_goldens.py
+"""
+import os
+import sys
+
+import torch
+from transformers import ReformerConfig, ReformerModelWithLMHead
+from transformers.models.reformer import modeling_reformer as mr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HASH_SEED = 1234
+
+
+def make(name, T, hidden, heads, axial, n_pairs, num_hashes, vocab=97, seed=0):
+    torch.manual_seed(seed)
+    cfg = ReformerConfig(
+        attn_layers=['local', 'lsh'] * n_pairs, hidden_size=hidden, num_attention_heads=heads,
+        attention_head_size=hidden // heads, feed_forward_size=4 * hidden, max_position_embeddings=axial[0] * axial[1],
+        axial_pos_shape=axial, axial_pos_embds_dim=(hidden // 4, 3 * hidden // 4), is_decoder=True, num_buckets=None,
+        num_hashes=num_hashes, vocab_size=vocab, hash_seed=HASH_SEED, eos_token_id=3, pad_token_id=1,
+        # reference / HF defaults in force: chunk 64/64, 1 chunk before, relu, eps 1e-12, dropouts 0.05/0.05/0.0
+    )
+    model = ReformerModelWithLMHead(cfg).eval()
+    with torch.no_grad():   # non-trivial scales so hashing / softmax are exercised
+        for n, p in model.named_parameters():
+            if p.dim() > 1 and 'position_embeddings' not in n:
+                p.mul_(4.0)
+            if 'layer_norm.weight' in n:
+                p.add_(0.1 * torch.randn_like(p))
+            if n.endswith('bias') and 'lm_head' not in n:
+                p.add_(0.05 * torch.randn_like(p))
+    ids = torch.randint(4, vocab, (2, T))
+    labels = ids.clone()
+    labels[1, T - 9:] = -100
+    buckets = {}
+    orig = mr.LSHSelfAttention._hash_vectors
+
+    def spy(self, vectors, num_hashes, attention_mask, increase_num_buckets=False):
+        b = orig(self, vectors, num_hashes, attention_mask, increase_num_buckets)
+        buckets[self.layer_idx] = b.clone()
+        return b
+
+    mr.LSHSelfAttention._hash_vectors = spy
+    with torch.no_grad():
+        out = model(input_ids=ids, labels=labels)
+    mr.LSHSelfAttention._hash_vectors = orig
+    rotations = {}
+    nb = model.config.num_buckets
+    if T > 64:
+        rot = nb if isinstance(nb, int) else sum(nb)
+        for l, kind in enumerate(cfg.attn_layers):
+            if kind == 'lsh':
+                torch.manual_seed(HASH_SEED)   # exactly what HF515:723-731 does
+                rotations[l] = torch.randn(heads, hidden // heads, num_hashes, rot // 2)
+    blob = dict(
+        config=dict(vocab_size=vocab, hidden_size=hidden, num_attention_heads=heads, attention_head_size=hidden // heads,
+                    feed_forward_size=4 * hidden, attn_layers=['local', 'lsh'] * n_pairs,
+                    max_position_embeddings=axial[0] * axial[1], axial_pos_shape=tuple(axial),
+                    axial_pos_embds_dim=(hidden // 4, 3 * hidden // 4), num_hashes=num_hashes),
+        num_buckets=nb, state_dict={k: v.clone() for k, v in model.state_dict().items()},
+        ids=ids, labels=labels, logits=out.logits.clone(), loss=out.loss.clone(),
+        buckets={k: v.to(torch.int32) for k, v in buckets.items()}, rotations=rotations, hash_seed=HASH_SEED,
+    )
+    path = os.path.join(HERE, f'reformer_{name}.pt')
+    torch.save(blob, path)
+    print(name, 'T', T, 'num_buckets', nb, 'loss', out.loss.item(), 'bytes', os.path.getsize(path))
+
+
+if __name__ == '__main__':
+    make('single_chunk', T=64, hidden=64, heads=2, axial=(8, 8), n_pairs=1, num_hashes=1)
+    make('chunked_h1', T=256, hidden=64, heads=2, axial=(16, 16), n_pairs=1, num_hashes=1)
+    make('chunked_h2', T=256, hidden=64, heads=2, axial=(16, 16), n_pairs=2, num_hashes=2)
+    make('dh64_h1', T=512, hidden=128, heads=2, axial=(16, 32), n_pairs=1, num_hashes=1)
