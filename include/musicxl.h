@@ -167,6 +167,43 @@ int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, con
 /* t_dev += 1; rng_ctr += 1 */
 int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Reformer path (A6-A8): replaces HuggingFace modeling_reformer.py as reached through
+ * musicnlp/models/reformer.py:114-127 (AxialPositionEmbeddings, LSHSelfAttention._hash_vectors / _stable_argsort /
+ * _attend / ReverseSort / hash-round merge, LocalSelfAttention).  Chunk length 64, one chunk look-back, causal decoder.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* out[b,t] = drop(E[ids]) + cat(W0[t / A1], W1[t % A1]) with HF's 2-D position dropout; E (V,d) bf16, W0 (A0,d0) f32, W1 (A1,d-d0) f32 */
+int mxl_axial_embed_fwd(const void* ids, const void* E, const float* W0, const float* W1, void* out, int B, int T, int d,
+                        int V, int A0, int A1, int d0, float drop_p, unsigned long long seed, unsigned site_emb,
+                        unsigned site_pos, void* stream);
+int mxl_axial_embed_bwd(const void* ids, const void* dout, const void* dout2, float* dE, float* dW0, float* dW1, int B, int T,
+                        int d, int V, int A0, int A1, int d0, float drop_p, unsigned long long seed, unsigned site_emb,
+                        unsigned site_pos, void* stream);
+/* buckets[b,h,r*T+t] = r*NB + combined argmax([xR;-xR]) per factor; qk (B,T,H,dh) bf16 strided (bs, rs);
+ * rotations (H, dh, n_h, sum(factors)/2) f32 supplied by the caller; factors_host: nfac ints on the host */
+int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* rotations, int* buckets, int B, int T, int H, int dh,
+                 int n_h, int nfac, const int* factors_host, void* stream);
+/* stable sort of the S = n_h*T slots of each of the BH rows by bucket: sorted_idx (slot -> element), sorted_pos = idx % T */
+int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, int S, int T, int n_buckets_total, void* stream);
+/* chunked attention: local (lsh=0, sorted_pos NULL, n_h=1; separate q/k/v) or LSH (lsh=1; k == q == shared qk).
+ * out rows (b, round, pos) x (H*dh) bf16; lse (B, n_h, H, T) f32; T % 64 == 0, T > 64; probs dropout drop_p */
+int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, const int* sorted_pos, void* out, float* lse, int B, int T,
+                       int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed,
+                       unsigned site, void* stream);
+/* backward: dq, dk, dv (B,T,H*dh) f32 are ACCUMULATED (atomics); for lsh, dk is w.r.t. the normalised key (see keynorm_bwd);
+ * dout has out's layout; dlse (B,n_h,H,T) f32 or NULL */
+int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out, const float* lse,
+                       const void* dout, const float* dlse, float* dq, float* dk, float* dv, int B, int T, int H, int dh,
+                       int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed, unsigned site,
+                       void* stream);
+/* dqk (B,T,H*dh) bf16 = dq + chain rule of k = qk * rsqrt(mean(qk^2)+1e-6)/sqrt(dh) applied to dk_eff */
+int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int B, int T,
+                        int H, int dh, void* stream);
+/* hash-round merge: out = sum_r softmax_r(lse) * out_r, and its backward (dout_r, dlse) */
+int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T, int H, int dh, int n_h, void* stream);
+int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r, float* dlse,
+                        int B, int T, int H, int dh, int n_h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,840 @@
+// Reformer path: axial position embeddings, LSH hashing, stable bucket sort, chunked
+// attention (local and LSH share one kernel), hash-round combine -- forward and backward.
+// Restates HuggingFace modeling_reformer.py as reached from musicnlp/models/reformer.py:114-127 ("HF515:" = line numbers
+// of the transformers 5.15 copy used to pin the oracle).
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// =====================================================================================================================
+// embeddings: out[b,t,:] = drop(E[ids[b,t]]) + cat(W0[t / A1], W1[t % A1]) with 2-D dropout over the (b, t % A1) columns
+// (HF515:222-256, 324-354)
+// =====================================================================================================================
+__global__ void axial_embed_fwd_kernel(const long long* ids, const bf16_t* E, const float* W0, const float* W1, bf16_t* out,
+                                       int B, int T, int d, int V, int A1, int d0, unsigned thresh, float dscale,
+                                       unsigned long long seed, unsigned site_emb, unsigned site_pos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T * d) return;
+    const int k = (int)(gid % d);
+    const long long n = gid / d;
+    const int t = (int)(n % T), b = (int)(n / T);
+    long long id = ids[n];
+    if (id < 0 || id >= V) id = 0;
+    float e = bf2f(E[(size_t)id * d + k]);
+    float pos = k < d0 ? W0[(size_t)(t / A1) * d0 + k] : W1[(size_t)(t % A1) * (d - d0) + (k - d0)];
+    if (thresh) {
+        e = dropout_keep(seed, site_emb, (uint64_t)gid, thresh) ? e * dscale : 0.f;
+        pos = dropout_keep(seed, site_pos, (uint64_t)b * A1 + (t % A1), thresh) ? pos * dscale : 0.f;
+    }
+    out[gid] = f2bf(e + pos);
+}
+
+__global__ void axial_embed_bwd_kernel(const long long* ids, const bf16_t* dout, const bf16_t* dout2, float* dE, float* dW0,
+                                       float* dW1, int B, int T, int d, int V, int A1, int d0, unsigned thresh, float dscale,
+                                       unsigned long long seed, unsigned site_emb, unsigned site_pos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T * d) return;
+    const int k = (int)(gid % d);
+    const long long n = gid / d;
+    const int t = (int)(n % T), b = (int)(n / T);
+    float g = bf2f(dout[gid]);
+    if (dout2) g += bf2f(dout2[gid]);
+    float ge = g, gp = g;
+    if (thresh) {
+        ge = dropout_keep(seed, site_emb, (uint64_t)gid, thresh) ? g * dscale : 0.f;
+        gp = dropout_keep(seed, site_pos, (uint64_t)b * A1 + (t % A1), thresh) ? g * dscale : 0.f;
+    }
+    const long long id = ids[n];
+    if (id >= 0 && id < V) atomicAdd(dE + (size_t)id * d + k, ge);
+    if (k < d0) atomicAdd(dW0 + (size_t)(t / A1) * d0 + k, gp);
+    else atomicAdd(dW1 + (size_t)(t % A1) * (d - d0) + (k - d0), gp);
+}
+
+// =====================================================================================================================
+// LSH hashing (HF515:698-770): buckets[b,h,r*T+t] = r*NB + combine_f argmax([x R_f ; -x R_f])
+// rotations (H, dh, n_h, R2) f32 given explicitly (HF draws them from the global RNG inside the layer)
+// =====================================================================================================================
+constexpr int MAX_R2 = 64;
+struct HashGeom { int nfac; int fac[4]; };
+
+__global__ __launch_bounds__(256) void lsh_hash_kernel(const bf16_t* qk, long long bs, int rs, const float* rot, int* buckets,
+                                                       int B, int T, int H, int dh, int n_h, int R2, int NB, HashGeom g) {
+    extern __shared__ float srot[];  // [dh][R2] for this (h, round)
+    const int h = blockIdx.y % H, r = blockIdx.y / H, b = blockIdx.z;
+    for (int i = threadIdx.x; i < dh * R2; i += 256) {
+        const int e = i / R2, c = i % R2;
+        srot[i] = rot[(((size_t)h * dh + e) * n_h + r) * R2 + c];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float acc[MAX_R2];
+#pragma unroll
+    for (int c = 0; c < MAX_R2; c++) acc[c] = 0.f;
+    const bf16_t* x = qk + (size_t)b * bs + (size_t)t * rs + h * dh;
+    for (int e = 0; e < dh; e++) {
+        const float xv = bf2f(x[e]);
+#pragma unroll
+        for (int c = 0; c < MAX_R2; c++)
+            if (c < R2) acc[c] = fmaf(xv, srot[e * R2 + c], acc[c]);
+    }
+    int bucket = 0, cur = 0, prod = 1;
+    for (int f = 0; f < g.nfac; f++) {
+        const int half = g.fac[f] / 2;
+        // argmax over [v_0..v_{half-1}, -v_0..-v_{half-1}], first maximum wins (torch.argmax)
+        float best = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < MAX_R2; c++)
+            if (c >= cur && c < cur + half) { const float v = acc[c]; if (v > best) { best = v; arg = c - cur; } }
+#pragma unroll
+        for (int c = 0; c < MAX_R2; c++)
+            if (c >= cur && c < cur + half) { const float v = -acc[c]; if (v > best) { best = v; arg = half + c - cur; } }
+        bucket += prod * arg;
+        prod *= g.fac[f];
+        cur += half;
+    }
+    buckets[((size_t)b * H + h) * n_h * T + (size_t)r * T + t] = r * NB + bucket;
+}
+
+// =====================================================================================================================
+// stable counting sort of S = n_h*T slots by bucket per (b,h) (HF515:151-157, 772-789: argsort of S*bucket + index).
+// one wave per (b,h): histogram -> scan -> in-order multisplit with ballot ranking.  Outputs sidx (slot -> element index
+// in [0,S)) and spos = sidx % T.
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void lsh_sort_kernel(const int* buckets, int* sidx, int* spos, int S, int T, int NBT) {
+    extern __shared__ int cnt[];  // [NBT]
+    const int lane = threadIdx.x;
+    const int* bk = buckets + (size_t)blockIdx.x * S;
+    int* so = sidx + (size_t)blockIdx.x * S;
+    int* sp = spos + (size_t)blockIdx.x * S;
+    for (int i = lane; i < NBT; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < S; i += 64) atomicAdd(&cnt[bk[i]], 1);
+    __syncthreads();
+    // exclusive scan over NBT counters (wave-serial over 64-wide strips)
+    int carry = 0;
+    for (int base = 0; base < NBT; base += 64) {
+        const int i = base + lane;
+        int v = i < NBT ? cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (i < NBT) cnt[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    int nbits = 1;
+    while ((1 << nbits) < NBT) nbits++;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < S;
+        const int b = ok ? bk[i] : -1;
+        unsigned long long peers = __ballot(ok);
+        for (int bit = 0; bit < nbits; bit++) {
+            const bool on = (b >> bit) & 1;
+            const unsigned long long bal = __ballot(on && ok);
+            peers &= on ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & lt);
+        int off = 0;
+        if (ok) off = cnt[b];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // all lanes have read cnt[] before any leader updates it (single wave)
+        if (ok) {
+            const int dst = off + rank;
+            so[dst] = i;
+            sp[dst] = i % T;
+            if (rank == 0) cnt[b] = off + __popcll(peers);
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================================
+// chunked attention, forward.  Slots s = 0..S-1 (sorted order for LSH, identity for local), chunk = 64 slots; queries
+// of chunk c attend the 128 keys of chunks (c-1 mod NC, c) (HF515:362-383).  dots = f_k * (q . x_k) with
+//   local: f = 1/sqrt(dh)                  LSH: x = shared qk, f_k = rsqrt(mean(x_k^2) + 1e-6) / sqrt(dh)   (HF515:1052-1066)
+// masks on ORIGINAL positions: causal (q_pos >= k_pos) else -1e9; LSH self mask (q_pos == k_pos) -> -1e5 afterwards.
+// lane = query ("swapped" S^T = K Q^T), single pass over the 128 keys.
+// =====================================================================================================================
+struct ChunkP {
+    const bf16_t *q, *k, *v;
+    const int* spos;            // (B,H,S) or null (identity)
+    bf16_t* out;                // rows (b, round, pos) x d
+    float* lse;                 // (B, n_h, H, T)
+    const bf16_t* dout;         // backward: same layout as out
+    const float* dlse;          // (B, n_h, H, T) or null
+    float *dq, *dk, *dv;        // f32 (B, T, d) accumulators (atomicAdd)
+    long long bs; int rs;       // q/k/v strides (elements)
+    int B, T, H, S, n_h, lsh;
+    float scale;
+    unsigned thresh; float dscale; unsigned long long seed; unsigned site;
+};
+
+template <int DH> struct GeoC {
+    static constexpr int KS = DH / 16, EB = (DH + 31) / 32, ROWB = DH * 2, CH = DH / 8;
+    static constexpr int ROWS = 192;
+    static constexpr int T_BYTES = ROWS * ROWB;
+    static constexpr int SMEM = 2 * T_BYTES + ROWS * 8;   // K, V images + kpos[192] + kfac[192]
+    __device__ static __forceinline__ int koff(int row, int ch) {
+        if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        return row * ROWB + (ch << 4);
+    }
+    __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
+};
+
+// stage the 3 key/value chunks (cprev, c0, c0+1) of this workgroup into LDS; returns nothing, all threads participate
+template <int DH>
+__device__ __forceinline__ void stage_kv(const ChunkP& p, char* sK, char* sV, int* sPos, float* sFac, int b, int h, int c0, int NC) {
+    using G = GeoC<DH>;
+    const int tid = threadIdx.x;
+    const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
+    for (int c = tid; c < G::ROWS * G::CH; c += 256) {
+        const int row = c / G::CH, ch = c % G::CH;
+        int chunk = c0 - 1 + (row >> 6);
+        if (chunk < 0) chunk += NC;
+        const bool ok = chunk < NC;
+        const int slot = chunk * 64 + (row & 63);
+        const int pos = ok ? (sp ? sp[slot] : slot) : 0;
+        const bf16_t* kr = p.k + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8;
+        const bf16_t* vr = p.v + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kr) : z;
+        const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vr) : z;
+        *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = kv;
+        *reinterpret_cast<u32x4*>(sV + G::koff(row, ch)) = vv;
+        // per-row key factor: the CH lanes holding one row are consecutive
+        float ss = 0.f;
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&kv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x = bf2f(e[j]); ss += x * x; }
+        for (int o = 1; o < G::CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        if (ch == 0) {
+            sPos[row] = ok ? pos : 0x7fffffff;   // invalid rows: position +inf -> masked by causality
+            sFac[row] = p.lsh ? rsqrtf(ss / (float)DH + 1e-6f) * p.scale : p.scale;
+        }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
+    using G = GeoC<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + G::T_BYTES;
+    int* sPos = reinterpret_cast<int*>(sV + G::T_BYTES);
+    float* sFac = reinterpret_cast<float*>(sPos + G::ROWS);
+    const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int NC = p.S / 64;
+    const int c0 = blockIdx.x * 2;
+    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
+    __syncthreads();
+    const int chunk = c0 + (wid >> 1);
+    if (chunk >= NC) return;
+    const int kb0 = 64 * (wid >> 1);                 // first LDS row of this chunk's 128 keys
+    const int qslot = chunk * 64 + 32 * (wid & 1) + r;
+    const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
+    const int qpos = sp ? sp[qslot] : qslot;
+    const int round = qslot / p.T;
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = p.q + (size_t)b * p.bs + (size_t)qpos * p.rs + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks + 8 * hh);
+    }
+    f32x16 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) s[kb][j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + G::koff(kb0 + 32 * kb + r, 2 * ks + hh));
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                            __builtin_bit_cast(mfma_bf16x8, qf[ks]), s[kb], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int row = kb0 + 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            const int kp = sPos[row];
+            float v = s[kb][j] * sFac[row];
+            v = (qpos >= kp) ? v : -1e9f;
+            if (p.lsh) v = (qpos != kp) ? v : -1e5f;
+            s[kb][j] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const float e = __expf(s[kb][j] - mx); s[kb][j] = e; sum += e; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    const size_t orow = ((size_t)b * p.n_h + round) * p.T + qpos;
+    if (hh == 0 && p.lse) p.lse[(((size_t)b * p.n_h + round) * p.H + h) * p.T + qpos] = mx + __logf(sum);
+    // probabilities (+ dropout), P^T fragments straight from the accumulators
+    f32x16 o[EB];
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
+    const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                float p0 = s[kb][8 * st + j] * inv, p1 = s[kb][8 * st + j + 1] * inv;
+                if (p.thresh) {
+                    const int k0 = 32 * kb + ((8 * st + j) & 3) + 8 * ((8 * st + j) >> 2) + 4 * hh;
+                    p0 = dropout_keep(p.seed, p.site, dbase + k0, p.thresh) ? p0 * p.dscale : 0.f;
+                    p1 = dropout_keep(p.seed, p.site, dbase + k0 + 1, p.thresh) ? p1 * p.dscale : 0.f;
+                }
+                const uint32_t w = pack2bf(p0, p1);
+                pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; e++) {
+                const int key = kb0 + 32 * kb + 16 * st + 4 * hh + q4;
+                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ecol < DH) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sV + G::eoff(key, ecol)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sV + G::eoff(key + 8, ecol)));
+                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+                o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                               __builtin_bit_cast(mfma_bf16x8, pf), o[e], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* op = p.out + orow * (size_t)(p.H * DH) + h * DH;
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int grp = 0; grp < 4; grp++) {
+            const int e0 = 32 * e + 8 * grp + 4 * hh;
+            if (e0 < DH) {
+                u32x2 w = {pack2bf(o[e][4 * grp], o[e][4 * grp + 1]), pack2bf(o[e][4 * grp + 2], o[e][4 * grp + 3])};
+                *reinterpret_cast<u32x2*>(op + e0) = w;
+            }
+        }
+}
+
+// =====================================================================================================================
+// chunked attention, backward.  Part A (lane = query): dq.  Part B (lane = key, key-owner over chunk kc with the queries
+// of chunks kc and kc+1 mod NC): dk', dv.  All three accumulate with f32 atomics into (B, T, d) buffers (a position occurs
+// n_h times; for n_h = 1 every element receives exactly one add).  dk' is the gradient w.r.t. the *effective* key
+// k' = f_k * x_k for LSH (the normalisation chain is applied by lsh_keynorm_bwd), and w.r.t. k for local attention.
+// With dropout: O = (keep*P/(1-p)) V;  dS = P * (keep*dPd/(1-p) - delta) + dlse * P,  delta = rowsum(dO * O).
+// =====================================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
+    using G = GeoC<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + G::T_BYTES;
+    int* sPos = reinterpret_cast<int*>(sV + G::T_BYTES);
+    float* sFac = reinterpret_cast<float*>(sPos + G::ROWS);
+    const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int NC = p.S / 64;
+    const int c0 = blockIdx.x * 2;
+    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
+    __syncthreads();
+    const int chunk = c0 + (wid >> 1);
+    if (chunk >= NC) return;
+    const int kb0 = 64 * (wid >> 1);
+    const int qslot = chunk * 64 + 32 * (wid & 1) + r;
+    const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
+    const int qpos = sp ? sp[qslot] : qslot;
+    const int round = qslot / p.T;
+    const int d = p.H * DH;
+    const size_t orow = ((size_t)b * p.n_h + round) * p.T + qpos;
+    bf16x8 qf[KS], dof[KS];
+    float dlt = 0.f;
+    {
+        const bf16_t* qp = p.q + (size_t)b * p.bs + (size_t)qpos * p.rs + h * DH;
+        const bf16_t* dop = p.dout + orow * d + h * DH;
+        const bf16_t* op = p.out + orow * d + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks + 8 * hh);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dop + 16 * ks + 8 * hh);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 16 * ks + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dlt += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)ov[j]);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+    }
+    const size_t sidx_ = (((size_t)b * p.n_h + round) * p.H + h) * p.T + qpos;
+    const float lse = p.lse[sidx_];
+    const float dl = p.dlse ? p.dlse[sidx_] : 0.f;
+    f32x16 s[4], dp[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) { s[kb][j] = 0.f; dp[kb][j] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + G::koff(kb0 + 32 * kb + r, 2 * ks + hh));
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                            __builtin_bit_cast(mfma_bf16x8, qf[ks]), s[kb], 0, 0, 0);
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(sV + G::koff(kb0 + 32 * kb + r, 2 * ks + hh));
+            dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
+                                                             __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp[kb], 0, 0, 0);
+        }
+    }
+    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int kk = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            const int row = kb0 + kk;
+            const int kp = sPos[row];
+            const float f = sFac[row];
+            float v = s[kb][j] * f;
+            v = (qpos >= kp) ? v : -1e9f;
+            if (p.lsh) v = (qpos != kp) ? v : -1e5f;
+            const float pr = __expf(v - lse);
+            float g = dp[kb][j];
+            if (p.thresh) g = dropout_keep(p.seed, p.site, dbase + kk, p.thresh) ? g * p.dscale : 0.f;
+            // gradient w.r.t. the raw dot (q . x_k): dS * f_k ; masked entries have pr == 0 (or constant score -> no grad)
+            const bool live = (qpos >= kp) && !(p.lsh && qpos == kp);
+            s[kb][j] = live ? (pr * (g - dlt) + dl * pr) * f : 0.f;
+        }
+    // dq^T[e, q] = sum_k X^T[e, k] * dSf^T[k, q]
+    f32x16 aq[EB];
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) aq[e][j] = 0.f;
+    const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const uint32_t w = pack2bf(s[kb][8 * st + j], s[kb][8 * st + j + 1]);
+                pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; e++) {
+                const int key = kb0 + 32 * kb + 16 * st + 4 * hh + q4;
+                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ecol < DH) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key, ecol)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key + 8, ecol)));
+                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+                aq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, pf), aq[e], 0, 0, 0);
+            }
+        }
+    float* dqp = p.dq + ((size_t)b * p.T + qpos) * d + h * DH;
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (ee < DH) atomicAdd(dqp + ee, aq[e][j]);
+        }
+}
+
+// key-owner: workgroup = key chunk kc; wave w owns 32 keys of it for one of the two query chunks: w = 2*qsel + khalf
+template <int DH>
+__global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
+    using G = GeoC<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: Q image [128][DH], dO image [128][DH], qpos[128], lse[128], delta[128], dlse[128]
+    char* sQ = smem;
+    char* sDO = sQ + 128 * G::ROWB;
+    int* sQpos = reinterpret_cast<int*>(sDO + 128 * G::ROWB);
+    float* sLse = reinterpret_cast<float*>(sQpos + 128);
+    float* sDl = sLse + 128;
+    float* sDlse = sDl + 128;
+    const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int NC = p.S / 64;
+    const int kc = blockIdx.x;
+    const int d = p.H * DH;
+    const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
+    // stage the 128 queries: rows 0-63 = chunk kc, rows 64-127 = chunk kc+1 (mod NC)
+    for (int c = tid; c < 128 * G::CH; c += 256) {
+        const int row = c / G::CH, ch = c % G::CH;
+        int chunk = kc + (row >> 6);
+        if (chunk >= NC) chunk -= NC;
+        const int slot = chunk * 64 + (row & 63);
+        const int pos = sp ? sp[slot] : slot;
+        const int round = slot / p.T;
+        const size_t orow = ((size_t)b * p.n_h + round) * p.T + pos;
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dout + orow * d + h * DH + ch * 8);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.out + orow * d + h * DH + ch * 8);
+        *reinterpret_cast<u32x4*>(sQ + G::koff(row, ch)) = qv;
+        *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = dv;
+        float dl = 0.f;
+        const bf16_t* a = reinterpret_cast<const bf16_t*>(&dv);
+        const bf16_t* o = reinterpret_cast<const bf16_t*>(&ov);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dl += bf2f(a[j]) * bf2f(o[j]);
+        for (int o2 = 1; o2 < G::CH; o2 <<= 1) dl += __shfl_xor(dl, o2, 64);
+        if (ch == 0) {
+            const size_t si = (((size_t)b * p.n_h + round) * p.H + h) * p.T + pos;
+            sQpos[row] = pos;
+            sLse[row] = p.lse[si];
+            sDl[row] = dl;
+            sDlse[row] = p.dlse ? p.dlse[si] : 0.f;
+        }
+    }
+    __syncthreads();
+    // with a single chunk (NC == 1) the "previous" chunk is the chunk itself: HF concatenates it twice; keep both
+    const int qsel = wid >> 1;                 // 0: queries of chunk kc (keys are their "current" chunk), 1: chunk kc+1
+    const int kslot = kc * 64 + 32 * (wid & 1) + r;
+    const int kpos = sp ? sp[kslot] : kslot;
+    bf16x8 kf[KS], vf[KS];
+    float ss = 0.f;
+    {
+        const bf16_t* kp = p.k + (size_t)b * p.bs + (size_t)kpos * p.rs + h * DH;
+        const bf16_t* vp = p.v + (size_t)b * p.bs + (size_t)kpos * p.rs + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * hh);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float x = bf2f((bf16_t)kf[ks][j]); ss += x * x; }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+    }
+    const float fac = p.lsh ? rsqrtf(ss / (float)DH + 1e-6f) * p.scale : p.scale;
+    f32x16 ak[EB], av[EB];
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; }
+    const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+    // index of this key inside the 128-key window of the query chunk (for the dropout counter): chunk kc is the
+    // "current" chunk for queries of kc (window index 64 + x) and the "previous" chunk for queries of kc+1 (index x)
+    const int kwin = (qsel == 0 ? 64 : 0) + 32 * (wid & 1) + r;
+#pragma unroll 1
+    for (int qb = 0; qb < 2; qb++) {           // two 32-query blocks of the selected query chunk
+        const int q0 = 64 * qsel + 32 * qb;    // LDS row of the first query
+        f32x16 s, dp;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { s[j] = 0.f; dp[j] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQ + G::koff(q0 + r, 2 * ks + hh));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                        __builtin_bit_cast(mfma_bf16x8, kf[ks]), s, 0, 0, 0);
+            const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sDO + G::koff(q0 + r, 2 * ks + hh));
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ad),
+                                                         __builtin_bit_cast(mfma_bf16x8, vf[ks]), dp, 0, 0, 0);
+        }
+        f32x16 pr;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+            const int qrow = q0 + ii;
+            const int qp = sQpos[qrow];
+            int chunkq = kc + qsel;
+            if (chunkq >= NC) chunkq -= NC;
+            const int qslot = chunkq * 64 + 32 * qb + ii;
+            float v = s[j] * fac;
+            v = (qp >= kpos) ? v : -1e9f;
+            if (p.lsh) v = (qp != kpos) ? v : -1e5f;
+            const float pv = __expf(v - sLse[qrow]);
+            float g = dp[j];
+            float pd = pv;
+            if (p.thresh) {
+                const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
+                const bool keep = dropout_keep(p.seed, p.site, dbase + kwin, p.thresh);
+                g = keep ? g * p.dscale : 0.f;
+                pd = keep ? pv * p.dscale : 0.f;
+            }
+            const bool live = (qp >= kpos) && !(p.lsh && qp == kpos);
+            const float ds = live ? (pv * (g - sDl[qrow]) + sDlse[qrow] * pv) : 0.f;
+            pr[j] = pd;
+            s[j] = p.lsh ? ds : ds * fac;      // local: d k = dS * scale * q ; LSH: d k' = dS * q (chain applied later)
+        }
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            bf16x8 pf, df;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const uint32_t w = pack2bf(pr[8 * st + j], pr[8 * st + j + 1]);
+                pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
+                const uint32_t w2 = pack2bf(s[8 * st + j], s[8 * st + j + 1]);
+                df[j] = (short)(w2 & 0xffff); df[j + 1] = (short)(w2 >> 16);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; e++) {
+                const int qrow = q0 + 16 * st + 4 * hh + q4;
+                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                bf16x8 a1 = {0, 0, 0, 0, 0, 0, 0, 0}, a2 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ecol < DH) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sDO + G::eoff(qrow, ecol)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sDO + G::eoff(qrow + 8, ecol)));
+                    a1 = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sQ + G::eoff(qrow, ecol)));
+                    const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sQ + G::eoff(qrow + 8, ecol)));
+                    a2 = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                }
+                av[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a1),
+                                                                __builtin_bit_cast(mfma_bf16x8, pf), av[e], 0, 0, 0);
+                ak[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a2),
+                                                                __builtin_bit_cast(mfma_bf16x8, df), ak[e], 0, 0, 0);
+            }
+        }
+    }
+    float* dkp = p.dk + ((size_t)b * p.T + kpos) * d + h * DH;
+    float* dvp = p.dv + ((size_t)b * p.T + kpos) * d + h * DH;
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (ee < DH) { atomicAdd(dkp + ee, ak[e][j]); atomicAdd(dvp + ee, av[e][j]); }
+        }
+}
+
+// =====================================================================================================================
+// LSH glue: key-normalisation chain, hash-round combine (HF515:636-655) and its backward
+// =====================================================================================================================
+// dqk[n][h][:] = dq + f * dk' - x * (sum_e dk'_e x_e) * (m + eps)^(-3/2) / dh^(3/2),  m = mean(x^2),  f = (m+eps)^(-1/2)/sqrt(dh)
+__global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, const float* dq, const float* dkp, bf16_t* dqk,
+                                       int B, int T, int H, int dh) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, t, h)
+    if (gid >= (long long)B * T * H) return;
+    const int h = (int)(gid % H);
+    const long long n = gid / H;
+    const int t = (int)(n % T), b = (int)(n / T);
+    const bf16_t* x = qk + (size_t)b * bs + (size_t)t * rs + h * dh;
+    const size_t o = (size_t)n * H * dh + (size_t)h * dh;
+    float m = 0.f, dot = 0.f;
+    for (int e = 0; e < dh; e++) { const float xv = bf2f(x[e]); m += xv * xv; dot += dkp[o + e] * xv; }
+    m = m / (float)dh + 1e-6f;
+    const float rs_ = rsqrtf(m);
+    const float f = rs_ * rsqrtf((float)dh);
+    const float c = dot * rs_ * rs_ * rs_ / ((float)dh * sqrtf((float)dh));
+    for (int e = 0; e < dh; e++) dqk[o + e] = f2bf(dq[o + e] + f * dkp[o + e] - bf2f(x[e]) * c);
+}
+
+// out[b,t,h,:] = sum_r w_r out_r[b,r,t,h,:],  w = softmax_r(lse[b,r,h,t])
+__global__ void lsh_combine_kernel(const bf16_t* out_r, const float* lse, bf16_t* out, int B, int T, int H, int dh, int n_h) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = H * dh;
+    if (gid >= (long long)B * T * d) return;
+    const int k = (int)(gid % d), h = k / dh;
+    const long long n = gid / d;
+    const int t = (int)(n % T), b = (int)(n / T);
+    float mx = -INFINITY;
+    for (int r = 0; r < n_h; r++) mx = fmaxf(mx, lse[(((size_t)b * n_h + r) * H + h) * T + t]);
+    float den = 0.f, acc = 0.f;
+    for (int r = 0; r < n_h; r++) {
+        const float w = __expf(lse[(((size_t)b * n_h + r) * H + h) * T + t] - mx);
+        den += w;
+        acc += w * bf2f(out_r[(((size_t)b * n_h + r) * T + t) * d + k]);
+    }
+    out[gid] = f2bf(acc / den);
+}
+
+// dout_r = w_r * dout ;  dlse_r = w_r * sum_e dout_e (out_r,e - out_e)      one wave-lane group per (b,t,h)
+__global__ void lsh_combine_bwd_kernel(const bf16_t* out_r, const float* lse, const bf16_t* out, const bf16_t* dout,
+                                       bf16_t* dout_r, float* dlse, int B, int T, int H, int dh, int n_h) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b,t,h)
+    if (gid >= (long long)B * T * H) return;
+    const int h = (int)(gid % H);
+    const long long n = gid / H;
+    const int t = (int)(n % T), b = (int)(n / T);
+    const int d = H * dh;
+    float mx = -INFINITY;
+    for (int r = 0; r < n_h; r++) mx = fmaxf(mx, lse[(((size_t)b * n_h + r) * H + h) * T + t]);
+    float den = 0.f;
+    for (int r = 0; r < n_h; r++) den += __expf(lse[(((size_t)b * n_h + r) * H + h) * T + t] - mx);
+    const size_t o = (size_t)n * d + (size_t)h * dh;
+    for (int r = 0; r < n_h; r++) {
+        const size_t si = (((size_t)b * n_h + r) * H + h) * T + t;
+        const float w = __expf(lse[si] - mx) / den;
+        const size_t orr = (((size_t)b * n_h + r) * T + t) * d + (size_t)h * dh;
+        float dot = 0.f;
+        for (int e = 0; e < dh; e++) {
+            const float g = bf2f(dout[o + e]);
+            dot += g * (bf2f(out_r[orr + e]) - bf2f(out[o + e]));
+            dout_r[orr + e] = f2bf(w * g);
+        }
+        dlse[si] = w * dot;
+    }
+}
+
+template <int DH>
+int launch_chunk(const ChunkP& p, int mode, hipStream_t s) {
+    using G = GeoC<DH>;
+    static bool attr = false;
+    const int kv_smem = 2 * 128 * G::ROWB + 128 * 16;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_attn_fwd_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_attn_bwd_q_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int NC = p.S / 64;
+    if (mode == 0) {
+        hipLaunchKernelGGL((chunk_attn_fwd_kernel<DH>), dim3((NC + 1) / 2, p.H, p.B), dim3(256), G::SMEM, s, p);
+    } else {
+        hipLaunchKernelGGL((chunk_attn_bwd_q_kernel<DH>), dim3((NC + 1) / 2, p.H, p.B), dim3(256), G::SMEM, s, p);
+        hipLaunchKernelGGL((chunk_attn_bwd_kv_kernel<DH>), dim3(NC, p.H, p.B), dim3(256), kv_smem, s, p);
+    }
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+int fill_chunk(ChunkP& p, const void* q, const void* k, const void* v, const int* spos, void* out, float* lse, int B, int T,
+               int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed, unsigned site) {
+    if (!(q && k && v && out && lse)) return MXL_EINVAL;
+    if (!(B > 0 && T > 0 && H > 0 && n_h >= 1 && (T % 64) == 0 && T > 64)) return MXL_EINVAL;
+    if ((rs % 8) || (bs % 8)) return MXL_EINVAL;
+    if (n_h > 1 && !lsh) return MXL_EINVAL;
+    if (lsh && !spos) return MXL_EINVAL;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.spos = spos; p.out = (bf16_t*)out; p.lse = lse;
+    p.dout = nullptr; p.dlse = nullptr; p.dq = p.dk = p.dv = nullptr;
+    p.bs = bs; p.rs = rs; p.B = B; p.T = T; p.H = H; p.S = n_h * T; p.n_h = n_h; p.lsh = lsh;
+    p.scale = 1.f / sqrtf((float)dh);
+    p.thresh = dropout_thresh(drop_p); p.dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.site = site;
+    return MXL_OK;
+}
+
+}  // namespace
+
+extern "C" int mxl_axial_embed_fwd(const void* ids, const void* E, const float* W0, const float* W1, void* out, int B, int T,
+                                   int d, int V, int A0, int A1, int d0, float drop_p, unsigned long long seed,
+                                   unsigned site_emb, unsigned site_pos, void* stream) {
+    MXL_CHECK_ARG(ids && E && W0 && W1 && out && B > 0 && T > 0 && d > 0 && d0 > 0 && d0 < d && T <= A0 * A1);
+    const long long n = (long long)B * T * d;
+    hipLaunchKernelGGL(axial_embed_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const bf16_t*)E, W0, W1, (bf16_t*)out, B, T, d, V, A1, d0, dropout_thresh(drop_p),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site_emb, site_pos);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_axial_embed_bwd(const void* ids, const void* dout, const void* dout2, float* dE, float* dW0, float* dW1,
+                                   int B, int T, int d, int V, int A0, int A1, int d0, float drop_p, unsigned long long seed,
+                                   unsigned site_emb, unsigned site_pos, void* stream) {
+    MXL_CHECK_ARG(ids && dout && dE && dW0 && dW1 && B > 0 && T > 0 && d0 > 0 && d0 < d && T <= A0 * A1);
+    const long long n = (long long)B * T * d;
+    hipLaunchKernelGGL(axial_embed_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const bf16_t*)dout, (const bf16_t*)dout2, dE, dW0, dW1, B, T, d, V, A1, d0,
+                       dropout_thresh(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site_emb, site_pos);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* rotations, int* buckets, int B, int T, int H,
+                            int dh, int n_h, int nfac, const int* factors_host, void* stream) {
+    MXL_CHECK_ARG(qk && rotations && buckets && factors_host && B > 0 && T > 0 && H > 0 && n_h >= 1 && nfac >= 1 && nfac <= 4);
+    HashGeom g;
+    g.nfac = nfac;
+    int R2 = 0, NB = 1;
+    for (int i = 0; i < 4; i++) g.fac[i] = 2;
+    for (int i = 0; i < nfac; i++) {
+        MXL_CHECK_ARG(factors_host[i] >= 2 && (factors_host[i] % 2) == 0);
+        g.fac[i] = factors_host[i]; R2 += factors_host[i] / 2; NB *= factors_host[i];
+    }
+    MXL_CHECK_ARG(R2 <= MAX_R2 && (size_t)dh * R2 * 4 <= 48 * 1024);
+    hipLaunchKernelGGL(lsh_hash_kernel, dim3((T + 255) / 256, H * n_h, B), dim3(256), (size_t)dh * R2 * 4, (hipStream_t)stream,
+                       (const bf16_t*)qk, bs, rs, rotations, buckets, B, T, H, dh, n_h, R2, NB, g);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, int S, int T, int n_buckets_total,
+                            void* stream) {
+    MXL_CHECK_ARG(buckets && sorted_idx && sorted_pos && BH > 0 && S > 0 && T > 0 && n_buckets_total > 0 && n_buckets_total <= 8192);
+    hipLaunchKernelGGL(lsh_sort_kernel, dim3(BH), dim3(64), (size_t)n_buckets_total * 4, (hipStream_t)stream, buckets, sorted_idx,
+                       sorted_pos, S, T, n_buckets_total);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, const int* sorted_pos, void* out, float* lse,
+                                  int B, int T, int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p,
+                                  unsigned long long seed, unsigned site, void* stream) {
+    ChunkP p;
+    int rc = fill_chunk(p, q, k, v, sorted_pos, out, lse, B, T, H, dh, n_h, lsh, bs, rs, drop_p, seed, site);
+    if (rc) return rc;
+    switch (dh) {
+        case 16: return launch_chunk<16>(p, 0, (hipStream_t)stream);
+        case 32: return launch_chunk<32>(p, 0, (hipStream_t)stream);
+        case 64: return launch_chunk<64>(p, 0, (hipStream_t)stream);
+        default: return MXL_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out,
+                                  const float* lse, const void* dout, const float* dlse, float* dq, float* dk, float* dv, int B,
+                                  int T, int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p,
+                                  unsigned long long seed, unsigned site, void* stream) {
+    ChunkP p;
+    int rc = fill_chunk(p, q, k, v, sorted_pos, (void*)out, (float*)lse, B, T, H, dh, n_h, lsh, bs, rs, drop_p, seed, site);
+    if (rc) return rc;
+    MXL_CHECK_ARG(dout && dq && dk && dv);
+    p.dout = (const bf16_t*)dout; p.dlse = dlse; p.dq = dq; p.dk = dk; p.dv = dv;
+    switch (dh) {
+        case 16: return launch_chunk<16>(p, 1, (hipStream_t)stream);
+        case 32: return launch_chunk<32>(p, 1, (hipStream_t)stream);
+        case 64: return launch_chunk<64>(p, 1, (hipStream_t)stream);
+        default: return MXL_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int B,
+                                   int T, int H, int dh, void* stream) {
+    MXL_CHECK_ARG(qk && dq && dk_eff && dqk && B > 0 && T > 0 && H > 0 && dh > 0);
+    const long long n = (long long)B * T * H;
+    hipLaunchKernelGGL(lsh_keynorm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, B, T, H, dh);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T, int H, int dh, int n_h, void* stream) {
+    MXL_CHECK_ARG(out_r && lse && out && B > 0 && T > 0 && n_h >= 1);
+    const long long n = (long long)B * T * H * dh;
+    hipLaunchKernelGGL(lsh_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)out_r, lse, (bf16_t*)out, B, T, H, dh, n_h);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r,
+                                   float* dlse, int B, int T, int H, int dh, int n_h, void* stream) {
+    MXL_CHECK_ARG(out_r && lse && out && dout && dout_r && dlse && B > 0 && T > 0 && n_h >= 1);
+    const long long n = (long long)B * T * H;
+    hipLaunchKernelGGL(lsh_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)out_r, lse, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dout_r, dlse, B, T, H, dh, n_h);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

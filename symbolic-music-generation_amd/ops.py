@@ -245,3 +245,54 @@ def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=
 
 def decode_advance(t_dev, rng_ctr):
     check(lib().mxl_decode_advance(_p(t_dev), _p(rng_ctr), _stream()), 'mxl_decode_advance')
+
+
+# ------------------------------------------------------------------ reformer
+def axial_embed_fwd(ids, E, W0, W1, out, A0, A1, drop_p=0.0, seed=0, site_emb=0, site_pos=1):
+    B, T = ids.shape
+    d, d0 = E.shape[1], W0.shape[-1]
+    check(lib().mxl_axial_embed_fwd(_p(ids), _p(E), _p(W0), _p(W1), _p(out), B, T, d, E.shape[0], A0, A1, d0, float(drop_p),
+                                    seed, site_emb, site_pos, _stream()), 'mxl_axial_embed_fwd')
+    return out
+
+
+def axial_embed_bwd(ids, dout, dE, dW0, dW1, A0, A1, drop_p=0.0, seed=0, site_emb=0, site_pos=1, dout2=None):
+    B, T = ids.shape
+    d, d0 = dE.shape[1], dW0.shape[-1]
+    check(lib().mxl_axial_embed_bwd(_p(ids), _p(dout), _p(dout2), _p(dE), _p(dW0), _p(dW1), B, T, d, dE.shape[0], A0, A1, d0,
+                                    float(drop_p), seed, site_emb, site_pos, _stream()), 'mxl_axial_embed_bwd')
+
+
+def lsh_hash(qk, bs, rs, rotations, buckets, B, T, H, dh, n_h, factors):
+    arr = (C.c_int * len(factors))(*factors)
+    check(lib().mxl_lsh_hash(_p(qk), bs, rs, _p(rotations), _p(buckets), B, T, H, dh, n_h, len(factors),
+                             C.cast(arr, C.c_void_p), _stream()), 'mxl_lsh_hash')
+    return buckets
+
+
+def lsh_sort(buckets, sorted_idx, sorted_pos, BH, S, T, n_buckets_total):
+    check(lib().mxl_lsh_sort(_p(buckets), _p(sorted_idx), _p(sorted_pos), BH, S, T, n_buckets_total, _stream()), 'mxl_lsh_sort')
+
+
+def chunk_attn_fwd(q, k, v, spos, out, lse, B, T, H, dh, n_h, lsh, bs, rs, drop_p=0.0, seed=0, site=0):
+    check(lib().mxl_chunk_attn_fwd(_p(q), _p(k), _p(v), _p(spos), _p(out), _p(lse), B, T, H, dh, n_h, int(lsh), bs, rs,
+                                   float(drop_p), seed, site, _stream()), 'mxl_chunk_attn_fwd')
+
+
+def chunk_attn_bwd(q, k, v, spos, out, lse, dout, dlse, dq, dk, dv, B, T, H, dh, n_h, lsh, bs, rs, drop_p=0.0, seed=0, site=0):
+    check(lib().mxl_chunk_attn_bwd(_p(q), _p(k), _p(v), _p(spos), _p(out), _p(lse), _p(dout), _p(dlse), _p(dq), _p(dk), _p(dv),
+                                   B, T, H, dh, n_h, int(lsh), bs, rs, float(drop_p), seed, site, _stream()),
+          'mxl_chunk_attn_bwd')
+
+
+def lsh_keynorm_bwd(qk, bs, rs, dq, dk_eff, dqk, B, T, H, dh):
+    check(lib().mxl_lsh_keynorm_bwd(_p(qk), bs, rs, _p(dq), _p(dk_eff), _p(dqk), B, T, H, dh, _stream()), 'mxl_lsh_keynorm_bwd')
+
+
+def lsh_combine(out_r, lse, out, B, T, H, dh, n_h):
+    check(lib().mxl_lsh_combine(_p(out_r), _p(lse), _p(out), B, T, H, dh, n_h, _stream()), 'mxl_lsh_combine')
+
+
+def lsh_combine_bwd(out_r, lse, out, dout, dout_r, dlse, B, T, H, dh, n_h):
+    check(lib().mxl_lsh_combine_bwd(_p(out_r), _p(lse), _p(out), _p(dout), _p(dout_r), _p(dlse), B, T, H, dh, n_h, _stream()),
+          'mxl_lsh_combine_bwd')
