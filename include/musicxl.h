@@ -39,6 +39,7 @@ const char* mxl_error_string(int code);
 #define MXL_GEMM_RELU           0x08  /* max(.,0)            (CoreNet.1)                         */
 #define MXL_GEMM_DROPOUT        0x10  /* inverted dropout with the (seed, site, m*N+n) keep-mask */
 #define MXL_GEMM_RELU_BWD       0x20  /* C = aux[m][n] > 0 ? acc : 0  (backward through relu+dropout) */
+#define MXL_GEMM_ADD_AUX        0x40  /* C = epilogue(acc) + aux[m][n]  (residual add after bias/dropout)  */
 int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                   int transA, int transB, int flags, float alpha, const float* bias,
                   const void* aux, int ldaux, int ksplits,
@@ -102,6 +103,10 @@ int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, cons
 int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                         const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
                         float drop_p, unsigned long long seed, unsigned site, void* stream);
+/* same, with an extra gradient stream added to the residual output: dres = dz + dadd (Reformer's y1 = x1 + f(x2) chains) */
+int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                            const float* gamma, const void* dadd, void* dres, float* dgamma, float* dbeta, int N, int d,
+                            void* stream);
 /* out[b][t][:] = bf16(x[b][t][:] + bias[:]) with x strided (x_bs, x_rs elements), out compact (B,T,n) */
 int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* bias, void* out, int B, int T, int n,
                          void* stream);

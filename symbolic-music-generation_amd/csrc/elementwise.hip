@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, int N,
                                                          int d, unsigned thresh, float dscale, unsigned long long seed,
-                                                         unsigned site) {
+                                                         unsigned site, const bf16_t* dadd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [d] dgamma partial
     float* sb = sg + d;                              // [d] dbeta partial
@@ -193,6 +193,11 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
                     if (thresh) ox[j] = dropout_keep(seed, site, (uint64_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
                 }
                 if (dres) {
+                    if (dadd) {
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(dadd + (size_t)row * d + c * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) o[j] += bf2f((bf16_t)av[j]);
+                    }
                     u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
                     *reinterpret_cast<u32x4*>(dres + (size_t)row * d + c * 8) = ov;
                 }
@@ -347,7 +352,18 @@ extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* 
     hipLaunchKernelGGL(ln_res_bwd_kernel, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
-                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                       const float* gamma, const void* dadd, void* dres, float* dgamma, float* dbeta, int N,
+                                       int d, void* stream) {
+    MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dres && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    hipLaunchKernelGGL(ln_res_bwd_kernel, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
+                       (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

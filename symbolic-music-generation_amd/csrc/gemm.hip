@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
                         v[r] = a > 0.f ? v[r] : 0.f;
                     }
             }
+            if (flags & MXL_GEMM_ADD_AUX) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+            }
             if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
                 float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
 #pragma unroll
@@ -258,11 +263,12 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     MXL_CHECK_ARG(transB ? ldb >= ((N + 7) & ~7) : ldb >= K);
     MXL_CHECK_ARG(ldc >= N);
     if (flags & MXL_GEMM_BIAS) MXL_CHECK_ARG(bias != nullptr);
-    if (flags & MXL_GEMM_RELU_BWD) MXL_CHECK_ARG(aux != nullptr && ldaux >= N);
+    if (flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) MXL_CHECK_ARG(aux != nullptr && ldaux >= N);
+    MXL_CHECK_ARG(!((flags & MXL_GEMM_RELU_BWD) && (flags & MXL_GEMM_ADD_AUX)));
     if (ksplits < 1) ksplits = 1;
     if (ksplits > 1) {
         MXL_CHECK_ARG(flags & MXL_GEMM_OUT_F32_ATOMIC);
-        MXL_CHECK_ARG(!(flags & (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_RELU_BWD)));
+        MXL_CHECK_ARG(!(flags & (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)));
     }
     GemmP p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;

@@ -37,8 +37,9 @@ def layer_buckets(layout, n_layer: int) -> Tuple[List[List[Tuple[int, int]]], Li
 
     per_layer = []
     covered = []
+    prefix = getattr(layout, 'layer_prefix', lambda l: f'transformer.layers.{l}.')
     for l in range(n_layer):
-        offs = span(f'transformer.layers.{l}.')
+        offs = span(prefix(l))
         dec = [o for o in offs if o[0] < layout.n_decay]
         nod = [o for o in offs if o[0] >= layout.n_decay]
         sl = [(min(o[0] for o in dec), _r8(max(o[1] for o in dec))), (min(o[0] for o in nod), _r8(max(o[1] for o in nod)))]
@@ -71,7 +72,8 @@ class GradSync:
 
     def __init__(self, engine):
         self.engine = engine
-        self.per_layer, self.rest = layer_buckets(engine.layout, engine.cfg.n_layer)
+        n_layer = getattr(engine.cfg, 'n_layer', None) or len(engine.cfg.attn_layers)
+        self.per_layer, self.rest = layer_buckets(engine.layout, n_layer)
         self.pending = []
 
     def layer_done(self, l: int):

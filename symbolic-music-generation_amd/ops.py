@@ -17,6 +17,7 @@ GEMM_BIAS = 0x04
 GEMM_RELU = 0x08
 GEMM_DROPOUT = 0x10
 GEMM_RELU_BWD = 0x20
+GEMM_ADD_AUX = 0x40
 
 
 def _stream() -> int:
@@ -113,6 +114,14 @@ def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, drop
     check(lib().mxl_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx),
                                     _p(dgamma), _p(dbeta), N, d, float(drop_p), seed, site, _stream()),
           'mxl_ln_residual_bwd')
+
+
+def ln_bwd_add(dy, dy2, z, mean, rstd, gamma, dadd, dres, dgamma, dbeta):
+    """dres = LayerNorm-backward(dy + dy2) + dadd"""
+    d = z.shape[-1]
+    N = z.numel() // d
+    check(lib().mxl_ln_residual_bwd_add(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dadd), _p(dres), _p(dgamma),
+                                        _p(dbeta), N, d, _stream()), 'mxl_ln_residual_bwd_add')
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int] = None):

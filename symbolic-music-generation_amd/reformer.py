@@ -1,0 +1,165 @@
+"""Drop-in surface for `musicnlp.models.reformer` (reference: musicnlp/models/reformer.py:13-127): `MyReformerConfig`
+(presets, derived fields, tokenizer ids, axial assert) and `MyReformerModelWithLMHead` (pass-through forward accepting
+`key_scores`), on the HIP engine `rf_engine.RFEngine` instead of HuggingFace `ReformerModelWithLMHead`."""
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+
+from .rf_engine import RFEngine
+
+__all__ = ['MyReformerConfig', 'MyReformerModelWithLMHead']
+
+
+class MyReformerConfig:
+    _layer_pair = ['local', 'lsh']
+    presets = {   # reformer.py:15-44
+        'debug': dict(max_position_embeddings=64, axial_pos_shape=(8, 8), hidden_size=128, num_attention_heads=8, attn_layers=_layer_pair * 3),
+        'debug-large': dict(max_position_embeddings=512, axial_pos_shape=(16, 32), hidden_size=128, num_attention_heads=8, attn_layers=_layer_pair * 3),
+        'tiny': dict(max_position_embeddings=1024, axial_pos_shape=(32, 32), hidden_size=256, num_attention_heads=8, attn_layers=_layer_pair * 3),
+        'small': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=512, num_attention_heads=8, attn_layers=_layer_pair * 3),
+        'base': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=768, num_attention_heads=12, attn_layers=_layer_pair * 6, num_hashes=2),
+        'large': dict(max_position_embeddings=2048, axial_pos_shape=(32, 64), hidden_size=1024, num_attention_heads=16, attn_layers=_layer_pair * 12, num_hashes=2),
+    }
+    # HF ReformerConfig defaults in force (logged config, notebook/train/reformer.ipynb cell 10)
+    _hf_defaults = dict(
+        vocab_size=320, num_hashes=1, num_buckets=None, lsh_attn_chunk_length=64, local_attn_chunk_length=64,
+        lsh_num_chunks_before=1, lsh_num_chunks_after=0, local_num_chunks_before=1, local_num_chunks_after=0,
+        hidden_act='relu', hidden_dropout_prob=0.05, lsh_attention_probs_dropout_prob=0.0,
+        local_attention_probs_dropout_prob=0.05, layer_norm_eps=1e-12, axial_norm_std=1.0, initializer_range=0.02,
+        chunk_size_lm_head=0, chunk_size_feed_forward=0, tie_word_embeddings=False, hash_seed=None, axial_pos_embds=True,
+        eos_token_id=2, pad_token_id=0, is_decoder=False,
+    )
+    model_type = 'reformer'
+
+    def __init__(self, model_size: str = 'base', tokenizer=None, **kwargs):
+        d_config = dict(self._hf_defaults)
+        preset = {k: (list(v) if isinstance(v, list) else v) for k, v in MyReformerConfig.presets[model_size].items()}
+        hd_sz, n_head = preset['hidden_size'], preset['num_attention_heads']
+        assert hd_sz % n_head == 0 and hd_sz % 4 == 0                                  # :46-48
+        preset.update(feed_forward_size=hd_sz * 4, attention_head_size=hd_sz // n_head,
+                      axial_pos_embds_dim=(hd_sz // 4, 3 * hd_sz // 4), is_decoder=True, num_buckets=None)   # :49-55
+        d_config.update(preset)
+        if tokenizer is not None:                                                       # :59-67
+            d_config.update(eos_token_id=tokenizer.eos_token_id, pad_token_id=tokenizer.pad_token_id,
+                            vocab_size=tokenizer.vocab_size)
+        d_config.update(kwargs)
+        for k, v in d_config.items():
+            setattr(self, k, v)
+        self.model_size = model_size
+        self.axial_pos_shape = tuple(self.axial_pos_shape)
+        self.axial_pos_embds_dim = tuple(self.axial_pos_embds_dim)
+        aps, mpe = self.axial_pos_shape, self.max_position_embeddings
+        assert len(aps) == 2 and aps[0] * aps[1] == mpe, \
+            'the product of `axial_pos_shape` must be `max_position_embeddings`'        # :71-73
+        if self.hidden_act != 'relu' or self.chunk_size_lm_head or self.chunk_size_feed_forward:
+            raise NotImplementedError('only the reference configuration (relu, no FF / LM-head chunking) is implemented')
+        self.use_return_dict = True
+
+    @property
+    def max_length_(self) -> int:                                                       # :75-77
+        return self.max_position_embeddings
+
+    @property
+    def model_meta(self) -> Dict[str, Any]:                                             # :79-87
+        return dict(axial_pos_shape=self.axial_pos_shape, n_layer=len(self.attn_layers), hidden_size=self.hidden_size,
+                    ff_size=self.feed_forward_size,
+                    attention_shape=f'{self.num_attention_heads}x{self.attention_head_size}', vocab_size=self.vocab_size)
+
+    def to_dict(self):
+        return {k: v for k, v in self.__dict__.items() if not k.startswith('_') and k != 'use_return_dict'}
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, 'config.json'), 'w') as f:
+            json.dump(self.to_dict(), f, indent=2)
+
+    @classmethod
+    def from_pretrained(cls, path):
+        with open(os.path.join(path, 'config.json')) as f:
+            d = json.load(f)
+        return cls(model_size=d.pop('model_size', 'base'), **d)
+
+
+@dataclass
+class ReformerModelWithLMHeadOutput:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_buckets_states: Any = None
+    hidden_states: Any = None
+    attentions: Any = None
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return tuple(v for v in (self.loss, self.logits) if v is not None)[k]
+
+
+class MyReformerModelWithLMHead:
+    cls_name = 'Reformer'
+
+    def __init__(self, config: MyReformerConfig, device='cuda:0', seed: int = 77):
+        self.config = config
+        self.engine = RFEngine(config, device, seed=seed)
+        self.training = True
+        self.device = torch.device(device)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *_a, **_k):
+        return self
+
+    def num_parameters(self):
+        return self.engine.num_parameters()
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd, strict=strict)
+
+    def save_pretrained(self, path):
+        self.config.save_pretrained(path)
+        torch.save(self.state_dict(), os.path.join(path, 'pytorch_model.bin'))
+
+    @classmethod
+    def from_pretrained(cls, path, device='cuda:0'):
+        m = cls(MyReformerConfig.from_pretrained(path), device=device)
+        m.load_state_dict(torch.load(os.path.join(path, 'pytorch_model.bin'), map_location='cpu'))
+        return m
+
+    def forward(self, key_scores=None, input_ids=None, position_ids=None, attention_mask=None, head_mask=None,
+                inputs_embeds=None, num_hashes=None, past_buckets_states=None, use_cache=None, output_hidden_states=None,
+                output_attentions=None, return_dict=None, labels=None, rotations=None, buckets=None):
+        """reformer.py:96-127.  The tokenizer never emits an attention mask (model_input_names = ['input_ids']), so pad
+        tokens are attended to and only dropped from the loss -- as in the reference.  `rotations` / `buckets`
+        ({lsh layer index: tensor}) make the hashing an explicit input for parity tests."""
+        if input_ids is None:
+            raise ValueError('input_ids required')
+        if any(x is not None for x in (position_ids, attention_mask, head_mask, inputs_embeds, past_buckets_states)) \
+                or use_cache or output_hidden_states or output_attentions:
+            raise NotImplementedError('only the arguments the reference passes (input_ids, labels) are implemented')
+        if num_hashes is not None and num_hashes != self.config.num_hashes:
+            raise NotImplementedError('per-call num_hashes override')
+        out = self.engine.forward(input_ids.to(self.device), labels=None if labels is None else labels.to(self.device),
+                                  train=self.training, rotations=rotations, buckets_override=buckets)
+        res = ReformerModelWithLMHeadOutput(loss=out['loss'], logits=out['logits'])
+        return res[:] if return_dict is False else res
+
+    __call__ = forward
+
+    def backward(self, grad_scale=1.0, layer_done=None):
+        self.engine.backward(grad_scale=grad_scale, layer_done=layer_done)
+
+    def zero_grad(self):
+        self.engine.zero_grad()
+
+    def generate(self, *a, **k):
+        raise NotImplementedError('Reformer incremental decoding (HF ReformerDynamicCache path) is not built yet; see DESIGN.md')
