@@ -296,13 +296,9 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const uint32_t w = pack2bf(s[kb][8 * st + j], s[kb][8 * st + j + 1]);
-                        pf[j] = (short)(w & 0xffff);
-                        pf[j + 1] = (short)(w >> 16);
-                    }
+                    const u32x4 pw = {pack2bf(s[kb][8 * st], s[kb][8 * st + 1]), pack2bf(s[kb][8 * st + 2], s[kb][8 * st + 3]),
+                                      pack2bf(s[kb][8 * st + 4], s[kb][8 * st + 5]), pack2bf(s[kb][8 * st + 6], s[kb][8 * st + 7])};
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
                     for (int e = 0; e < EB; e++) {
                         const int key = 32 * kb + 16 * st + 4 * hh + q4;
@@ -406,7 +402,7 @@ template <int DH> struct GeoK {
 };
 
 template <int DH>
-__global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(BwdP p) {
+__global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     using G = GeoK<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -589,14 +585,11 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(BwdP p) {
             const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
 #pragma unroll
             for (int st = 0; st < 2; st++) {
-                bf16x8 pf, df;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const uint32_t w = pack2bf(pr[8 * st + j], pr[8 * st + j + 1]);
-                    pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
-                    const uint32_t w2 = pack2bf(s[8 * st + j], s[8 * st + j + 1]);
-                    df[j] = (short)(w2 & 0xffff); df[j + 1] = (short)(w2 >> 16);
-                }
+                const u32x4 pw = {pack2bf(pr[8 * st], pr[8 * st + 1]), pack2bf(pr[8 * st + 2], pr[8 * st + 3]),
+                                  pack2bf(pr[8 * st + 4], pr[8 * st + 5]), pack2bf(pr[8 * st + 6], pr[8 * st + 7])};
+                const u32x4 dw = {pack2bf(s[8 * st], s[8 * st + 1]), pack2bf(s[8 * st + 2], s[8 * st + 3]),
+                                  pack2bf(s[8 * st + 4], s[8 * st + 5]), pack2bf(s[8 * st + 6], s[8 * st + 7])};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), df = __builtin_bit_cast(bf16x8, dw);
 #pragma unroll
                 for (int e = 0; e < EB; e++) {
                     const int qrow = 16 * st + 4 * hh + q4;

@@ -15,6 +15,7 @@
 // lane-local.  The rel-shift (BD[i,p] = G[i, i-p]) is a lane-private LDS round trip: lane writes its column of G^T as a
 // row [query][distance & 127] and reads it back at distance i - p.  P stays in registers and feeds O^T += V^T.P^T directly
 // (accumulator-as-operand, V^T fragments via ds_read_b64_tr_b16).
+#include <type_traits>
 #include "common.h"
 #include "musicxl_internal.h"
 
@@ -36,7 +37,7 @@ struct RelAttnP {
 
 constexpr int QB = 128;      // queries per workgroup
 constexpr int KT = 64;       // keys per tile
-constexpr int GRS = 132;     // skew-buffer row stride in floats (even -> conflict-free skewed reads; %4 -> b128 writes)
+constexpr int GS = 100;      // skew buffer: 96 distance columns (+4 pad) per query row, fp16 -> 200-byte rows
 constexpr float NEG_BIG = -1.0e30f;
 
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -52,8 +53,8 @@ template <int DH> struct Geo {
     static constexpr int K_BYTES = KT * ROWB;
     static constexpr int V_BYTES = KT * VROWB;
     static constexpr int R_BYTES = 256 * ROWB;
-    static constexpr int G_BYTES = 4 * 32 * GRS * 4;
-    static constexpr int SMEM = 2 * K_BYTES + 2 * V_BYTES + R_BYTES + G_BYTES;
+    static constexpr int G_BYTES = 4 * 32 * GS * 2;
+    static constexpr int SMEM = K_BYTES + V_BYTES + R_BYTES + G_BYTES;   // 73 KiB at DH = 64: two workgroups per CU
     static constexpr int NLD_K = (KT * CH + 255) / 256;  // 16-byte chunks per thread per tile
     static constexpr int NLD_V = (KT * CH + 255) / 256;
     __device__ static __forceinline__ int koff(int row, int ch) {  // K / Rd image: [row][DH], XOR swizzle for 128-B rows
@@ -66,15 +67,38 @@ template <int DH> struct Geo {
     }
 };
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+
+// 16 skewed fp16 reads of one 32-key block as genuine ds_read_u16 (the compiler would fuse the constant-offset reads into
+// ds_read_b64 at lane-dependent, mis-aligned addresses: 64-cycle replays each, SQ_LDS_UNALIGNED_STALL).  `base` is the LDS
+// byte address of column (r - 4*hh + 64 - 32*kb - 27) of this lane's row; register j reads column offset 27 - pat(j),
+// pat(j) = (j & 3) + 8 * (j >> 2).  Loads and their wait sit in ONE asm statement (hipcc does not count asm loads).
+__device__ __forceinline__ void skew_read16(uint32_t base, uint32_t (&u)[16]) {
+    asm volatile(
+        "ds_read_u16 %0, %16 offset:54\n\t"  "ds_read_u16 %1, %16 offset:52\n\t"  "ds_read_u16 %2, %16 offset:50\n\t"
+        "ds_read_u16 %3, %16 offset:48\n\t"  "ds_read_u16 %4, %16 offset:38\n\t"  "ds_read_u16 %5, %16 offset:36\n\t"
+        "ds_read_u16 %6, %16 offset:34\n\t"  "ds_read_u16 %7, %16 offset:32\n\t"  "ds_read_u16 %8, %16 offset:22\n\t"
+        "ds_read_u16 %9, %16 offset:20\n\t"  "ds_read_u16 %10, %16 offset:18\n\t" "ds_read_u16 %11, %16 offset:16\n\t"
+        "ds_read_u16 %12, %16 offset:6\n\t"  "ds_read_u16 %13, %16 offset:4\n\t"  "ds_read_u16 %14, %16 offset:2\n\t"
+        "ds_read_u16 %15, %16\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
+          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
+        : "v"(base)
+        : "memory");
+}
+
 template <int DH>
-__global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
+__global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     using G = Geo<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                          // [2][64][DH]
-    char* sV = sK + 2 * G::K_BYTES;           // [2][64][VW]
-    char* sR = sV + 2 * G::V_BYTES;           // ring [256][DH]
-    float* sG = reinterpret_cast<float*>(sR + G::R_BYTES);  // [4][32][GRS]
+    char* sK = smem;                          // [64][DH]
+    char* sV = sK + G::K_BYTES;               // [64][VW]
+    char* sR = sV + G::V_BYTES;               // ring [256][DH]
+    _Float16* sG = reinterpret_cast<_Float16*>(sR + G::R_BYTES);  // [4][32][GS] fp16
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
@@ -83,7 +107,13 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
     const int iw0 = i0 + 32 * wid;
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;  // lowest stored key position
-    float* myG = sG + wid * 32 * GRS + r * GRS;
+    // skew buffer of this wave: row = query, column c = distance - dlo in [0, 96).  All addresses are per-lane constants
+    // plus immediates: writes land at column 32*gb + 8*grp + 4*hh, the read of score (kb, j) at column r - jj + 64.
+    _Float16* gW = sG + wid * 32 * GS + r * GS + 4 * hh;
+    const _Float16* gR = sG + wid * 32 * GS + r * GS + r + 64 - 4 * hh;
+    // LDS byte address of column (r - 4hh + 64 - 27) for skew_read16 (key block kb subtracts 32 columns = 64 bytes)
+    const uint32_t gRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(gR - 27);
+    f16x4 carry[4];   // block 0 of the previous tile (= block 2 of this one), kept in registers
 
     const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
     const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
@@ -127,14 +157,14 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
             rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
         }
     };
-    auto store_kv = [&](int buf) {
+    auto store_kv = [&]() {
 #pragma unroll
         for (int n = 0; n < G::NLD_K; n++) {
             const int c = tid + n * 256;
             if (c < KT * G::CH) {
                 const int row = c / G::CH, ch = c % G::CH;
-                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = rk[n];
-                *reinterpret_cast<u32x4*>(sV + buf * G::V_BYTES + G::voff(row, ch * 16)) = rv[n];
+                *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = rk[n];
+                *reinterpret_cast<u32x4*>(sV + G::voff(row, ch * 16)) = rv[n];
             }
         }
     };
@@ -164,15 +194,71 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
 
     // zero the V pad columns once (DH < 32): tr-reads of O^T rows >= DH must see zeros
     if (DH < G::VW) {
-        for (int i = tid; i < 2 * G::V_BYTES / 4; i += 256) reinterpret_cast<uint32_t*>(sV)[i] = 0u;
+        for (int i = tid; i < G::V_BYTES / 4; i += 256) reinterpret_cast<uint32_t*>(sV)[i] = 0u;
         __syncthreads();
+    }
+
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // ---- phantom keys.  Key positions below the first stored tile (pz) are upstream's zero mems: k = v = 0, so such a key
+    // contributes exp(BD) to the softmax denominator and nothing else, and BD depends only on the distance.  Instead of
+    // walking those key tiles (S, skew, PV all wasted) walk the DISTANCES d in [i - pz + 1, M - 1] block-wise: G^T blocks
+    // straight from the accumulators, no skew, no K/V traffic.  The tile loop then starts at tile pz.
+    const int pz = floordiv(p0, KT) * KT;
+    int kt_start = kt_lo;
+    if (kt_lo * KT < pz) {
+        kt_start = pz / KT;
+        const int qi = iw0 + r;
+        load_r(i0 - pz);
+#pragma unroll 1
+        for (int db = i0 - pz; db <= M - 1; db += 64) {
+            store_r(db);
+            __syncthreads();
+            if (db + 64 <= M - 1) load_r(db + 64);      // prefetch the next chunk while this one is consumed
+            if (iw0 < T) {
+#pragma unroll 1
+                for (int gb = 0; gb < 2; gb++) {
+                    const int dblk = db + 32 * gb;
+                    if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform: no phantom cell in this block
+                    f32x16 g;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) g[j] = 0.f;
+                    const int slot = (dblk + r) & 255;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                    }
+                    float mx = NEG_BIG;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                        const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
+                        g[j] = valid ? g[j] * p.scale_log2e : NEG_BIG;
+                        mx = fmaxf(mx, g[j]);
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run, mx);
+                    float rs = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const float pv = __builtin_amdgcn_exp2f(g[j] - m_new);
+                        rs += (g[j] > 0.5f * NEG_BIG) ? pv : 0.f;
+                    }
+                    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + rs;
+                    m_run = m_new;
+                }
+            }
+            __syncthreads();
+        }
     }
 
     // ---- prologue: first tile + its distance window [i0-P0-64, i0-P0+127] (wave w: dlo_w = i0+32w-P0-64, 96 rows)
     {
-        const int P0 = kt_lo * KT;
-        load_kv(kt_lo);
-        store_kv(0);
+        const int P0 = kt_start * KT;
+        load_kv(kt_start);
+        store_kv();
 #pragma unroll 1
         for (int q4 = 0; q4 < 3; q4++) {
             const int dbase = i0 - P0 - 64 + 64 * q4;
@@ -187,12 +273,10 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
     for (int e = 0; e < EB; e++)
 #pragma unroll
         for (int j = 0; j < 16; j++) o[e][j] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
     bool have_ring = false;
-    int cur = 0;
 
 #pragma unroll 1
-    for (int kt = kt_lo; kt <= kt_hi; kt++) {
+    for (int kt = kt_start; kt <= kt_hi; kt++) {
         const int P = kt * KT;
         const bool more = kt < kt_hi;
         if (more) {
@@ -202,8 +286,8 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
         const int dmin_w = iw0 - P - (KT - 1), dmax_w = iw0 + 31 - P;
         const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);
         if (active) {
-            const char* cK = sK + cur * G::K_BYTES;
-            const char* cV = sV + cur * G::V_BYTES;
+            const char* cK = sK;
+            const char* cV = sV;
             const int dlo = iw0 - P - 64;
             // ---- S^T = K . Qw^T : two 32-key blocks
             f32x16 s[2];
@@ -218,10 +302,8 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
                                                                     __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
                 }
             }
-            // ---- G^T = Rd . Qr^T for the new distance blocks, written to the lane-private skew ring
-            const int nb = have_ring ? 2 : 3;
-#pragma unroll 1
-            for (int gb = 0; gb < nb; gb++) {
+            // ---- G^T = Rd . Qr^T for the new distance blocks -> lane-private skew buffer (fp16)
+            auto gblock = [&](int gb, f16x4 (&dst)[4]) {
                 f32x16 g;
 #pragma unroll
                 for (int j = 0; j < 16; j++) g[j] = 0.f;
@@ -234,63 +316,82 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
                 }
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++) {
-                    const int d = dlo + 32 * gb + 8 * grp + 4 * hh;
-                    *reinterpret_cast<f32x4*>(myG + (d & 127)) = f32x4{g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    dst[grp] = __builtin_convertvector(v4, f16x4);
                 }
+            };
+            f16x4 b0[4], b1[4];
+            if (!have_ring) gblock(2, carry);
+            gblock(0, b0);
+            gblock(1, b1);
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
+                *reinterpret_cast<f16x4*>(gW + 32 + 8 * grp) = b1[grp];
+                *reinterpret_cast<f16x4*>(gW + 64 + 8 * grp) = carry[grp];
+                carry[grp] = b0[grp];
             }
             have_ring = true;
-            // ---- scores: (AC + BD) * scale, band mask, online softmax (lane = query)
-            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T);
+            // ---- scores: (AC + BD) * scale, band mask, online softmax (lane = query).  Two explicit code paths on a
+            // scalar (readfirstlane) flag: hipcc otherwise if-converts the mask into per-element compares on every tile.
+            const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
             const int qi = iw0 + r;
             float mx = NEG_BIG;
+            auto scores = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
+                for (int kb = 0; kb < 2; kb++) {
+                    uint32_t bdu[16];
+                    skew_read16(gRb - 64 * kb, bdu);
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    const int d = qi - P - jj;
-                    const float bd = myG[d & 127];
-                    float val = (s[kb][j] + bd) * p.scale_log2e;
-                    if (!full) {
-                        const bool valid = (d >= 0) && (d <= M - 1) && (qi < T);
-                        val = valid ? val : NEG_BIG;
+                    for (int j = 0; j < 16; j++) {
+                        const float bd = (float)__builtin_bit_cast(_Float16, (unsigned short)bdu[j]);
+                        float val = (s[kb][j] + bd) * p.scale_log2e;
+                        if (MASKED) {
+                            const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
+                            const bool valid = (d >= 0) && (d <= M - 1) && (qi < T);
+                            val = valid ? val : NEG_BIG;
+                        }
+                        s[kb][j] = val;
+                        mx = fmaxf(mx, val);
                     }
-                    s[kb][j] = val;
-                    mx = fmaxf(mx, val);
                 }
-            }
+            };
+            if (full) scores(std::false_type{}); else scores(std::true_type{});
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             float rs = 0.f;
+            auto probs = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
+                for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    float pv = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
-                    pv = (s[kb][j] > 0.5f * NEG_BIG) ? pv : 0.f;
-                    s[kb][j] = pv;
-                    rs += pv;
+                    for (int j = 0; j < 16; j++) {
+                        float pv = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
+                        if (MASKED) pv = (s[kb][j] > 0.5f * NEG_BIG) ? pv : 0.f;   // exp2(NEG_BIG - NEG_BIG) = 1 otherwise
+                        s[kb][j] = pv;
+                        rs += pv;
+                    }
                 }
-            }
+            };
+            if (full) probs(std::false_type{}); else probs(std::true_type{});
             l_run = l_run * alpha + rs;
+            if (__any(alpha != 1.0f)) {      // row maxima settle after the first tiles: skip the O^T rescale when nothing moved
 #pragma unroll
-            for (int e = 0; e < EB; e++)
+                for (int e = 0; e < EB; e++)
 #pragma unroll
-                for (int j = 0; j < 16; j++) o[e][j] *= alpha;
+                    for (int j = 0; j < 16; j++) o[e][j] *= alpha;
+            }
             // ---- O^T += V^T . P^T
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const uint32_t w = pack2bf(s[kb][8 * st + j], s[kb][8 * st + j + 1]);
-                        pf[j] = (short)(w & 0xffff);
-                        pf[j + 1] = (short)(w >> 16);
-                    }
+                    const u32x4 pw = {pack2bf(s[kb][8 * st], s[kb][8 * st + 1]), pack2bf(s[kb][8 * st + 2], s[kb][8 * st + 3]),
+                                      pack2bf(s[kb][8 * st + 4], s[kb][8 * st + 5]), pack2bf(s[kb][8 * st + 6], s[kb][8 * st + 7])};
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
                     const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
 #pragma unroll
                     for (int e = 0; e < EB; e++) {
@@ -307,12 +408,12 @@ __global__ __launch_bounds__(256, 1) void relattn_fwd_kernel(RelAttnP p) {
                 }
             }
         }
+        __syncthreads();                     // every wave is done reading this tile
         if (more) {
-            store_kv(cur ^ 1);
+            store_kv();
             store_r(i0 - (P + KT) - 64);
         }
         __syncthreads();
-        cur ^= 1;
     }
 
     // ---- epilogue: normalise, store O (lane = query, 4 consecutive e per register group) and LSE
