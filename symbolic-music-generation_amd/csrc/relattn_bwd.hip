@@ -13,6 +13,7 @@
 //                       (q + r_r_bias) by the batched TT GEMM to obtain dRd (a correlation along diagonals that neither a
 //                       query- nor a key-owner can accumulate on chip).
 //   relattn_bwd_dkv   : key-owner (lane = key): dk, dv.
+#include <type_traits>
 #include "common.h"
 #include "musicxl_internal.h"
 
@@ -270,26 +271,31 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 }
             }
             have_ring = true;
-            // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127
-            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T);
+            // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127.  Scalar branch on the
+            // (readfirstlane) full-tile flag, otherwise hipcc if-converts the mask onto every tile.
+            const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
+            auto grads = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
+                for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    const int d = qi - P - jj;
-                    const float bd = myG[d & 127];
-                    const float val = (s[kb][j] + bd) * p.scale_log2e - lse2;
-                    float pv = __builtin_amdgcn_exp2f(val);
-                    if (!full) {
-                        const bool valid = (d >= 0) && (d <= M - 1) && qok;
-                        pv = valid ? pv : 0.f;
+                    for (int j = 0; j < 16; j++) {
+                        const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                        const int d = qi - P - jj;
+                        const float bd = myG[d & 127];
+                        const float val = (s[kb][j] + bd) * p.scale_log2e - lse2;
+                        float pv = __builtin_amdgcn_exp2f(val);
+                        if (MASKED) {
+                            const bool valid = (d >= 0) && (d <= M - 1) && qok;
+                            pv = valid ? pv : 0.f;
+                        }
+                        const float ds = p.scale * pv * (dp[kb][j] - dlt);
+                        s[kb][j] = ds;
+                        myDG[d & 127] = f2bf(ds);
                     }
-                    const float ds = p.scale * pv * (dp[kb][j] - dlt);
-                    s[kb][j] = ds;
-                    myDG[d & 127] = f2bf(ds);
                 }
-            }
+            };
+            if (full) grads(std::false_type{}); else grads(std::true_type{});
             // dQw^T += K^T . dSr^T   (A = K^T through transposed reads of the K image, accumulator-permuted k order)
             const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
 #pragma unroll
@@ -565,22 +571,26 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
                     myS[ii * SKS + 32 * gb + r] = g[j];
                 }
             }
-            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (I + 31 < T);
+            const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (I + 31 < T))) != 0;
             f32x16 pr;
+            auto grads = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                const int d = I + ii - pk;             // = dlo + (ii - r + 32)
-                const float bd = myS[ii * SKS + (ii - r + 32)];
-                const float val = (s[j] + bd) * p.scale_log2e - sLse[ii];
-                float pv = __builtin_amdgcn_exp2f(val);
-                if (!full) {
-                    const bool valid = (d >= 0) && (d <= M - 1) && (I + ii < T);
-                    pv = valid ? pv : 0.f;
+                for (int j = 0; j < 16; j++) {
+                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const float bd = myS[ii * SKS + (ii - r + 32)];
+                    const float val = (s[j] + bd) * p.scale_log2e - sLse[ii];
+                    float pv = __builtin_amdgcn_exp2f(val);
+                    if (MASKED) {
+                        const int d = I + ii - pk;             // = dlo + (ii - r + 32)
+                        const bool valid = (d >= 0) && (d <= M - 1) && (I + ii < T);
+                        pv = valid ? pv : 0.f;
+                    }
+                    pr[j] = pv;
+                    s[j] = p.scale * pv * (dp[j] - sDl[ii]);
                 }
-                pr[j] = pv;
-                s[j] = p.scale * pv * (dp[j] - sDl[ii]);
-            }
+            };
+            if (full) grads(std::false_type{}); else grads(std::true_type{});
             // dV^T += dO^T . P ; dK^T += Qw^T . dSr   (A through transposed reads, accumulator-permuted k order)
             const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
 #pragma unroll
