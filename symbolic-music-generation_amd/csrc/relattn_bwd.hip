@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_delta_kernel(BwdP p, int dh) 
 // query-owner kernel
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int QB = 128, KT = 64;
-constexpr int GRS = 132;   // fp32 skew ring stride (floats)
-constexpr int DGS = 136;   // bf16 un-skew ring stride (elements): 272 B rows keep ds_read_b128 aligned
+constexpr int GS = 100;    // fp16 skew buffer: 96 distance columns (+pad) per query row (see relattn_fwd.hip)
+constexpr int DGS = 104;   // bf16 un-skew buffer: 96 columns (+pad): 208-byte rows keep ds_read_b128 aligned
 
 template <int DH> struct GeoQ {
     static constexpr int KS = DH / 16;
@@ -84,9 +84,9 @@ template <int DH> struct GeoQ {
     static constexpr int CH = DH / 8;
     static constexpr int K_BYTES = KT * ROWB;
     static constexpr int R_BYTES = 256 * ROWB;
-    static constexpr int G_BYTES = 4 * 32 * GRS * 4;
+    static constexpr int G_BYTES = 4 * 32 * GS * 2;
     static constexpr int DG_BYTES = 4 * 32 * DGS * 2;
-    static constexpr int SMEM = 2 * K_BYTES + R_BYTES + G_BYTES + DG_BYTES;
+    static constexpr int SMEM = 4 * K_BYTES + R_BYTES + G_BYTES + DG_BYTES;
     static constexpr int NLD = (KT * CH + 255) / 256;
     __device__ static __forceinline__ int koff(int row, int ch) {
         if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
@@ -96,15 +96,48 @@ template <int DH> struct GeoQ {
     __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
 };
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// see relattn_fwd.hip: 16 genuine ds_read_u16 at column offsets 27 - pat(j) from `base` (bytes), pat(j) = (j&3) + 8*(j>>2)
+__device__ __forceinline__ void skew_read16(uint32_t base, uint32_t (&u)[16]) {
+    asm volatile(
+        "ds_read_u16 %0, %16 offset:54\n\t"  "ds_read_u16 %1, %16 offset:52\n\t"  "ds_read_u16 %2, %16 offset:50\n\t"
+        "ds_read_u16 %3, %16 offset:48\n\t"  "ds_read_u16 %4, %16 offset:38\n\t"  "ds_read_u16 %5, %16 offset:36\n\t"
+        "ds_read_u16 %6, %16 offset:34\n\t"  "ds_read_u16 %7, %16 offset:32\n\t"  "ds_read_u16 %8, %16 offset:22\n\t"
+        "ds_read_u16 %9, %16 offset:20\n\t"  "ds_read_u16 %10, %16 offset:18\n\t" "ds_read_u16 %11, %16 offset:16\n\t"
+        "ds_read_u16 %12, %16 offset:6\n\t"  "ds_read_u16 %13, %16 offset:4\n\t"  "ds_read_u16 %14, %16 offset:2\n\t"
+        "ds_read_u16 %15, %16\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
+          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
+        : "v"(base)
+        : "memory");
+}
+// the mirror image: 16 genuine ds_write_b16 (low halves of u[j]) at the same column pattern
+__device__ __forceinline__ void skew_write16(uint32_t base, const uint32_t (&u)[16]) {
+    asm volatile(
+        "ds_write_b16 %16, %0 offset:54\n\t"  "ds_write_b16 %16, %1 offset:52\n\t"  "ds_write_b16 %16, %2 offset:50\n\t"
+        "ds_write_b16 %16, %3 offset:48\n\t"  "ds_write_b16 %16, %4 offset:38\n\t"  "ds_write_b16 %16, %5 offset:36\n\t"
+        "ds_write_b16 %16, %6 offset:34\n\t"  "ds_write_b16 %16, %7 offset:32\n\t"  "ds_write_b16 %16, %8 offset:22\n\t"
+        "ds_write_b16 %16, %9 offset:20\n\t"  "ds_write_b16 %16, %10 offset:18\n\t" "ds_write_b16 %16, %11 offset:16\n\t"
+        "ds_write_b16 %16, %12 offset:6\n\t"  "ds_write_b16 %16, %13 offset:4\n\t"  "ds_write_b16 %16, %14 offset:2\n\t"
+        "ds_write_b16 %16, %15"
+        :
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]), "v"(u[8]), "v"(u[9]),
+          "v"(u[10]), "v"(u[11]), "v"(u[12]), "v"(u[13]), "v"(u[14]), "v"(u[15]), "v"(base)
+        : "memory");
+}
+
 template <int DH>
 __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     using G = GeoQ<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                       // [64][DH]
-    char* sV = sK + G::K_BYTES;            // [64][DH]  (row reads only here)
-    char* sR = sV + G::K_BYTES;            // ring [256][DH]
-    float* sG = reinterpret_cast<float*>(sR + G::R_BYTES);                       // [4][32][GRS] f32
+    char* sK = smem;                       // [2][64][DH]   double-buffered: one barrier per tile, loads hidden behind compute
+    char* sV = sK + 2 * G::K_BYTES;        // [2][64][DH]
+    char* sR = sV + 2 * G::K_BYTES;        // ring [256][DH]
+    _Float16* sG = reinterpret_cast<_Float16*>(sR + G::R_BYTES);                  // [4][32][GS] fp16
     bf16_t* sDG = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sG) + G::G_BYTES);  // [4][32][DGS] bf16
 
     const int tid = threadIdx.x;
@@ -114,8 +147,14 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     const int iw0 = i0 + 32 * wid;
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;
-    float* myG = sG + wid * 32 * GRS + r * GRS;
-    bf16_t* myDG = sDG + wid * 32 * DGS + r * DGS;
+    // both per-wave buffers use FIXED columns c = distance - dlo in [0, 96): every address is a per-lane constant plus an
+    // immediate.  Carry between tiles (block 0 -> block 2): G in registers, dG by an LDS move of the lane's own row.
+    _Float16* gW = sG + wid * 32 * GS + r * GS + 4 * hh;
+    const _Float16* gR = sG + wid * 32 * GS + r * GS + r + 64 - 4 * hh;
+    const uint32_t gRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(gR - 27);
+    bf16_t* myDG = sDG + wid * 32 * DGS + r * DGS;                 // row of this lane's query
+    const uint32_t dgWb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(myDG + r + 64 - 4 * hh - 27);
+    f16x4 carry[4];
 
     const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
     const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
@@ -170,14 +209,14 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
 #pragma unroll
         for (int n = 0; n < G::NLD; n++) {
             const int c = tid + n * 256;
             if (c < KT * G::CH) {
                 const int row = c / G::CH, ch = c % G::CH;
-                *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = rk[n];
-                *reinterpret_cast<u32x4*>(sV + G::koff(row, ch)) = rv[n];
+                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = rk[n];
+                *reinterpret_cast<u32x4*>(sV + buf * G::K_BYTES + G::koff(row, ch)) = rv[n];
             }
         }
     };
@@ -206,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     {
         const int P0 = kt_lo * KT;
         load_kv(kt_lo);
-        store_kv();
+        store_kv(0);
 #pragma unroll 1
         for (int q4 = 0; q4 < 3; q4++) {
             const int dbase = i0 - P0 - 64 + 64 * q4;
@@ -222,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 #pragma unroll
         for (int j = 0; j < 16; j++) { aw[e][j] = 0.f; ar[e][j] = 0.f; }
     bool have_ring = false;
+    int cur = 0;
     bf16_t* dgrow = p.dg ? p.dg + (((size_t)b * p.H + h) * T + (qok ? qi : 0)) * (size_t)M : nullptr;
 
 #pragma unroll 1
@@ -236,6 +276,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
         const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);
         if (active) {
             const int dlo = iw0 - P - 64;
+            const char* cK = sK + cur * G::K_BYTES;
+            const char* cV = sV + cur * G::K_BYTES;
             f32x16 s[2], dp[2];
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
@@ -243,17 +285,15 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 for (int j = 0; j < 16; j++) { s[kb][j] = 0.f; dp[kb][j] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + G::koff(32 * kb + r, 2 * ks + hh));
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                     __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sV + G::koff(32 * kb + r, 2 * ks + hh));
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(cV + G::koff(32 * kb + r, 2 * ks + hh));
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
                                                                      __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp[kb], 0, 0, 0);
                 }
             }
-            const int nb = have_ring ? 2 : 3;
-#pragma unroll 1
-            for (int gb = 0; gb < nb; gb++) {
+            auto gblock = [&](int gb, f16x4 (&dst)[4]) {
                 f32x16 g;
 #pragma unroll
                 for (int j = 0; j < 16; j++) g[j] = 0.f;
@@ -266,9 +306,27 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 }
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++) {
-                    const int d = dlo + 32 * gb + 8 * grp + 4 * hh;
-                    *reinterpret_cast<f32x4*>(myG + (d & 127)) = f32x4{g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    dst[grp] = __builtin_convertvector(v4, f16x4);
                 }
+            };
+            f16x4 b0[4], b1[4];
+            if (!have_ring) gblock(2, carry);
+            gblock(0, b0);
+            gblock(1, b1);
+            // move the carried dG block: columns [0,32) of the previous tile are columns [64,96) of this one
+            {
+                const u32x4 m0 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh);
+                const u32x4 m1 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh + 8);
+                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh) = m0;
+                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh + 8) = m1;
+            }
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
+                *reinterpret_cast<f16x4*>(gW + 32 + 8 * grp) = b1[grp];
+                *reinterpret_cast<f16x4*>(gW + 64 + 8 * grp) = carry[grp];
+                carry[grp] = b0[grp];
             }
             have_ring = true;
             // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127.  Scalar branch on the
@@ -278,21 +336,23 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
+                    uint32_t bdu[16], dsu[16];
+                    skew_read16(gRb - 64 * kb, bdu);
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        const int jj = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                        const int d = qi - P - jj;
-                        const float bd = myG[d & 127];
+                        const float bd = (float)__builtin_bit_cast(_Float16, (unsigned short)bdu[j]);
                         const float val = (s[kb][j] + bd) * p.scale_log2e - lse2;
                         float pv = __builtin_amdgcn_exp2f(val);
                         if (MASKED) {
+                            const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
                             const bool valid = (d >= 0) && (d <= M - 1) && qok;
                             pv = valid ? pv : 0.f;
                         }
                         const float ds = p.scale * pv * (dp[kb][j] - dlt);
                         s[kb][j] = ds;
-                        myDG[d & 127] = f2bf(ds);
+                        dsu[j] = (uint32_t)f2bf(ds);
                     }
+                    skew_write16(dgWb - 64 * kb, dsu);
                 }
             };
             if (full) grads(std::false_type{}); else grads(std::true_type{});
@@ -311,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                         const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
                         bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
                         if (ecol < DH) {
-                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key, ecol)));
-                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sK + G::eoff(key + 8, ecol)));
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(cK + G::eoff(key, ecol)));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(cK + G::eoff(key + 8, ecol)));
                             a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         }
                         aw[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
@@ -326,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 #pragma unroll
                 for (int ks2 = 0; ks2 < 2; ks2++) {
                     const int d8 = dlo + 32 * blk + 16 * ks2 + 8 * hh;  // 8 consecutive distances (natural k order)
-                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(myDG + (d8 & 127));
+                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(myDG + 32 * blk + 16 * ks2 + 8 * hh);
                     if (dgrow && qok && d8 >= 0 && d8 + 7 <= M - 1)
                         *reinterpret_cast<bf16x8*>(dgrow + d8) = bfrag;
 #pragma unroll
@@ -345,12 +405,12 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 }
             }
         }
-        __syncthreads();
         if (more) {
-            store_kv();
+            store_kv(cur ^ 1);
             store_r(i0 - (P + KT) - 64);
         }
         __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: dq = dQw + dQr (lane = query); bias gradients = sums over the wave's queries
