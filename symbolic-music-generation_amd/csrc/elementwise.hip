@@ -224,14 +224,38 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
 }
 
 // out[n] += sum_m X[m][n]   (bias gradients: CoreNet.0/3 bias, crit bias).  bf16 in, fp32 atomic out.
+// block = 32 column-threads (8 columns each, 16-byte loads) x 8 row-lanes; rows_per_block rows per block.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out, int M, int N, int ld, int rows_per_block) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][256];
+    const int ct = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + ct * 8;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    if (col >= N) return;
-    float s = 0.f;
-    for (int r = r0; r < r1; r++) s += bf2f(X[(size_t)r * ld + col]);
-    atomicAdd(out + col, s);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    if (col + 7 < N && (ld & 7) == 0) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)v[j]);
+        }
+    } else if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 8)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (col + j < N) acc[j] += bf2f(X[(size_t)r * ld + col + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[rl][ct * 8 + j] = acc[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += red[k][c];
+        atomicAdd(out + blockIdx.x * 256 + c, s);
+    }
 }
 
 // new_mem[b] = cat(mem[b], hid[b])[-M:]   (TransfoXLModel._update_mems; batch-major (B, len, d))
@@ -370,7 +394,7 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
 
 extern "C" int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream) {
     MXL_CHECK_ARG(X && out && M > 0 && N > 0 && ld >= N);
-    const int rpb = 256;
+    const int rpb = 512;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)X, out, M, N, ld, rpb);
     MXL_LAUNCH_CHECK();

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
 struct GemmP {
@@ -42,11 +42,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
 __device__ __forceinline__ int swzT(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-template <bool T>
-__device__ __forceinline__ void g2r(const bf16_t* __restrict__ X, int ld, int R, int kend, int r0, int k0, u32x4 (&v)[4]) {
+template <bool T, int R_>
+__device__ __forceinline__ void g2r(const bf16_t* __restrict__ X, int ld, int R, int kend, int r0, int k0, u32x4 (&v)[R_ / 32]) {
     const int t = threadIdx.x;
+    constexpr int RC = R_ / 8;   // 16-byte chunks per k-row of a transposed tile
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < R_ / 32; i++) {
         const int c = t + i * 256;
         u32x4 z = {0u, 0u, 0u, 0u};
         if (!T) {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void g2r(const bf16_t* __restrict__ X, int ld, int R,
             const bool ok = (gr < R) && (gk < kend);
             v[i] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)gr * ld + gk) : z;
         } else {
-            const int kr = c >> 4, rc = c & 15;
+            const int kr = c / RC, rc = c % RC;
             const int gk = k0 + kr, gr = r0 + rc * 8;
             const bool ok = (gk < kend) && (gr < R);
             v[i] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)gk * ld + gr) : z;
@@ -63,26 +64,27 @@ __device__ __forceinline__ void g2r(const bf16_t* __restrict__ X, int ld, int R,
     }
 }
 
-template <bool T>
-__device__ __forceinline__ void r2s(char* base, const u32x4 (&v)[4]) {
+template <bool T, int R_>
+__device__ __forceinline__ void r2s(char* base, const u32x4 (&v)[R_ / 32]) {
     const int t = threadIdx.x;
+    constexpr int RC = R_ / 8;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < R_ / 32; i++) {
         const int c = t + i * 256;
         int off;
         if (!T) {
             const int row = c >> 3, kc = c & 7;
             off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
         } else {
-            const int kr = c >> 4, rc = c & 15;
-            off = kr * 256 + (((rc >> 1) ^ swzT(kr)) << 5) + ((rc & 1) << 4);
+            const int kr = c / RC, rc = c % RC;
+            off = kr * (R_ * 2) + (((rc >> 1) ^ (swzT(kr) & (R_ / 16 - 1))) << 5) + ((rc & 1) << 4);
         }
         *reinterpret_cast<u32x4*>(base + off) = v[i];
     }
 }
 
 // fragment for 16 rows [rb, rb+16) of the tile, k-step ks (32 k's): lane l holds row rb+(l&15), k = 8*(l>>4)+j
-template <bool T>
+template <bool T, int R_>
 __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
     const int l = threadIdx.x & 63;
     const int g = l >> 4, li = l & 15;
@@ -94,9 +96,9 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
         const int q = li >> 2, pp = li & 3;
         const int krow = ks * 32 + 8 * g + q;
         const int col = rb + 4 * pp;
-        const int off = krow * 256 + (((col >> 4) ^ swzT(krow)) << 5) + ((col & 15) << 1);
+        const int off = krow * (R_ * 2) + (((col >> 4) ^ (swzT(krow) & (R_ / 16 - 1))) << 5) + ((col & 15) << 1);
         const lds_bf16x4* p0 = (const lds_bf16x4*)(base + off);
-        const lds_bf16x4* p1 = (const lds_bf16x4*)(base + off + 4 * 256);
+        const lds_bf16x4* p1 = (const lds_bf16x4*)(base + off + 4 * (R_ * 2));
         bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p0);
         bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p1);
         bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -104,8 +106,12 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
     }
 }
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, int BN_>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
+    constexpr int BN = BN_;              // 128, or 64 for skinny-N problems (the per-head dRd contraction: N = d_head)
+    constexpr int NF = BN / 32;          // 16-wide n-fragments per wave
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int STAGE = TILE_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware remap: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles so
     // neighbouring tiles (same A row panel) hit the same L2.  Bijective for any grid size.
@@ -132,52 +138,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     const int wid = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wr = wid >> 1, wc = wid & 1;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NF];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[4], rb[4];
-    g2r<AT>(p.A, p.lda, p.M, kend, m0, kbeg, ra);
-    g2r<BT>(p.B, p.ldb, p.N, kend, n0, kbeg, rb);
-    r2s<AT>(smem, ra);
-    r2s<BT>(smem + TILE_BYTES, rb);
+    u32x4 ra[4], rb[BN / 32];
+    g2r<AT, 128>(p.A, p.lda, p.M, kend, m0, kbeg, ra);
+    g2r<BT, BN>(p.B, p.ldb, p.N, kend, n0, kbeg, rb);
+    r2s<AT, 128>(smem, ra);
+    r2s<BT, BN>(smem + TILE_BYTES, rb);
     __syncthreads();
 
     int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
         const bool more = (kt + 1 < nk);
         if (more) {
-            g2r<AT>(p.A, p.lda, p.M, kend, m0, kbeg + (kt + 1) * BK, ra);
-            g2r<BT>(p.B, p.ldb, p.N, kend, n0, kbeg + (kt + 1) * BK, rb);
+            g2r<AT, 128>(p.A, p.lda, p.M, kend, m0, kbeg + (kt + 1) * BK, ra);
+            g2r<BT, BN>(p.B, p.ldb, p.N, kend, n0, kbeg + (kt + 1) * BK, rb);
         }
-        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sa = smem + cur * STAGE;
         const char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[4], fb[NF];
 #pragma unroll
-            for (int i = 0; i < 4; i++) fa[i] = ldfrag<AT>(sa, wr * 64 + i * 16, ks);
+            for (int i = 0; i < 4; i++) fa[i] = ldfrag<AT, 128>(sa, wr * 64 + i * 16, ks);
 #pragma unroll
-            for (int j = 0; j < 4; j++) fb[j] = ldfrag<BT>(sb, wc * 64 + j * 16, ks);
+            for (int j = 0; j < NF; j++) fb[j] = ldfrag<BT, BN>(sb, wc * (BN / 2) + j * 16, ks);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int j = 0; j < NF; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(mfma_bf16x8, fb[j]), __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         }
         if (more) {
-            char* da = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            r2s<AT>(da, ra);
-            r2s<BT>(da + TILE_BYTES, rb);
+            char* da = smem + (cur ^ 1) * STAGE;
+            r2s<AT, 128>(da, ra);
+            r2s<BT, BN>(da + TILE_BYTES, rb);
         }
         __syncthreads();
         cur ^= 1;
     }
 
-    // epilogue.  acc[i][j][r]: m = m0 + wr*64 + i*16 + (l&15), n = n0 + wc*64 + j*16 + (l>>4)*4 + r
+    // epilogue.  acc[i][j][r]: m = m0 + wr*64 + i*16 + (l&15), n = n0 + wc*(BN/2) + j*16 + (l>>4)*4 + r
     const int flags = p.flags;
     const int mrow_l = l & 15, nq = (l >> 4) * 4;
 #pragma unroll
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
         const int m = m0 + wr * 64 + i * 16 + mrow_l;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = n0 + wc * 64 + j * 16 + nq;
+        for (int j = 0; j < NF; j++) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + nq;
             if (n >= p.N) continue;
             float v[4];
 #pragma unroll
@@ -281,6 +287,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
+    const int BN = (N <= 64) ? 64 : 128;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     MXL_CHECK_ARG(batch >= 1 && bdiv >= 1);
     if (batch > 1) {
@@ -289,12 +296,17 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     }
     p.bdiv = bdiv; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2;
     dim3 grid(p.tiles_m * p.tiles_n, batch, ksplits), block(256);
-    const size_t shm = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, shm, s, p);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, shm, s, p);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, shm, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, shm, s, p);
+#define MXL_GEMM_LAUNCH(AT_, BT_)                                                                                          \
+    do {                                                                                                                   \
+        if (BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, 64>), grid, block, 2 * (TILE_BYTES + 64 * BK * 2), s, p); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, 128>), grid, block, 4 * TILE_BYTES, s, p);                      \
+    } while (0)
+    if (!transA && !transB) MXL_GEMM_LAUNCH(false, false);
+    else if (!transA && transB) MXL_GEMM_LAUNCH(false, true);
+    else if (transA && !transB) MXL_GEMM_LAUNCH(true, false);
+    else MXL_GEMM_LAUNCH(true, true);
+#undef MXL_GEMM_LAUNCH
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -17,7 +17,7 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 192), (257, 1190, 520), (64, 72, 1032)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 192), (257, 1190, 520), (64, 72, 1032), (300, 64, 256), (136, 40, 192)])
 def test_gemm_layouts(dev, ta, tb, M, N, K):
     from symbolic_music_generation_amd import ops
     torch.manual_seed(M + N + K)
