@@ -54,9 +54,10 @@ __device__ __forceinline__ uint32_t mxl_hash32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
-    // thresh = p * 2^32 ; keep iff rnd >= thresh
-    uint32_t h = mxl_hash32((uint32_t)idx ^ mxl_hash32((uint32_t)(idx >> 32) + site * 0x9E3779B9U + (uint32_t)seed));
-    h = mxl_hash32(h + (uint32_t)(seed >> 32));
+    // thresh = p * 2^32 ; keep iff rnd >= thresh.  `mix` depends only on kernel arguments (hoisted out of every loop);
+    // per element: two multiplies for the index spread + one lowbias32 round.
+    const uint32_t mix = mxl_hash32((uint32_t)seed ^ (site * 0x9E3779B9U)) + (uint32_t)(seed >> 32);
+    const uint32_t h = mxl_hash32(((uint32_t)idx * 0x9E3779B1U) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77U) ^ mix);
     return h >= thresh;
 }
 static inline uint32_t dropout_thresh(float p) {

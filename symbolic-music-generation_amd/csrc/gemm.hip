@@ -199,8 +199,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
             for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] * p.alpha;
             const bool full = (n + 3 < p.N);
             if (flags & MXL_GEMM_BIAS) {
+                if (full) {
+                    const float b0 = p.bias[n], b1 = p.bias[n + 1], b2 = p.bias[n + 2], b3 = p.bias[n + 3];
+                    v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+                }
             }
             if (flags & MXL_GEMM_RELU) {
 #pragma unroll
@@ -214,17 +219,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
                 }
             }
             if (flags & MXL_GEMM_RELU_BWD) {
+                if (full && ((p.ldaux & 3) == 0)) {
+                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (n + r < p.N) {
-                        const float a = bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
-                        v[r] = a > 0.f ? v[r] : 0.f;
-                    }
+                    for (int r = 0; r < 4; r++) v[r] = bf2f((bf16_t)a4[r]) > 0.f ? v[r] : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) {
+                            const float a = bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                            v[r] = a > 0.f ? v[r] : 0.f;
+                        }
+                }
             }
             if (flags & MXL_GEMM_ADD_AUX) {
+                if (full && ((p.ldaux & 3) == 0)) {
+                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                    for (int r = 0; r < 4; r++) v[r] += bf2f((bf16_t)a4[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                }
             }
             if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
                 float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
