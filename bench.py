@@ -50,7 +50,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c3', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (sequences)')
-    ap.add_argument('--mode', default='train', choices=['train', 'decode'],
+    ap.add_argument('--mode', default='train', choices=['train', 'decode', 'reformer'],
                     help='train = headline metric; decode = AR decode tok/s (SURVEY C5), single GPU replicas')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -76,6 +76,8 @@ def main():
 
     if args.mode == 'decode':
         return decode_bench(args, dev, rank, world)
+    if args.mode == 'reformer':
+        return reformer_bench(args, dev, rank, world, dist)
     wl = WORKLOADS[args.workload]
     B = args.batch or wl['B']
     T, M = wl['T'], wl['M']
@@ -171,6 +173,58 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def reformer_bench(args, dev, rank, world, dist):
+    """Reformer 6L (3 local + 3 LSH) d=512 H=8 dh=64 F=2048, T=8192 (axial 64x128), num_hashes=1, per-GPU B=8,
+    dropout on (0.05), auto num_buckets = [16,16].  Step = fwd + bwd + all-reduce + clip + AdamW."""
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    from symbolic_music_generation_amd.dist import GradSync
+    B, T = args.batch or 8, 8192
+    cfg = MyReformerConfig('small', vocab_size=V, max_position_embeddings=T, axial_pos_shape=(64, 128), num_hashes=1)
+    model = MyReformerModelWithLMHead(cfg, device=dev, seed=77).train()
+    eng = model.engine
+    sync = GradSync(eng)
+    gen = torch.Generator(device='cpu').manual_seed(77 + rank)
+    ids = torch.randint(4, V, (B, T), generator=gen).to(dev)
+
+    def step():
+        eng.zero_grad()
+        model(input_ids=ids, labels=ids)
+        eng.backward(layer_done=sync.layer_done)
+        sync.finish()
+        eng.optimizer_step(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / world)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        d = cfg.hidden_size
+        # SURVEY 8(d): local layer 24d^2 + 2*2*(2*64)*d, LSH layer 22d^2 + n_h*(d*rot + 512 d), head 2*2d*V; train = 3x
+        rot = 32
+        f_fwd = 3 * (24 * d * d + 512 * d) + 3 * (22 * d * d + (d * rot + 512 * d)) + 2 * 2 * d * V
+        tokens = B * T * world * args.steps
+        print(json.dumps({'metric': 'train tokens/sec (Reformer 6L/512d seq8192 bf16), whole job', 'value': tokens / dt,
+                          'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'bf16', 'data': 'synthetic',
+                          'config': {'workload': 'SURVEY C4: Reformer small (3 local + 3 LSH) d=512 T=8192 axial 64x128 n_h=1',
+                                     'per_gpu_batch': B, 'train_flops_per_token': 3 * f_fwd,
+                                     'whole_step_mfma_frac': 3 * f_fwd * tokens / dt / world / (MFMA_BF16_PEAK_TFLOPS * 1e12)}}),
+              flush=True)
 
 
 def decode_bench(args, dev, rank, world):
