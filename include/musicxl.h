@@ -51,6 +51,11 @@ int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
                           long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2,
                           void* stream);
 
+/* skinny-M (M <= 64) weight-streaming form for the decode step: C[M,N] = A[M,K] . W[N,K]^T (+bias)(relu);
+ * flags: MXL_GEMM_OUT_F32 | MXL_GEMM_BIAS | MXL_GEMM_RELU.  Deterministic (fixed-order in-workgroup split-K). */
+int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc, int flags,
+                         const float* bias, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Relative-position banded attention (K4).  Replaces RelPartialLearnableMultiHeadAttn.forward between qkv_net and
  * o_net in upstream modeling_transfo_xl.py (AC/BD einsums, _rel_shift, same_length mask, softmax, P.V), as called

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
 
     // pass 1: scores
     float mx = -1e30f;
+#pragma unroll 4
     for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
         const int s = s0 + ksub;
         float acc = 0.f;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll 4
     for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
         const int s = s0 + ksub;
         if (s < M) {

@@ -1,0 +1,83 @@
+// Skinny-M GEMM for the decode step: C[M<=64, N] = A[M,K] . W[N,K]^T (+bias)(relu), bf16 in, fp32 accumulate.
+// At M = 64 a GEMM is weight streaming: every W element is read once and the activations (64 x K, L2-resident) are
+// re-read by everyone.  So: no LDS staging at all -- fragments go straight from global memory to the MFMA operands
+// (16 bytes per lane per fragment) -- and the parallelism comes from N and K instead of M:
+//   workgroup = 16 output columns x all 64 rows, 8 waves, wave w owns K-slice w (in-workgroup split-K, LDS reduction).
+// N = 768 -> 48 workgroups x 8 waves; N = 2304 -> 144 x 8: enough loads in flight to stream the weights.
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+struct SkP {
+    const bf16_t* A; const bf16_t* W; void* C; const float* bias;
+    int M, N, K, lda, ldw, ldc, flags;
+};
+
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
+    __shared__ float red[8][64 * 16];   // [wave][m][n] partial sums, reduced in fixed order (deterministic)
+    const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63;
+    const int n0 = blockIdx.x * 16;
+    const int li = l & 15, kq = 8 * (l >> 4);
+    // K slice of this wave (multiples of 32)
+    const int ksteps = (p.K + 31) / 32;
+    const int per = (ksteps + 7) / 8;
+    const int ks0 = wid * per, ks1 = min(ksteps, ks0 + per);
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + li;
+    const bf16_t* wrow = p.W + (size_t)(n < p.N ? n : 0) * p.ldw;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int ks = ks0; ks < ks1; ks++) {
+        const int k = ks * 32 + kq;
+        const bool kok = k < p.K;
+        const bf16x8 fb = (kok && n < p.N) ? *reinterpret_cast<const bf16x8*>(wrow + k) : z;
+        bf16x8 fa[4];
+#pragma unroll
+        for (int mf = 0; mf < 4; mf++) {
+            const int m = mf * 16 + li;
+            fa[mf] = (kok && m < p.M) ? *reinterpret_cast<const bf16x8*>(p.A + (size_t)m * p.lda + k) : z;
+        }
+#pragma unroll
+        for (int mf = 0; mf < 4; mf++)
+            acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb),
+                                                              __builtin_bit_cast(mfma_bf16x8, fa[mf]), acc[mf], 0, 0, 0);
+    }
+    // acc[mf][r]: m = mf*16 + (l&15), n = n0 + (l>>4)*4 + r
+#pragma unroll
+    for (int mf = 0; mf < 4; mf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wid][(mf * 16 + li) * 16 + (l >> 4) * 4 + r] = acc[mf][r];
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 512) {
+        const int m = i >> 4, nn = n0 + (i & 15);
+        if (m < p.M && nn < p.N) {
+            float v = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
+            if (p.flags & MXL_GEMM_BIAS) v += p.bias[nn];
+            if (p.flags & MXL_GEMM_RELU) v = fmaxf(v, 0.f);
+            if (p.flags & MXL_GEMM_OUT_F32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nn] = v;
+            else reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                    int flags, const float* bias, void* stream) {
+    MXL_CHECK_ARG(A && W && C && M > 0 && M <= 64 && N > 0 && K > 0);
+    MXL_CHECK_ARG((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ldc >= N);
+    MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    MXL_CHECK_ARG(!(flags & ~(MXL_GEMM_OUT_F32 | MXL_GEMM_BIAS | MXL_GEMM_RELU)));
+    if (flags & MXL_GEMM_BIAS) MXL_CHECK_ARG(bias != nullptr);
+    SkP p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.flags = flags;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(512), 0, (hipStream_t)stream, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

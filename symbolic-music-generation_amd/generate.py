@@ -92,27 +92,28 @@ class XLDecoder:
         e, c = self.eng, self.eng.cfg
         B, d, H, dh, M, Fi, L = self.B, c.d_model, c.n_head, c.d_head, c.mem_len, c.d_inner, c.n_layer
         E = e.w16('transformer.word_emb.emb_layers.0.weight')
+        G = ops.gemm_skinny if B <= 64 else ops.gemm     # weight-streaming form for decode batches
         ops.decode_embed(self.ids, self.t_dev, E, self.h[0], math.sqrt(d))
         for l in range(L):
             h_in, h_out = self.h[l & 1], self.h[(l + 1) & 1]
-            ops.gemm(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
+            G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
             ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev)
             ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
                                e._lw(l, 'dec_attn.r_r_bias', e.P), self.av, self.t_dev, H, dh)
-            ops.gemm(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
+            G(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
             ops.ln_residual_fwd(self.tmp, h_in, e._lw(l, 'dec_attn.layer_norm.weight', e.P),
                                 e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)
-            ops.gemm(self.h1, e._lw(l, 'pos_ff.CoreNet.0.weight'), self.a, B, Fi, d, flags=ops.GEMM_BIAS | ops.GEMM_RELU,
-                     bias=e._lw(l, 'pos_ff.CoreNet.0.bias', e.P))
-            ops.gemm(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.tmp, B, d, Fi, flags=ops.GEMM_BIAS,
-                     bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
+            G(self.h1, e._lw(l, 'pos_ff.CoreNet.0.weight'), self.a, B, Fi, d, flags=ops.GEMM_BIAS | ops.GEMM_RELU,
+              bias=e._lw(l, 'pos_ff.CoreNet.0.bias', e.P))
+            G(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.tmp, B, d, Fi, flags=ops.GEMM_BIAS,
+              bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
             ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
                                 e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
         hid = self.h[L & 1]
         nrow, nrow_p = e.layout.n_head_rows, e.layout.head_rows_padded
         head_w = e.W[:nrow_p * d].view(nrow_p, d)
         boff = e.layout.entries['crit.out_layers.0.bias'][0]
-        ops.gemm(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
+        G(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
         ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
         ops.decode_advance(self.t_dev, self.rng)

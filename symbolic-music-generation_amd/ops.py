@@ -57,6 +57,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: i
     return c
 
 
+def gemm_skinny(a, w, c, M, N, K, *, flags=0, bias=None, lda=None, ldw=None, ldc=None):
+    """C[M<=64, N] = A W^T (+bias)(relu): weight-streaming form used by the decode step"""
+    check(lib().mxl_gemm_skinny_bf16(_p(a), _p(w), _p(c), M, N, K, lda if lda is not None else a.stride(-2),
+                                     ldw if ldw is not None else w.stride(-2), ldc if ldc is not None else c.stride(-2),
+                                     flags, _p(bias), _stream()), 'mxl_gemm_skinny_bf16')
+    return c
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, relu=False, out=None,
            out_f32=False, drop_p=0.0, seed=0, site=0) -> torch.Tensor:
     """y = x @ w.T (+bias)(relu)(dropout); x (N, K) bf16, w (O, K) bf16."""

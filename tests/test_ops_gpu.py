@@ -342,3 +342,20 @@ def test_relattn_bwd(dev, B, T, H, dh, M, Kc, name):
                          ('d_rrb', d_rrb.cpu(), rrbr.grad)]:
         errs[nm] = rel_err(got, ref)
     assert all(e < 2e-2 for e in errs.values()), f'{name}: {errs}'
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 2304, 768), (64, 768, 3072), (3, 1190, 768), (17, 40, 136)])
+def test_gemm_skinny(dev, M, N, K):
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(M + N)
+    x, w, b = bf(torch.randn(M, K)), bf(torch.randn(N, K) * 0.1), torch.randn(N)
+    ref = torch.relu(x.float() @ w.float().t() + b)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm_skinny(x.to(dev), w.to(dev), out, M, N, K, flags=ops.GEMM_BIAS | ops.GEMM_RELU, bias=b.to(dev))
+    assert rel_err(out.cpu(), ref) < 6e-3
+    out32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+    ops.gemm_skinny(x.to(dev), w.to(dev), out32, M, N, K, flags=ops.GEMM_OUT_F32)
+    assert rel_err(out32.cpu(), x.float() @ w.float().t()) < 1e-5
+    out32b = torch.empty_like(out32)
+    ops.gemm_skinny(x.to(dev), w.to(dev), out32b, M, N, K, flags=ops.GEMM_OUT_F32)
+    assert torch.equal(out32, out32b)     # deterministic reduction order
