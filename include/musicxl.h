@@ -156,18 +156,19 @@ int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
  * cat(mems, h) -> qkv_net recomputation.  All step state is on the device (t_dev = position of the token being fed,
  * rng_ctr), so a step is capture-safe and replays as a hipGraph.
  *   ids     : (B, ld_ids) int64 token buffer; step reads ids[b][t], sampler writes ids[b][t+1]
- *   k/vcache: (B, M, d) bf16 rings of projected K/V rows, slot = position mod M, zero-initialised (= upstream zero mems)
+ *   k/vcache: head-major (B, H, M, dh) bf16 rings of projected K/V rows, slot = position mod M, zero-initialised
+ *             (= upstream zero mems)
  * ---------------------------------------------------------------------------------------------------------- */
 int mxl_decode_embed(const void* ids, int ld_ids, const int* t_dev, const void* E, void* out, int B, int d, int V,
                      float scale, void* stream);
 /* cache[b][t mod M] <- k, v of the (B, 3d) qkv rows of the current token */
-int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, void* stream);
+int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, int dh, void* stream);
 /* after the prompt forward: cache slots <- K/V rows of the last min(T, M) positions of a (B, T, 3d) qkv buffer */
-int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, void* stream);
-/* single-query relative attention over the ring: distances 0..M-1, rd (M, H*dh) bf16; out (B, H*dh) bf16 */
-int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const void* rd, const float* r_w_bias,
-                       const float* r_r_bias, void* out, const int* t_dev, int B, int H, int dh, int M, float scale,
-                       void* stream);
+int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, int dh, void* stream);
+/* single-query relative attention over the ring, distances 0..M-1.  bd (B, H, M) f32 = (q + r_r_bias) . rd[dist], the
+ * positional term for the whole batch (one mxl_gemm_bf16_batched per layer over heads); out (B, H*dh) bf16 */
+int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
+                       void* out, const int* t_dev, int B, int H, int dh, int M, float scale, void* stream);
 /* next token from log-probs (B, ldl): greedy argmax (do_sample=0) or temperature -> top-k -> top-p -> renormalise ->
  * multinomial (do_sample=1), as HF's logits warpers with renormalize_logits=True (musicnlp/trainer/eval.py:277-326).
  * V <= 2048.  out_probs (B, V) f32 optional: the renormalised distribution actually sampled from (test hook). */

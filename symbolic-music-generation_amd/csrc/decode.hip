@@ -29,20 +29,24 @@ __global__ void decode_embed_kernel(const long long* ids, int ld_ids, const int*
 }
 
 // cache[b][t mod M] = (k, v) of the current token (rows of the (B, 3d) qkv buffer)
-__global__ void kv_append_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, const int* t_dev, int B, int M, int d) {
+// ring layout is head-major (B, H, M, dh): the attention kernel of one (b, h) then streams one contiguous 2*M*dh-byte
+// region instead of 128-byte pieces at a d-element stride (DRAM page locality)
+__global__ void kv_append_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, const int* t_dev, int B, int M, int d, int dh) {
     const int chunks = d >> 3;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= B * chunks) return;
     const int b = gid / chunks, c = gid % chunks;
     const int slot = (*t_dev) % M;
+    const int h = (c * 8) / dh, e = (c * 8) % dh, H = d / dh;
     const u32x4 k = *reinterpret_cast<const u32x4*>(qkv + (size_t)b * 3 * d + d + c * 8);
     const u32x4 v = *reinterpret_cast<const u32x4*>(qkv + (size_t)b * 3 * d + 2 * d + c * 8);
-    *reinterpret_cast<u32x4*>(kc + ((size_t)b * M + slot) * d + c * 8) = k;
-    *reinterpret_cast<u32x4*>(vc + ((size_t)b * M + slot) * d + c * 8) = v;
+    const size_t o = (((size_t)b * H + h) * M + slot) * dh + e;
+    *reinterpret_cast<u32x4*>(kc + o) = k;
+    *reinterpret_cast<u32x4*>(vc + o) = v;
 }
 
 // bulk fill after the prompt forward: cache slots (p mod M) <- K/V rows of positions p in [max(0, T-M), T)
-__global__ void kv_fill_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, int B, int T, int M, int d) {
+__global__ void kv_fill_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, int B, int T, int M, int d, int dh) {
     const int chunks = d >> 3;
     const int keep = min(T, M);
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,14 +57,16 @@ __global__ void kv_fill_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, int B,
     const int pos = T - keep + r;
     const int slot = pos % M;
     const bf16_t* row = qkv + ((size_t)b * T + pos) * 3 * d;
-    *reinterpret_cast<u32x4*>(kc + ((size_t)b * M + slot) * d + c * 8) = *reinterpret_cast<const u32x4*>(row + d + c * 8);
-    *reinterpret_cast<u32x4*>(vc + ((size_t)b * M + slot) * d + c * 8) = *reinterpret_cast<const u32x4*>(row + 2 * d + c * 8);
+    const int h = (c * 8) / dh, e = (c * 8) % dh, H = d / dh;
+    const size_t o = (((size_t)b * H + h) * M + slot) * dh + e;
+    *reinterpret_cast<u32x4*>(kc + o) = *reinterpret_cast<const u32x4*>(row + d + c * 8);
+    *reinterpret_cast<u32x4*>(vc + o) = *reinterpret_cast<const u32x4*>(row + 2 * d + c * 8);
 }
 
 // one workgroup per (head, batch row); dh = 8 * LPK, LPK lanes share one key row, 64/LPK keys per wave instruction
 template <int DH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* kc, const bf16_t* vc,
-                                                          const bf16_t* rd, const float* rwb, const float* rrb,
+                                                          const float* bd, const float* rwb,
                                                           bf16_t* out, const int* t_dev, int B, int H, int M, float scale) {
     constexpr int LPK = DH / 8;          // lanes per key row
     constexpr int KPW = 64 / LPK;        // keys per wave per iteration
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     const int t = *t_dev;
     const int tm = t % M;
 
-    float qw[8], qr[8];
+    float qw[8];
     {
         const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qkv + (size_t)b * 3 * d + h * DH + c8 * 8);
 #pragma unroll
@@ -83,33 +89,43 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
             const float q = bf2f((bf16_t)qv[j]);
             // mirror the training kernels: (q + bias) is rounded to bf16 before the contraction
             qw[j] = bf2f(f2bf(q + rwb[h * DH + c8 * 8 + j]));
-            qr[j] = bf2f(f2bf(q + rrb[h * DH + c8 * 8 + j]));
         }
     }
-    const bf16_t* kb = kc + (size_t)b * M * d + h * DH + c8 * 8;
-    const bf16_t* vb = vc + (size_t)b * M * d + h * DH + c8 * 8;
-    const bf16_t* rb = rd + h * DH + c8 * 8;
+    // positional term BD[b,h,dist] = (q + r_r_bias) . Rd[dist], precomputed for the whole batch by one batched GEMM per layer
+    // (reads the Rd table once per head instead of once per (sequence, head))
+    const float* bdrow = bd + ((size_t)b * H + h) * M;
+    const bf16_t* kb = kc + ((size_t)b * H + h) * M * DH + c8 * 8;     // head-major ring: rows are DH apart
+    const bf16_t* vb = vc + ((size_t)b * H + h) * M * DH + c8 * 8;
 
-    // pass 1: scores
+    // pass 1: scores.  Explicit batches of U key groups: all U loads are issued before any is consumed, so each wave keeps
+    // U KiB in flight (a plain unroll pragma left one load per iteration on the critical path: ~HBM latency per 8 keys)
+    constexpr int U = 8;
     float mx = -1e30f;
-#pragma unroll 4
-    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
-        const int s = s0 + ksub;
-        float acc = 0.f;
-        if (s < M) {
+    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW * U) {
+        bf16x8 kvv[U];
+        float bdv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u * 4 * KPW + ksub;
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            kvv[u] = (s < M) ? *reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH) : z;
             int dist = tm - s;
             if (dist < 0) dist += M;
-            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (size_t)s * d);
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(rb + (size_t)dist * d);
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc += qw[j] * bf2f((bf16_t)kv[j]) + qr[j] * bf2f((bf16_t)rv[j]);
+            bdv[u] = (s < M && c8 == 0) ? bdrow[dist] : 0.f;
         }
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
-        acc *= scale;
-        if (s < M) {
-            if (c8 == 0) sc[s] = acc;
-            mx = fmaxf(mx, acc);
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u * 4 * KPW + ksub;
+            float acc = bdv[u];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += qw[j] * bf2f((bf16_t)kvv[u][j]);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            acc *= scale;
+            if (s < M) {
+                if (c8 == 0) sc[s] = acc;
+                mx = fmaxf(mx, acc);
+            }
         }
     }
     mx = wave_max(mx);
@@ -127,18 +143,24 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     __syncthreads();
     const float inv = 1.f / (wred[4] + wred[5] + wred[6] + wred[7]);
 
-    // pass 2: o = sum_s p_s v_s   (P rounded to bf16 like the training kernel's MFMA operand)
+    // pass 2: o = sum_s p_s v_s   (P rounded to bf16 like the training kernel's MFMA operand); same batched loads
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = 0.f;
-#pragma unroll 4
-    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW) {
-        const int s = s0 + ksub;
-        if (s < M) {
-            const float pv = bf2f(f2bf(sc[s]));
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (size_t)s * d);
+    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW * U) {
+        bf16x8 vvv[U];
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vv[j]);
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u * 4 * KPW + ksub;
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            vvv[u] = (s < M) ? *reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH) : z;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u * 4 * KPW + ksub;
+            const float pv = (s < M) ? bf2f(f2bf(sc[s])) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vvv[u][j]);
         }
     }
 #pragma unroll
@@ -257,34 +279,35 @@ extern "C" int mxl_decode_embed(const void* ids, int ld_ids, const int* t_dev, c
     return MXL_OK;
 }
 
-extern "C" int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, void* stream) {
-    MXL_CHECK_ARG(qkv && kcache && vcache && t_dev && B > 0 && M > 0 && (d % 8) == 0);
+extern "C" int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, int dh,
+                             void* stream) {
+    MXL_CHECK_ARG(qkv && kcache && vcache && t_dev && B > 0 && M > 0 && (d % 8) == 0 && dh > 0 && (dh % 8) == 0 && (d % dh) == 0);
     const int n = B * (d / 8);
     hipLaunchKernelGGL(kv_append_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)kcache, (bf16_t*)vcache, t_dev, B, M, d);
+                       (bf16_t*)kcache, (bf16_t*)vcache, t_dev, B, M, d, dh);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
 
-extern "C" int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, void* stream) {
-    MXL_CHECK_ARG(qkv && kcache && vcache && B > 0 && T > 0 && M > 0 && (d % 8) == 0);
+extern "C" int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, int dh, void* stream) {
+    MXL_CHECK_ARG(qkv && kcache && vcache && B > 0 && T > 0 && M > 0 && (d % 8) == 0 && dh > 0 && (dh % 8) == 0 && (d % dh) == 0);
     const long long n = (long long)B * (T < M ? T : M) * (d / 8);
     hipLaunchKernelGGL(kv_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, T, M, d);
+                       (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, T, M, d, dh);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
 
-extern "C" int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const void* rd,
-                                  const float* r_w_bias, const float* r_r_bias, void* out, const int* t_dev, int B, int H,
+extern "C" int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd,
+                                  const float* r_w_bias, void* out, const int* t_dev, int B, int H,
                                   int dh, int M, float scale, void* stream) {
-    MXL_CHECK_ARG(qkv && kcache && vcache && rd && r_w_bias && r_r_bias && out && t_dev && B > 0 && H > 0 && M > 0);
+    MXL_CHECK_ARG(qkv && kcache && vcache && bd && r_w_bias && out && t_dev && B > 0 && H > 0 && M > 0);
     const size_t shm = (size_t)M * 4 + 4 * 64 * 4;
     MXL_CHECK_ARG(shm <= 64 * 1024);
     dim3 grid(H, B);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(DH) hipLaunchKernelGGL((decode_attn_kernel<DH>), grid, dim3(256), shm, s, (const bf16_t*)qkv, (const bf16_t*)kcache, \
-                                      (const bf16_t*)vcache, (const bf16_t*)rd, r_w_bias, r_r_bias, (bf16_t*)out, t_dev, B, H, M, scale)
+                                      (const bf16_t*)vcache, bd, r_w_bias, (bf16_t*)out, t_dev, B, H, M, scale)
     switch (dh) {
         case 16: LAUNCH(16); break;
         case 32: LAUNCH(32); break;

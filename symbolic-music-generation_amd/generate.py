@@ -26,8 +26,9 @@ class XLDecoder:
         dev = engine.dev
         d, M, L, Fi = c.d_model, c.mem_len, c.n_layer, c.d_inner
         bf = dict(device=dev, dtype=torch.bfloat16)
-        self.kc = [torch.zeros(batch, M, d, **bf) for _ in range(L)]
-        self.vc = [torch.zeros(batch, M, d, **bf) for _ in range(L)]
+        H, dh = c.n_head, c.d_head
+        self.kc = [torch.zeros(batch, H, M, dh, **bf) for _ in range(L)]    # head-major rings
+        self.vc = [torch.zeros(batch, H, M, dh, **bf) for _ in range(L)]
         self.rd = None                                  # per-layer Rd tables (eval: no dropout on pos_emb)
         self.ids = torch.zeros(batch, max_total_len + 1, device=dev, dtype=torch.int64)
         self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -36,6 +37,8 @@ class XLDecoder:
         self.h = [torch.empty(batch, d, **bf) for _ in range(2)]
         self.qkv = torch.empty(batch, 3 * d, **bf)
         self.av = torch.empty(batch, d, **bf)
+        self.qr = torch.empty(batch, d, **bf)
+        self.bd = torch.empty(batch, H, M, device=dev, dtype=torch.float32)
         self.tmp = torch.empty(batch, d, **bf)
         self.h1 = torch.empty(batch, d, **bf)
         self.a = torch.empty(batch, Fi, **bf)
@@ -99,7 +102,7 @@ class XLDecoder:
             G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
             ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev)
             ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
-                               e._lw(l, 'dec_attn.r_r_bias', e.P), self.av, self.t_dev, H, dh)
+                               e._lw(l, 'dec_attn.r_r_bias', e.P), self.av, self.t_dev, H, dh, self.qr, self.bd)
             G(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
             ops.ln_residual_fwd(self.tmp, h_in, e._lw(l, 'dec_attn.layer_norm.weight', e.P),
                                 e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)

@@ -237,19 +237,25 @@ def decode_embed(ids, t_dev, E, out, scale):
 
 
 def kv_append(qkv, kc, vc, t_dev):
-    B, M, d = kc.shape
-    check(lib().mxl_kv_append(_p(qkv), _p(kc), _p(vc), _p(t_dev), B, M, d, _stream()), 'mxl_kv_append')
+    """kc / vc: head-major rings (B, H, M, dh)"""
+    B, H, M, dh = kc.shape
+    check(lib().mxl_kv_append(_p(qkv), _p(kc), _p(vc), _p(t_dev), B, M, H * dh, dh, _stream()), 'mxl_kv_append')
 
 
 def kv_fill(qkv, kc, vc, T):
-    B, M, d = kc.shape
-    check(lib().mxl_kv_fill(_p(qkv), _p(kc), _p(vc), B, T, M, d, _stream()), 'mxl_kv_fill')
+    B, H, M, dh = kc.shape
+    check(lib().mxl_kv_fill(_p(qkv), _p(kc), _p(vc), B, T, M, H * dh, dh, _stream()), 'mxl_kv_fill')
 
 
-def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, scale=None):
-    B, M, d = kc.shape
+def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf, scale=None):
+    """qr_buf (B, H*dh) bf16 and bd_buf (B, H, M) f32 are scratch: BD = (q + r_r_bias) . rd^T for the whole batch."""
+    B, _, M, _ = kc.shape
+    d = H * dh
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
-    check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(rd), _p(rwb), _p(rrb), _p(out), _p(t_dev), B, H, dh, M,
+    add_rowbias(qkv, 3 * d, 3 * d, rrb.reshape(-1), qr_buf, B, 1, d)
+    gemm_batched(qr_buf, rd, bd_buf, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=GEMM_OUT_F32, batch=H, bdiv=1,
+                 sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
+    check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(bd_buf), _p(rwb), _p(out), _p(t_dev), B, H, dh, M,
                                    float(scale), _stream()), 'mxl_relattn_decode')
 
 
