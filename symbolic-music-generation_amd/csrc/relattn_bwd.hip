@@ -242,9 +242,101 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
         }
     };
 
+    f32x16 aw[EB], ar[EB];  // dQw^T, dQr^T : [e][query]
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { aw[e][j] = 0.f; ar[e][j] = 0.f; }
+    bool have_ring = false;
+    int cur = 0;
+    bf16_t* dgrow = p.dg ? p.dg + (((size_t)b * p.H + h) * T + (qok ? qi : 0)) * (size_t)M : nullptr;
+    __syncthreads();   // dG buffer zeroed
+
+    // ---- phantom keys (see relattn_fwd.hip): for key positions below the first stored tile pz, k = v = 0, hence S = 0 and
+    // dP = 0: dSr = -scale * P * delta depends only on the distance.  Walk those DISTANCES d in [i - pz + 1, M - 1] block-wise:
+    // G^T (no skew) -> P -> dG^T straight from the accumulators -> dQr MFMA + dG store.  No K/V, no S/dP/dQw, no LDS rings.
+    // The one block that straddles real and phantom distances (d in [iw0-pz, iw0-pz+31]) is deposited into the un-skew buffer
+    // (block-0 columns) so that the first real tile completes and emits it.
+    const int pz = floordiv(p0, KT) * KT;
+    int kt_start = kt_lo;
+    if (kt_lo * KT < pz) {
+        kt_start = pz / KT;
+        const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+        load_r(i0 - pz);
+#pragma unroll 1
+        for (int db = i0 - pz; db <= M - 1; db += 64) {
+            store_r(db);
+            __syncthreads();
+            if (db + 64 <= M - 1) load_r(db + 64);
+            if (iw0 < T) {
+#pragma unroll 1
+                for (int gb = 0; gb < 2; gb++) {
+                    const int dblk = db + 32 * gb;
+                    if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform
+                    f32x16 g;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) g[j] = 0.f;
+                    const int slot = (dblk + r) & 255;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                        const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && qok;
+                        const float pv = valid ? __builtin_amdgcn_exp2f(g[j] * p.scale_log2e - lse2) : 0.f;
+                        g[j] = -p.scale * pv * dlt;
+                    }
+                    if (dblk == iw0 - pz) {
+                        // straddling block: into block-0 columns of the un-skew buffer (4 consecutive distances per store)
+#pragma unroll
+                        for (int grp = 0; grp < 4; grp++) {
+                            const u32x2 w = {pack2bf(g[4 * grp], g[4 * grp + 1]), pack2bf(g[4 * grp + 2], g[4 * grp + 3])};
+                            *reinterpret_cast<u32x2*>(myDG + 8 * grp + 4 * hh) = w;
+                        }
+                    } else {
+                        if (dgrow && qok) {
+#pragma unroll
+                            for (int grp = 0; grp < 4; grp++) {
+                                const int d4 = dblk + 8 * grp + 4 * hh;
+                                if (d4 + 3 <= M - 1) {
+                                    const u32x2 w = {pack2bf(g[4 * grp], g[4 * grp + 1]), pack2bf(g[4 * grp + 2], g[4 * grp + 3])};
+                                    *reinterpret_cast<u32x2*>(dgrow + d4) = w;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int st = 0; st < 2; st++) {
+                            const u32x4 pw = {pack2bf(g[8 * st], g[8 * st + 1]), pack2bf(g[8 * st + 2], g[8 * st + 3]),
+                                              pack2bf(g[8 * st + 4], g[8 * st + 5]), pack2bf(g[8 * st + 6], g[8 * st + 7])};
+                            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                            for (int e = 0; e < EB; e++) {
+                                const int dist = dblk + 16 * st + 4 * hh + q4;      // accumulator-permuted k order
+                                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                                bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                                if (ecol < DH) {
+                                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff(dist & 255, ecol)));
+                                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff((dist + 8) & 255, ecol)));
+                                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                }
+                                ar[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                                __builtin_bit_cast(mfma_bf16x8, pf), ar[e], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     {
-        const int P0 = kt_lo * KT;
-        load_kv(kt_lo);
+        const int P0 = kt_start * KT;
+        load_kv(kt_start);
         store_kv(0);
 #pragma unroll 1
         for (int q4 = 0; q4 < 3; q4++) {
@@ -255,17 +347,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     }
     __syncthreads();
 
-    f32x16 aw[EB], ar[EB];  // dQw^T, dQr^T : [e][query]
-#pragma unroll
-    for (int e = 0; e < EB; e++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) { aw[e][j] = 0.f; ar[e][j] = 0.f; }
-    bool have_ring = false;
-    int cur = 0;
-    bf16_t* dgrow = p.dg ? p.dg + (((size_t)b * p.H + h) * T + (qok ? qi : 0)) * (size_t)M : nullptr;
-
 #pragma unroll 1
-    for (int kt = kt_lo; kt <= kt_hi; kt++) {
+    for (int kt = kt_start; kt <= kt_hi; kt++) {
         const int P = kt * KT;
         const bool more = kt < kt_hi;
         if (more) {
