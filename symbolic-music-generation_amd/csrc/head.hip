@@ -43,36 +43,47 @@ __global__ void label_guard_kernel(long long* labels, int T, long long eos) {
 
 // nll[b][t] for t in [0, T-1); acc[0] += sum(nll), acc[1] += count(nll != 0).  lse_out[row][0] = head lse,
 // lse_out[row][1] = tail lse of the label's cluster (if any).
+constexpr int NLL_ROWS_PER_WAVE = 16;   // 64 token rows per block: one atomic pair per block instead of per row
 __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logits, int ldl, const long long* labels, float* nll,
                                                       float* lse_out, float* acc, int B, int T, HeadGeom g) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B * T) return;
-    const int lane = threadIdx.x & 63;
-    const int b = row / T, t = row % T;
-    if (t == T - 1) return;  // hidden[:, :-1]
-    const long long lab = labels[(size_t)b * T + t + 1];
-    float* out = nll + (size_t)b * (T - 1) + t;
-    if (lab < 0 || lab >= g.V) {  // -100 (or any out-of-vocab id): no cluster matches -> stays 0
-        if (lane == 0) { *out = 0.f; lse_out[2 * (size_t)row] = 0.f; lse_out[2 * (size_t)row + 1] = 0.f; }
-        return;
+    __shared__ float part[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float tsum = 0.f, tcnt = 0.f;
+    for (int rr = 0; rr < NLL_ROWS_PER_WAVE; rr++) {
+        const int row = (blockIdx.x * 4 + wid) * NLL_ROWS_PER_WAVE + rr;
+        if (row >= B * T) break;
+        const int b = row / T, t = row % T;
+        if (t == T - 1) continue;  // hidden[:, :-1]
+        const long long lab = labels[(size_t)b * T + t + 1];
+        float* out = nll + (size_t)b * (T - 1) + t;
+        if (lab < 0 || lab >= g.V) {  // -100 (or any out-of-vocab id): no cluster matches -> stays 0
+            if (lane == 0) { *out = 0.f; lse_out[2 * (size_t)row] = 0.f; lse_out[2 * (size_t)row + 1] = 0.f; }
+            continue;
+        }
+        const float* lr = logits + (size_t)row * ldl;
+        const float head_lse = wave_lse_range(lr, 0, g.cut[1], lane, 0.f, lr + g.V, g.ncl);
+        int ci = 0;
+        for (int i = 1; i <= g.ncl; i++) if (lab >= g.cut[i]) ci = i;
+        float v, tail_lse = 0.f;
+        if (ci == 0) {
+            v = head_lse - lr[lab];
+        } else {
+            tail_lse = wave_lse_range(lr, g.cut[ci], g.cut[ci + 1], lane, 0.f, nullptr, 0);
+            v = (head_lse - lr[g.V + ci - 1]) + (tail_lse - lr[lab]);
+        }
+        if (lane == 0) {
+            *out = v;
+            lse_out[2 * (size_t)row] = head_lse;
+            lse_out[2 * (size_t)row + 1] = tail_lse;
+        }
+        tsum += v;
+        if (v != 0.f) tcnt += 1.f;
     }
-    const float* lr = logits + (size_t)row * ldl;
-    const float head_lse = wave_lse_range(lr, 0, g.cut[1], lane, 0.f, lr + g.V, g.ncl);
-    int ci = 0;
-    for (int i = 1; i <= g.ncl; i++) if (lab >= g.cut[i]) ci = i;
-    float v, tail_lse = 0.f;
-    if (ci == 0) {
-        v = head_lse - lr[lab];
-    } else {
-        tail_lse = wave_lse_range(lr, g.cut[ci], g.cut[ci + 1], lane, 0.f, nullptr, 0);
-        v = (head_lse - lr[g.V + ci - 1]) + (tail_lse - lr[lab]);
-    }
-    if (lane == 0) {
-        *out = v;
-        lse_out[2 * (size_t)row] = head_lse;
-        lse_out[2 * (size_t)row + 1] = tail_lse;
-        atomicAdd(acc, v);
-        if (v != 0.f) atomicAdd(acc + 1, 1.f);
+    if (lane == 0) { part[wid] = tsum; part[4 + wid] = tcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, (part[0] + part[1]) + (part[2] + part[3]));
+        atomicAdd(acc + 1, (part[4] + part[5]) + (part[6] + part[7]));
     }
 }
 
@@ -157,7 +168,7 @@ extern "C" int mxl_adaptive_nll_fwd(const float* logits, int ldl, const void* la
     int rc = make_geom(g, V, ncl, cutoffs_host);
     if (rc) return rc;
     MXL_CHECK_ARG(ldl >= V + ncl);
-    hipLaunchKernelGGL(nll_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3((B * T + 4 * NLL_ROWS_PER_WAVE - 1) / (4 * NLL_ROWS_PER_WAVE)), dim3(256), 0, (hipStream_t)stream, logits, ldl,
                        (const long long*)labels, nll, lse, acc2, B, T, g);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
