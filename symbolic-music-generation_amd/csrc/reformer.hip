@@ -452,13 +452,23 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
             }
         }
     float* dqp = p.dq + ((size_t)b * p.T + qpos) * d + h * DH;
+    if (p.n_h == 1) {   // every (position, head) occurs once: plain 16-byte stores, no atomics, no pre-zeroing needed
 #pragma unroll
-    for (int e = 0; e < EB; e++)
+        for (int e = 0; e < EB; e++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (ee < DH) atomicAdd(dqp + ee, aq[e][j]);
-        }
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) *reinterpret_cast<f32x4*>(dqp + e0) = f32x4{aq[e][4 * grp], aq[e][4 * grp + 1], aq[e][4 * grp + 2], aq[e][4 * grp + 3]};
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                if (ee < DH) atomicAdd(dqp + ee, aq[e][j]);
+            }
+    }
 }
 
 // key-owner: workgroup = key chunk kc; wave w owns 32 keys of it for one of the two query chunks: w = 2*qsel + khalf
@@ -608,15 +618,47 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
             }
         }
     }
-    float* dkp = p.dk + ((size_t)b * p.T + kpos) * d + h * DH;
-    float* dvp = p.dv + ((size_t)b * p.T + kpos) * d + h * DH;
+    // the two query chunks that see this key live in different waves of the workgroup (qsel): combine them through LDS so
+    // each (key, e) is written once -- plain stores for n_h == 1, one atomic per element otherwise
+    __syncthreads();
+    constexpr int RS = DH + 4;                        // padded row: spreads the 32 key rows of a wave over the banks
+    float* red = reinterpret_cast<float*>(smem);     // [2 kinds][64 keys][RS] f32 (re-uses the whole query staging area)
+    const int krow = 32 * (wid & 1) + r;
+    if (qsel == 1) {
 #pragma unroll
-    for (int e = 0; e < EB; e++)
+        for (int e = 0; e < EB; e++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (ee < DH) { atomicAdd(dkp + ee, ak[e][j]); atomicAdd(dvp + ee, av[e][j]); }
-        }
+            for (int j = 0; j < 16; j++) {
+                const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                if (ee < DH) { red[krow * RS + ee] = ak[e][j]; red[64 * RS + krow * RS + ee] = av[e][j]; }
+            }
+    }
+    __syncthreads();
+    if (qsel == 0) {
+        float* dkp = p.dk + ((size_t)b * p.T + kpos) * d + h * DH;
+        float* dvp = p.dv + ((size_t)b * p.T + kpos) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    f32x4 vk, vv;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        vk[t] = ak[e][4 * grp + t] + red[krow * RS + e0 + t];
+                        vv[t] = av[e][4 * grp + t] + red[64 * RS + krow * RS + e0 + t];
+                    }
+                    if (p.n_h == 1) {
+                        *reinterpret_cast<f32x4*>(dkp + e0) = vk;
+                        *reinterpret_cast<f32x4*>(dvp + e0) = vv;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) { atomicAdd(dkp + e0 + t, vk[t]); atomicAdd(dvp + e0 + t, vv[t]); }
+                    }
+                }
+            }
+    }
 }
 
 // =====================================================================================================================
@@ -625,20 +667,37 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
 // dqk[n][h][:] = dq + f * dk' - x * (sum_e dk'_e x_e) * (m + eps)^(-3/2) / dh^(3/2),  m = mean(x^2),  f = (m+eps)^(-1/2)/sqrt(dh)
 __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, const float* dq, const float* dkp, bf16_t* dqk,
                                        int B, int T, int H, int dh) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, t, h)
-    if (gid >= (long long)B * T * H) return;
-    const int h = (int)(gid % H);
-    const long long n = gid / H;
+    // dh/8 consecutive lanes own one (b, t, h) vector: 16-byte bf16 loads, 2 x 16-byte fp32 loads per operand
+    const int lpv = dh >> 3;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long vec = gid / lpv;
+    const int c = (int)(gid % lpv);
+    const bool ok = vec < (long long)B * T * H;
+    const long long v_ = ok ? vec : 0;
+    const int h = (int)(v_ % H);
+    const long long n = v_ / H;
     const int t = (int)(n % T), b = (int)(n / T);
-    const bf16_t* x = qk + (size_t)b * bs + (size_t)t * rs + h * dh;
-    const size_t o = (size_t)n * H * dh + (size_t)h * dh;
+    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(qk + (size_t)b * bs + (size_t)t * rs + h * dh + c * 8);
+    const size_t o = (size_t)n * H * dh + (size_t)h * dh + c * 8;
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(dkp + o), k1 = *reinterpret_cast<const f32x4*>(dkp + o + 4);
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(dq + o), q1 = *reinterpret_cast<const f32x4*>(dq + o + 4);
+    float x[8], dk[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+    float dqv[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
     float m = 0.f, dot = 0.f;
-    for (int e = 0; e < dh; e++) { const float xv = bf2f(x[e]); m += xv * xv; dot += dkp[o + e] * xv; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x[j] = bf2f((bf16_t)xv[j]); m += x[j] * x[j]; dot += dk[j] * x[j]; }
+    for (int off = 1; off < lpv; off <<= 1) { m += __shfl_xor(m, off, 64); dot += __shfl_xor(dot, off, 64); }
     m = m / (float)dh + 1e-6f;
     const float rs_ = rsqrtf(m);
     const float f = rs_ * rsqrtf((float)dh);
-    const float c = dot * rs_ * rs_ * rs_ / ((float)dh * sqrtf((float)dh));
-    for (int e = 0; e < dh; e++) dqk[o + e] = f2bf(dq[o + e] + f * dkp[o + e] - bf2f(x[e]) * c);
+    const float cc = dot * rs_ * rs_ * rs_ / ((float)dh * sqrtf((float)dh));
+    if (ok) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = dqv[j] + f * dk[j] - x[j] * cc;
+        u32x4 w = {pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7])};
+        *reinterpret_cast<u32x4*>(dqk + o) = w;
+    }
 }
 
 // out[b,t,h,:] = sum_r w_r out_r[b,r,t,h,:],  w = softmax_r(lse[b,r,h,t])
@@ -813,7 +872,8 @@ extern "C" int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, c
 extern "C" int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int B,
                                    int T, int H, int dh, void* stream) {
     MXL_CHECK_ARG(qk && dq && dk_eff && dqk && B > 0 && T > 0 && H > 0 && dh > 0);
-    const long long n = (long long)B * T * H;
+    MXL_CHECK_ARG((dh % 8) == 0 && (64 % (dh / 8)) == 0);
+    const long long n = (long long)B * T * H * (dh / 8);
     hipLaunchKernelGGL(lsh_keynorm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, B, T, H, dh);
     MXL_LAUNCH_CHECK();
