@@ -167,7 +167,8 @@ def main():
             ach = alg / (ms * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'relattn_bwd (delta + dq + dkv launches, one layer)', 'bound': 'mfma', 'achieved': ach,
                                'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS,
-                               'traffic': None, 'avg_launch_ms': ms, 'launches_timed': len(timed['ev'])}
+                               'traffic': pmc_traffic(args.workload, B), 'traffic_unit': 'HBM bytes per launch group (PMC)',
+                               'avg_launch_ms': ms, 'launches_timed': len(timed['ev'])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, T, M)
         print(json.dumps(out), flush=True)
@@ -266,6 +267,21 @@ def decode_bench(args, dev, rank, world):
                             'frac': bytes_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                             'algorithmic_bytes_per_step': bytes_step}}
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic(workload, B):
+    """HBM bytes per attention-backward call from the committed PMC passes (profiles/r01_c3_pmc_traffic.json, produced by
+    scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same command; FETCH doubled per the
+    gfx950 correction).  Counters cannot be collected from inside the timed run, so this is the recorded measurement for the
+    default workload and None for any other."""
+    path = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_traffic.json')
+    if workload != 'c3' or B != WORKLOADS['c3']['B'] or not os.path.exists(path):
+        return None
+    k = json.load(open(path))['kernels']
+    names = ('relattn_bwd_delta_kernel', 'relattn_bwd_dq_kernel<64>', 'relattn_bwd_dkv_kernel<64>')
+    if not all(n in k for n in names):
+        return None
+    return sum(k[n]['hbm_bytes_per_launch'] for n in names)
 
 
 def cpu_baseline(wl, T, M):

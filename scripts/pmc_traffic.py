@@ -1,0 +1,40 @@
+"""Aggregate the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs -- both do not fit the TCC slots) of
+`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` into per-kernel HBM traffic per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py ...
+    python scripts/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv \
+        profiles/r01_c3_pmc_traffic.json
+
+Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KB; on gfx950 FETCH_SIZE
+tallies the 128-byte requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for
+16-byte stores and float atomics.  Infinity-Cache hits are included in both (memory-side L2 counters)."""
+import json
+import sys
+
+import pandas as pd
+
+
+def per_kernel(path, counter):
+    df = pd.read_csv(path)
+    df = df[df.Counter_Name == counter]
+    df = df.assign(k=df.Kernel_Name.str.replace(r'\(anonymous namespace\)::', '', regex=True).str.replace(r'\(.*', '', regex=True)
+                   .str.replace('void ', ''))
+    return df.groupby('k').Counter_Value.agg(['count', 'mean'])
+
+
+def main(fetch_csv, write_csv, out_json):
+    f = per_kernel(fetch_csv, 'FETCH_SIZE')
+    w = per_kernel(write_csv, 'WRITE_SIZE')
+    out = {}
+    for k in sorted(set(f.index) | set(w.index)):
+        fk = float(f['mean'].get(k, 0.0)) * 1000.0
+        wk = float(w['mean'].get(k, 0.0)) * 1000.0
+        out[k] = {'launches': int(f['count'].get(k, w['count'].get(k, 0))), 'fetch_size_bytes_raw': fk,
+                  'fetch_bytes_corrected_x2': 2.0 * fk, 'write_bytes': wk, 'hbm_bytes_per_launch': 2.0 * fk + wk}
+    json.dump({'command': 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (SURVEY C3, 1x MI355X)',
+               'units': 'bytes per launch (counter mean over launches x 1000)', 'kernels': out}, open(out_json, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
