@@ -114,21 +114,33 @@ __device__ __forceinline__ void skew_read16(uint32_t base, uint32_t (&u)[16]) {
         : "v"(base)
         : "memory");
 }
-// the mirror image: 16 genuine ds_write_b16 (low halves of u[j]) at the same column pattern
-__device__ __forceinline__ void skew_write16(uint32_t base, const uint32_t (&u)[16]) {
+// the mirror image of skew_read16 for dSr: 16 genuine 16-bit writes at the same column pattern.
+// packed variant: w[m] holds (value 2m, value 2m+1) as a bf16 pair; the odd one leaves through ds_write_b16_d16_hi
+__device__ __forceinline__ void skew_write16p(uint32_t base, const uint32_t (&w)[8]) {
     asm volatile(
-        "ds_write_b16 %16, %0 offset:54\n\t"  "ds_write_b16 %16, %1 offset:52\n\t"  "ds_write_b16 %16, %2 offset:50\n\t"
-        "ds_write_b16 %16, %3 offset:48\n\t"  "ds_write_b16 %16, %4 offset:38\n\t"  "ds_write_b16 %16, %5 offset:36\n\t"
-        "ds_write_b16 %16, %6 offset:34\n\t"  "ds_write_b16 %16, %7 offset:32\n\t"  "ds_write_b16 %16, %8 offset:22\n\t"
-        "ds_write_b16 %16, %9 offset:20\n\t"  "ds_write_b16 %16, %10 offset:18\n\t" "ds_write_b16 %16, %11 offset:16\n\t"
-        "ds_write_b16 %16, %12 offset:6\n\t"  "ds_write_b16 %16, %13 offset:4\n\t"  "ds_write_b16 %16, %14 offset:2\n\t"
-        "ds_write_b16 %16, %15"
+        "ds_write_b16 %8, %0 offset:54\n\t"         "ds_write_b16_d16_hi %8, %0 offset:52\n\t"
+        "ds_write_b16 %8, %1 offset:50\n\t"         "ds_write_b16_d16_hi %8, %1 offset:48\n\t"
+        "ds_write_b16 %8, %2 offset:38\n\t"         "ds_write_b16_d16_hi %8, %2 offset:36\n\t"
+        "ds_write_b16 %8, %3 offset:34\n\t"         "ds_write_b16_d16_hi %8, %3 offset:32\n\t"
+        "ds_write_b16 %8, %4 offset:22\n\t"         "ds_write_b16_d16_hi %8, %4 offset:20\n\t"
+        "ds_write_b16 %8, %5 offset:18\n\t"         "ds_write_b16_d16_hi %8, %5 offset:16\n\t"
+        "ds_write_b16 %8, %6 offset:6\n\t"          "ds_write_b16_d16_hi %8, %6 offset:4\n\t"
+        "ds_write_b16 %8, %7 offset:2\n\t"          "ds_write_b16_d16_hi %8, %7"
         :
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]), "v"(u[8]), "v"(u[9]),
-          "v"(u[10]), "v"(u[11]), "v"(u[12]), "v"(u[13]), "v"(u[14]), "v"(u[15]), "v"(base)
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(base)
         : "memory");
 }
+// s + (float)h in ONE VALU issue (v_fma_mix_f32: f32 * 1.0 + f16 from the low half of `h16`)
+__device__ __forceinline__ float add_f16(float s, uint32_t h16) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(h16));
+    return r;
+}
 
+// Operand scaling shared by the three attention kernels (relattn_fwd.hip builds its fragments the same way, so the
+// recomputed scores match the forward's LSE bit for bit):  Qw, Qr carry scale*log2(e) (scores come out in exp2 units),
+// dO carries `scale` (dP comes out as scale*dP).  -lse and -scale*delta enter as the C operand of the first MFMA of each
+// chain, so the per-score VALU work is one v_fma_mix (S + BD), one v_exp and one multiply.
 template <int DH>
 __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     using G = GeoQ<DH>;
@@ -175,15 +187,18 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float qf = qok ? bf2f((bf16_t)qv[j]) : 0.f;
-                qw[ks][j] = (short)f2bf(qf + p.rwb[h * DH + e0 + j]);
-                qr[ks][j] = (short)f2bf(qf + p.rrb[h * DH + e0 + j]);
-                dof[ks][j] = qok ? dv[j] : (short)0;
+                qw[ks][j] = (short)f2bf((qf + p.rwb[h * DH + e0 + j]) * p.scale_log2e);
+                qr[ks][j] = (short)f2bf((qf + p.rrb[h * DH + e0 + j]) * p.scale_log2e);
+                dof[ks][j] = qok ? (short)f2bf(bf2f((bf16_t)dv[j]) * p.scale) : (short)0;
             }
         }
     }
     const size_t sidx = ((size_t)b * p.H + h) * T + (qok ? qi : 0);
     const float lse2 = qok ? p.lse[sidx] * LOG2E : 0.f;
-    const float dlt = qok ? p.delta[sidx] : 0.f;
+    const float ndlt = qok ? -p.scale * p.delta[sidx] : 0.f;
+    f32x16 c_lse, c_dlt;          // MFMA C operands: -lse (log2 units) and -scale*delta of this lane's query
+#pragma unroll
+    for (int j = 0; j < 16; j++) { c_lse[j] = -lse2; c_dlt[j] = ndlt; }
 
     // zero this wave's un-skew ring: never-written cells must read as 0
     {
@@ -273,9 +288,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 for (int gb = 0; gb < 2; gb++) {
                     const int dblk = db + 32 * gb;
                     if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform
-                    f32x16 g;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) g[j] = 0.f;
+                    f32x16 g = c_lse;
                     const int slot = (dblk + r) & 255;
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
@@ -283,12 +296,19 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                         g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                     __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                     }
+                    // dSr = -scale * P * delta.  Only boundary blocks need the per-cell validity test (scalar branch).
+                    const bool fullblk = __builtin_amdgcn_readfirstlane(
+                        (int)((dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T))) != 0;
+                    if (fullblk) {
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                        const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && qok;
-                        const float pv = valid ? __builtin_amdgcn_exp2f(g[j] * p.scale_log2e - lse2) : 0.f;
-                        g[j] = -p.scale * pv * dlt;
+                        for (int j = 0; j < 16; j++) g[j] = __builtin_amdgcn_exp2f(g[j]) * ndlt;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                            const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && qok;
+                            g[j] = valid ? __builtin_amdgcn_exp2f(g[j]) * ndlt : 0.f;
+                        }
                     }
                     if (dblk == iw0 - pz) {
                         // straddling block: into block-0 columns of the un-skew buffer (4 consecutive distances per store)
@@ -364,8 +384,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             f32x16 s[2], dp[2];
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) { s[kb][j] = 0.f; dp[kb][j] = 0.f; }
+                s[kb] = c_lse;
+                dp[kb] = c_dlt;
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
@@ -415,27 +435,26 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127.  Scalar branch on the
             // (readfirstlane) full-tile flag, otherwise hipcc if-converts the mask onto every tile.
             const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
+            uint32_t dsw[2][8];       // dSr as bf16 pairs (2m, 2m+1): MFMA operand and skew-write source
             auto grads = [&](auto masked) {
                 constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
-                    uint32_t bdu[16], dsu[16];
+                    uint32_t bdu[16];
                     skew_read16(gRb - 64 * kb, bdu);
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        const float bd = (float)__builtin_bit_cast(_Float16, (unsigned short)bdu[j]);
-                        const float val = (s[kb][j] + bd) * p.scale_log2e - lse2;
-                        float pv = __builtin_amdgcn_exp2f(val);
+                        float pv = __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[j]));
                         if (MASKED) {
                             const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
                             const bool valid = (d >= 0) && (d <= M - 1) && qok;
                             pv = valid ? pv : 0.f;
                         }
-                        const float ds = p.scale * pv * (dp[kb][j] - dlt);
-                        s[kb][j] = ds;
-                        dsu[j] = (uint32_t)f2bf(ds);
+                        s[kb][j] = pv * dp[kb][j];
                     }
-                    skew_write16(dgWb - 64 * kb, dsu);
+#pragma unroll
+                    for (int m = 0; m < 8; m++) dsw[kb][m] = pack2bf(s[kb][2 * m], s[kb][2 * m + 1]);
+                    skew_write16p(dgWb - 64 * kb, dsw[kb]);
                 }
             };
             if (full) grads(std::false_type{}); else grads(std::true_type{});
@@ -445,8 +464,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
-                    const u32x4 pw = {pack2bf(s[kb][8 * st], s[kb][8 * st + 1]), pack2bf(s[kb][8 * st + 2], s[kb][8 * st + 3]),
-                                      pack2bf(s[kb][8 * st + 4], s[kb][8 * st + 5]), pack2bf(s[kb][8 * st + 6], s[kb][8 * st + 7])};
+                    const u32x4 pw = {dsw[kb][4 * st], dsw[kb][4 * st + 1], dsw[kb][4 * st + 2], dsw[kb][4 * st + 3]};
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
                     for (int e = 0; e < EB; e++) {
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 // key-owner kernel: wave owns 32 keys (lane = key), workgroup 128 keys; streams 32-query tiles
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int KB = 128, QT = 32;
-constexpr int SKS = 68;  // fp32 skew row stride
+constexpr int SKS = 68;  // fp16 skew row stride (64 distance columns + pad): 136-byte rows, 8-byte aligned groups
 
 template <int DH> struct GeoK {
     static constexpr int KS = DH / 16;
@@ -541,7 +559,7 @@ template <int DH> struct GeoK {
     static constexpr int CH = DH / 8;
     static constexpr int Q_BYTES = QT * ROWB;          // one 32-row tile image
     static constexpr int R_BYTES = 256 * ROWB;
-    static constexpr int S_BYTES = 4 * 32 * SKS * 4;
+    static constexpr int S_BYTES = 4 * 32 * SKS * 2;
     static constexpr int SMEM = 3 * Q_BYTES + 2 * QT * 4 + R_BYTES + S_BYTES;
     __device__ static __forceinline__ int koff(int row, int ch) {
         if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
@@ -549,6 +567,24 @@ template <int DH> struct GeoK {
     }
     __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
 };
+
+// key-owner skew read: register j belongs to query ii = pat(j) + 4*hh and needs column ii - r + 32 of row ii, i.e. the
+// per-lane base plus pat(j) * (SKS + 1) elements: 16 genuine ds_read_u16 with immediate offsets (see relattn_fwd.hip)
+__device__ __forceinline__ void skew_read16k(uint32_t base, uint32_t (&u)[16]) {
+    static_assert(SKS == 68, "offsets below are pat(j) * (SKS + 1) * 2 bytes");
+    asm volatile(
+        "ds_read_u16 %0, %16\n\t"              "ds_read_u16 %1, %16 offset:138\n\t"   "ds_read_u16 %2, %16 offset:276\n\t"
+        "ds_read_u16 %3, %16 offset:414\n\t"   "ds_read_u16 %4, %16 offset:1104\n\t"  "ds_read_u16 %5, %16 offset:1242\n\t"
+        "ds_read_u16 %6, %16 offset:1380\n\t"  "ds_read_u16 %7, %16 offset:1518\n\t"  "ds_read_u16 %8, %16 offset:2208\n\t"
+        "ds_read_u16 %9, %16 offset:2346\n\t"  "ds_read_u16 %10, %16 offset:2484\n\t" "ds_read_u16 %11, %16 offset:2622\n\t"
+        "ds_read_u16 %12, %16 offset:3312\n\t" "ds_read_u16 %13, %16 offset:3450\n\t" "ds_read_u16 %14, %16 offset:3588\n\t"
+        "ds_read_u16 %15, %16 offset:3726\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
+          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
+        : "v"(base)
+        : "memory");
+}
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
@@ -558,10 +594,10 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     char* sQw = smem;
     char* sQr = sQw + G::Q_BYTES;
     char* sDO = sQr + G::Q_BYTES;
-    float* sLse = reinterpret_cast<float*>(sDO + G::Q_BYTES);  // [32] (log2 units)
-    float* sDl = sLse + QT;                                     // [32]
+    float* sLse = reinterpret_cast<float*>(sDO + G::Q_BYTES);  // [32] -lse (log2 units)
+    float* sDl = sLse + QT;                                     // [32] -scale * delta
     char* sR = reinterpret_cast<char*>(sDl + QT);               // ring [256][DH]
-    float* sS = reinterpret_cast<float*>(sR + G::R_BYTES);      // [4][32][SKS]
+    _Float16* sS = reinterpret_cast<_Float16*>(sR + G::R_BYTES);   // [4][32 queries][SKS] fp16: G rows, lane-private per wave
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
@@ -572,7 +608,10 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     const int Pw = P0 + 32 * wid;
     const int pk = Pw + r;                 // this lane's key position
     const bool kok = pk < T;               // pk >= p0 always
-    float* myS = sS + wid * 32 * SKS;
+    _Float16* myS = sS + wid * 32 * SKS;
+    _Float16* sW = myS + r * SKS + 4 * hh;                                  // G^T column of query r: row r, 4 distances per store
+    const uint32_t sRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)
+                         (myS + 4 * hh * (SKS + 1) + 32 - r);
 
     const bf16_t* qbase = p.q + (size_t)b * p.q_bs + (size_t)h * DH;
     const bf16_t* dobase = p.dout + (size_t)b * p.o_bs + (size_t)h * DH;
@@ -611,26 +650,29 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
         if (tid < QT) {
             const bool ok2 = I + tid < T;
             const size_t sidx = ((size_t)b * p.H + h) * T + (ok2 ? I + tid : 0);
-            tl = ok2 ? p.lse[sidx] * LOG2E : 0.f;
-            tdl = ok2 ? p.delta[sidx] : 0.f;
+            tl = ok2 ? -p.lse[sidx] * LOG2E : 0.f;
+            tdl = ok2 ? -p.scale * p.delta[sidx] : 0.f;
         }
     };
     auto store_q = [&]() {
         if (tid < QT * G::CH) {
             const int row = tid / G::CH, ch = tid % G::CH;
-            u32x4 w, rq;
+            u32x4 w, rq, wd;
             const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
+            const bf16_t* sdo = reinterpret_cast<const bf16_t*>(&tdo);
             bf16_t* dw = reinterpret_cast<bf16_t*>(&w);
             bf16_t* dr = reinterpret_cast<bf16_t*>(&rq);
+            bf16_t* dd = reinterpret_cast<bf16_t*>(&wd);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < 8; j++) {     // operand scaling: see the note above relattn_bwd_dq_kernel
                 const float qf = bf2f(src[j]);
-                dw[j] = f2bf(qf + p.rwb[h * DH + ch * 8 + j]);
-                dr[j] = f2bf(qf + p.rrb[h * DH + ch * 8 + j]);
+                dw[j] = f2bf((qf + p.rwb[h * DH + ch * 8 + j]) * p.scale_log2e);
+                dr[j] = f2bf((qf + p.rrb[h * DH + ch * 8 + j]) * p.scale_log2e);
+                dd[j] = f2bf(bf2f(sdo[j]) * p.scale);
             }
             *reinterpret_cast<u32x4*>(sQw + G::koff(row, ch)) = w;
             *reinterpret_cast<u32x4*>(sQr + G::koff(row, ch)) = rq;
-            *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = tdo;
+            *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = wd;
         }
         if (tid < QT) { sLse[tid] = tl; sDl[tid] = tdl; }
     };
@@ -681,10 +723,16 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
         const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pw < T);
         if (active) {
             const int dlo = I - Pw - 32;
-            // S = Qw . K^T and dP = dO . V^T  (rows = queries, lane = key)
+            // S = Qw . K^T - lse and dP = scale * (dO . V^T - delta)  (rows = queries, lane = key); the per-query constants
+            // enter as the C operand (register j <-> query (j&3) + 8*(j>>2) + 4*hh: four 16-byte LDS reads each)
             f32x16 s, dp;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { s[j] = 0.f; dp[j] = 0.f; }
+            for (int grp = 0; grp < 4; grp++) {
+                const f32x4 cl = *reinterpret_cast<const f32x4*>(sLse + 8 * grp + 4 * hh);
+                const f32x4 cd = *reinterpret_cast<const f32x4*>(sDl + 8 * grp + 4 * hh);
+#pragma unroll
+                for (int t = 0; t < 4; t++) { s[4 * grp + t] = cl[t]; dp[4 * grp + t] = cd[t]; }
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQw + G::koff(r, 2 * ks + hh));
@@ -694,8 +742,10 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ad),
                                                              __builtin_bit_cast(mfma_bf16x8, vf[ks]), dp, 0, 0, 0);
             }
-            // G = Qr . Rd^T over the 64-distance window (lane = distance), skewed through LDS to lane = key
-#pragma unroll 1
+            // G^T = Rd . Qr^T over the 64-distance window (lane = query, registers = distances): the lane writes its query's
+            // row of the fp16 skew buffer (4 consecutive distances per store); key lane r then reads column ii - r + 32 of
+            // row ii
+#pragma unroll
             for (int gb = 0; gb < 2; gb++) {
                 f32x16 g;
 #pragma unroll
@@ -703,34 +753,34 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
                 const int slot = (dlo + 32 * gb + r) & 255;
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQr + G::koff(r, 2 * ks + hh));
                     const bf16x8 bb = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                                __builtin_bit_cast(mfma_bf16x8, bb), g, 0, 0, 0);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQr + G::koff(r, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, bb),
+                                                                __builtin_bit_cast(mfma_bf16x8, a), g, 0, 0, 0);
                 }
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    myS[ii * SKS + 32 * gb + r] = g[j];
+                for (int grp = 0; grp < 4; grp++) {
+                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    *reinterpret_cast<f16x4*>(sW + 32 * gb + 8 * grp) = __builtin_convertvector(v4, f16x4);
                 }
             }
             const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (I + 31 < T))) != 0;
             f32x16 pr;
+            uint32_t bdu[16];
+            skew_read16k(sRb, bdu);
             auto grads = [&](auto masked) {
                 constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    const float bd = myS[ii * SKS + (ii - r + 32)];
-                    const float val = (s[j] + bd) * p.scale_log2e - sLse[ii];
-                    float pv = __builtin_amdgcn_exp2f(val);
+                    float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
                     if (MASKED) {
+                        const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
                         const int d = I + ii - pk;             // = dlo + (ii - r + 32)
                         const bool valid = (d >= 0) && (d <= M - 1) && (I + ii < T);
                         pv = valid ? pv : 0.f;
                     }
                     pr[j] = pv;
-                    s[j] = p.scale * pv * (dp[j] - sDl[ii]);
+                    s[j] = pv * dp[j];
                 }
             };
             if (full) grads(std::false_type{}); else grads(std::true_type{});
@@ -771,6 +821,14 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
         __syncthreads();
     }
 
+    // undo the operand scaling: dK was accumulated against scale*log2(e)*Qw, dV against scale*dO
+    {
+        const float fk = 1.f / p.scale_log2e, fv = 1.f / p.scale;
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) { ak[e][j] *= fk; av[e][j] *= fv; }
+    }
     if (kok) {
         const size_t srow = (size_t)(pk - p0);
         bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * DH;

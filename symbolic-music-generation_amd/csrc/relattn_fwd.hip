@@ -90,6 +90,15 @@ __device__ __forceinline__ void skew_read16(uint32_t base, uint32_t (&u)[16]) {
         : "memory");
 }
 
+// s + (float)h in ONE VALU issue (v_fma_mix_f32: f32 * 1.0 + f16 taken from the low half of `h16`)
+__device__ __forceinline__ float add_f16(float s, uint32_t h16) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(h16));
+    return r;
+}
+
+constexpr float RESCALE_THRESH = 8.0f;   // log2 units: accumulators are re-based when a score exceeds the reference by 2^8
+
 template <int DH>
 __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     using G = Geo<DH>;
@@ -132,8 +141,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float qf = ok ? bf2f((bf16_t)qv[j]) : 0.f;
-                qw[ks][j] = (short)f2bf(qf + p.rwb[h * DH + e0 + j]);
-                qr[ks][j] = (short)f2bf(qf + p.rrb[h * DH + e0 + j]);
+                // scale * log2(e) folded into the operands: the MFMA results are already in exp2 units
+                qw[ks][j] = (short)f2bf((qf + p.rwb[h * DH + e0 + j]) * p.scale_log2e);
+                qr[ks][j] = (short)f2bf((qf + p.rrb[h * DH + e0 + j]) * p.scale_log2e);
             }
         }
     }
@@ -198,7 +208,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
         __syncthreads();
     }
 
+    // Online softmax with a LAZY reference: every accumulated quantity is relative to m_run (log2 units), which is only
+    // moved when a new score exceeds it by RESCALE_THRESH (or when it is still unset = NEG_BIG).  -m_run is kept in 16
+    // registers (`cinit`) and enters the score for free as the C operand of the first MFMA of each chain, so a score costs
+    // one v_fma_mix (S + BD), half a v_max3, one v_exp and one add.  Both lanes of a query (hh = 0/1) see the same merged
+    // maximum and therefore take identical decisions.
     float m_run = NEG_BIG, l_run = 0.f;
+    f32x16 cinit;
+#pragma unroll
+    for (int j = 0; j < 16; j++) cinit[j] = 0.f;
 
     // ---- phantom keys.  Key positions below the first stored tile (pz) are upstream's zero mems: k = v = 0, so such a key
     // contributes exp(BD) to the softmax denominator and nothing else, and BD depends only on the distance.  Instead of
@@ -220,9 +238,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 for (int gb = 0; gb < 2; gb++) {
                     const int dblk = db + 32 * gb;
                     if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform: no phantom cell in this block
-                    f32x16 g;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) g[j] = 0.f;
+                    f32x16 g = cinit;
                     const int slot = (dblk + r) & 255;
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
@@ -230,24 +246,35 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                         g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                     __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                     }
-                    float mx = NEG_BIG;
+                    // every (query, distance) cell of the block phantom and in range?  (scalar)
+                    const bool fullblk = __builtin_amdgcn_readfirstlane(
+                        (int)((dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T))) != 0;
+                    if (!fullblk) {
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                        const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
-                        g[j] = valid ? g[j] * p.scale_log2e : NEG_BIG;
-                        mx = fmaxf(mx, g[j]);
+                        for (int j = 0; j < 16; j++) {
+                            const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                            const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
+                            g[j] = valid ? g[j] : NEG_BIG;
+                        }
                     }
+                    float mx = fmaxf(g[0], g[1]);
+#pragma unroll
+                    for (int j = 2; j < 16; j += 2) mx = fmaxf(mx, fmaxf(g[j], g[j + 1]));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const float m_new = fmaxf(m_run, mx);
+                    const bool unset = m_run == NEG_BIG;
+                    const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
+                    if (__any(need)) {
+                        const float delta = need ? mx : 0.f;
+                        if (need && !unset) l_run *= __builtin_amdgcn_exp2f(-delta);
+                        if (need) m_run = (unset ? 0.f : m_run) + delta;
+                        const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) { g[j] -= delta; cinit[j] = neg; }
+                    }
                     float rs = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const float pv = __builtin_amdgcn_exp2f(g[j] - m_new);
-                        rs += (g[j] > 0.5f * NEG_BIG) ? pv : 0.f;
-                    }
-                    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + rs;
-                    m_run = m_new;
+                    for (int j = 0; j < 16; j++) rs += __builtin_amdgcn_exp2f(g[j]);   // exp2(NEG_BIG) = 0 for masked cells
+                    l_run += rs;
                 }
             }
             __syncthreads();
@@ -293,8 +320,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             f32x16 s[2];
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) s[kb][j] = 0.f;
+                s[kb] = cinit;               // = -m_run: the scores come out relative to the softmax reference
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
@@ -345,45 +371,48 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     skew_read16(gRb - 64 * kb, bdu);
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        const float bd = (float)__builtin_bit_cast(_Float16, (unsigned short)bdu[j]);
-                        float val = (s[kb][j] + bd) * p.scale_log2e;
+                        float val = add_f16(s[kb][j], bdu[j]);
                         if (MASKED) {
                             const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
                             const bool valid = (d >= 0) && (d <= M - 1) && (qi < T);
                             val = valid ? val : NEG_BIG;
                         }
                         s[kb][j] = val;
-                        mx = fmaxf(mx, val);
                     }
+#pragma unroll
+                    for (int j = 0; j < 16; j += 2) mx = fmaxf(mx, fmaxf(s[kb][j], s[kb][j + 1]));
                 }
             };
             if (full) scores(std::false_type{}); else scores(std::true_type{});
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            float rs = 0.f;
-            auto probs = [&](auto masked) {
-                constexpr bool MASKED = decltype(masked)::value;
+            {
+                const bool unset = m_run == NEG_BIG;
+                const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
+                if (__any(need)) {               // rare after the first tile: move the reference, re-base O, l and the scores
+                    const float delta = need ? mx : 0.f;
+                    const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+                    if (need) m_run = (unset ? 0.f : m_run) + delta;
+                    const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
+                    l_run *= alpha;
 #pragma unroll
-                for (int kb = 0; kb < 2; kb++) {
+                    for (int j = 0; j < 16; j++) { s[0][j] -= delta; s[1][j] -= delta; cinit[j] = neg; }
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        float pv = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
-                        if (MASKED) pv = (s[kb][j] > 0.5f * NEG_BIG) ? pv : 0.f;   // exp2(NEG_BIG - NEG_BIG) = 1 otherwise
-                        s[kb][j] = pv;
-                        rs += pv;
-                    }
+                    for (int e = 0; e < EB; e++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++) o[e][j] *= alpha;
                 }
-            };
-            if (full) probs(std::false_type{}); else probs(std::true_type{});
-            l_run = l_run * alpha + rs;
-            if (__any(alpha != 1.0f)) {      // row maxima settle after the first tiles: skip the O^T rescale when nothing moved
-#pragma unroll
-                for (int e = 0; e < EB; e++)
-#pragma unroll
-                    for (int j = 0; j < 16; j++) o[e][j] *= alpha;
             }
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kb][j]);     // masked cells: exp2(NEG_BIG) = 0
+                    s[kb][j] = pv;
+                    rs += pv;
+                }
+            }
+            l_run += rs;
             // ---- O^T += V^T . P^T
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
