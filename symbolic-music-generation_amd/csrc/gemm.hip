@@ -13,6 +13,7 @@
 // global -> registers -> LDS (XOR-swizzled images), LDS double-buffered, one barrier per K-tile.
 // K-contiguous operands are read with ds_read_b128, K-strided ones with ds_read_b64_tr_b16.
 // The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4 consecutive n of one m (8-byte stores).
+#include <stdlib.h>
 #include "common.h"
 #include "musicxl_internal.h"
 
@@ -106,6 +107,81 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
     }
 }
 
+// One 1x4 output quad (row m, columns n..n+3, n < N): alpha, bias, relu, dropout, relu-backward mask, aux add, store.
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = a4_[r] * p.alpha;
+            const bool full = (n + 3 < p.N);
+            if (flags & MXL_GEMM_BIAS) {
+                if (full) {
+                    const float b0 = p.bias[n], b1 = p.bias[n + 1], b2 = p.bias[n + 2], b3 = p.bias[n + 3];
+                    v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+                }
+            }
+            if (flags & MXL_GEMM_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (flags & MXL_GEMM_DROPOUT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool keep = dropout_keep(p.seed, p.site, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), p.thresh);
+                    v[r] = keep ? v[r] * p.drop_scale : 0.f;
+                }
+            }
+            if (flags & MXL_GEMM_RELU_BWD) {
+                if (full && ((p.ldaux & 3) == 0)) {
+                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = bf2f((bf16_t)a4[r]) > 0.f ? v[r] : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) {
+                            const float a = bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                            v[r] = a > 0.f ? v[r] : 0.f;
+                        }
+                }
+            }
+            if (flags & MXL_GEMM_ADD_AUX) {
+                if (full && ((p.ldaux & 3) == 0)) {
+                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] += bf2f((bf16_t)a4[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
+                }
+            }
+            if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (n + r < p.N) atomicAdd(c + r, v[r]);
+            } else if (flags & MXL_GEMM_OUT_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (full && ((p.ldc & 3) == 0)) {
+                    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = v[r];
+                }
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+                if (full && ((p.ldc & 3) == 0)) {
+                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(c) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = f2bf(v[r]);
+                }
+            }
+}
+
 template <bool AT, bool BT, int BN_>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     constexpr int BN = BN_;              // 128, or 64 for skinny-N problems (the per-head dRd contraction: N = d_head)
@@ -194,77 +270,132 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < NF; j++) {
             const int n = n0 + wc * (BN / 2) + j * 16 + nq;
             if (n >= p.N) continue;
-            float v[4];
+            epilogue_quad(p, flags, m, n, acc[i][j]);
+        }
+    }
+}
+
+// =====================================================================================================================
+// Large-tile kernel for the K-contiguous ("NT") form y = x W^T with M >= 256: the forward linears and, through the
+// transposed weight copies the engine keeps, the dX products.
+//
+//   tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 8 x 4 fragments: 12 KB of fragment reads per 32
+//   MFMAs (the 128^2 kernel above reads 16 KB per 32 and sits on the LDS-bandwidth roof).
+//   HBM/L2 -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write pass) into a FOUR-stage ring of 32 KB
+//   stages; the XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the LDS side of the DMA is
+//   lane-linear).  Loads run three K-steps ahead and stay in flight across the one raw s_barrier per K-step: counted
+//   s_waitcnt vmcnt(4), never 0 inside the loop.  Fragments are register double-buffered: the ds_reads of step t+1 are
+//   issued before the MFMAs of step t.
+//
+//   step t:   glds(t+3) -> stage (t+3)&3     (last read by the fragment loads of step t-1, issued in step t-2)
+//             ds_read fragments(t+1)         (landed: waited at the end of step t-1, published by that barrier)
+//             32 MFMAs on fragments(t)
+//             s_waitcnt vmcnt(4)  [tile t+2 landed; tile t+3 may still fly]   lgkmcnt(0)   s_barrier
+// =====================================================================================================================
+constexpr int G2_OP_BYTES = 256 * 32 * 2;      // one operand, one stage: [256 rows][32 k] bf16 = 16 KiB
+constexpr int G2_STAGE = 2 * G2_OP_BYTES;
+constexpr int G2_SMEM = 4 * G2_STAGE;          // 128 KiB
+
+typedef __attribute__((address_space(1))) const void* g2_gptr;
+typedef __attribute__((address_space(3))) void* g2_lptr;
+
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = p.K >> 5;
+
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // staging: DMA instruction i of wave w fills LDS rows (8i + w) * 16 .. +15 of the operand image (16 rows x 64 B,
+    // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ (l >> 4)
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] * p.alpha;
-            const bool full = (n + 3 < p.N);
-            if (flags & MXL_GEMM_BIAS) {
-                if (full) {
-                    const float b0 = p.bias[n], b1 = p.bias[n + 1], b2 = p.bias[n + 2], b3 = p.bias[n + 3];
-                    v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
-                } else {
+    for (int i = 0; i < 2; i++) {
+        const int row = (8 * i + wid) * 16 + (l >> 2);
+        const int kc = ((l & 3) ^ (l >> 4)) * 8;
+        ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kc;     // rows past the edge re-read the last row (never stored)
+        gb[i] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + kc;
+    }
+    auto issue = [&](int t) {
+        char* st = smem + (t & 3) * G2_STAGE;
+        const int k0 = t << 5;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
-                }
-            }
-            if (flags & MXL_GEMM_RELU) {
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((g2_gptr)(ga[i] + k0), (g2_lptr)(st + (8 * i + wid) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g2_gptr)(gb[i] + k0), (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16, 0, 0);
+        }
+    };
+    // fragment addresses: row = base + (l & 15), k-group g = l >> 4 sits in slot g ^ ((row >> 2) & 3)
+    const int fsw = ((l >> 4) ^ ((l >> 2) & 3)) << 4;
+    const int a_off = (wr * 128 + (l & 15)) * 64 + fsw;
+    const int b_off = G2_OP_BYTES + (wc * 64 + (l & 15)) * 64 + fsw;
+    auto frags = [&](int t, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) {
+        const char* st = smem + (t & 3) * G2_STAGE;
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (flags & MXL_GEMM_DROPOUT) {
+        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool keep = dropout_keep(p.seed, p.site, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), p.thresh);
-                    v[r] = keep ? v[r] * p.drop_scale : 0.f;
-                }
-            }
-            if (flags & MXL_GEMM_RELU_BWD) {
-                if (full && ((p.ldaux & 3) == 0)) {
-                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+        for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
+    };
+
+    f32x4 acc[8][4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = bf2f((bf16_t)a4[r]) > 0.f ? v[r] : 0.f;
-                } else {
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (n + r < p.N) {
-                            const float a = bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
-                            v[r] = a > 0.f ? v[r] : 0.f;
-                        }
-                }
-            }
-            if (flags & MXL_GEMM_ADD_AUX) {
-                if (full && ((p.ldaux & 3) == 0)) {
-                    const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: three tiles in flight, tiles 0 and 1 landed before the first barrier
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    frags(0, fa0, fb0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): nothing outstanding at loop entry, so the loop body needs no wait before its MFMAs
+
+    auto step = [&](int t, bf16x8 (&fa)[8], bf16x8 (&fb)[4], bf16x8 (&na)[8], bf16x8 (&nb)[4]) {
+        const bool more3 = t + 3 < nk;
+        if (more3) issue(t + 3);
+        if (t + 1 < nk) frags(t + 1, na, nb);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] += bf2f((bf16_t)a4[r]);
-                } else {
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
-                }
-            }
-            if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        if (more3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 2) {
+        step(t, fa0, fb0, fa1, fb1);
+        if (t + 1 < nk) step(t + 1, fa1, fb1, fa0, fb0);
+    }
+
+    // epilogue.  acc[i][j][r]: m = m0 + wr*128 + i*16 + (l&15), n = n0 + wc*64 + j*16 + (l>>4)*4 + r
+    const int flags = p.flags;
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (n + r < p.N) atomicAdd(c + r, v[r]);
-            } else if (flags & MXL_GEMM_OUT_F32) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-                if (full && ((p.ldc & 3) == 0)) {
-                    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
+    for (int i = 0; i < 8; i++) {
+        const int m = m0 + wr * 128 + i * 16 + (l & 15);
+        if (m >= p.M) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = v[r];
-                }
-            } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
-                if (full && ((p.ldc & 3) == 0)) {
-                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(c) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = f2bf(v[r]);
-                }
-            }
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wc * 64 + j * 16 + (l >> 4) * 4;
+            if (n >= p.N) continue;
+            epilogue_quad(p, flags, m, n, acc[i][j]);
         }
     }
 }
@@ -312,8 +443,22 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         MXL_CHECK_ARG(!(flags & (MXL_GEMM_RELU_BWD)));
     }
     p.bdiv = bdiv; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2;
-    dim3 grid(p.tiles_m * p.tiles_n, batch, ksplits), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (!transA && !transB && batch == 1 && ksplits == 1 && (K % 32) == 0 && M >= 256 && N >= 192 &&
+        !(flags & MXL_GEMM_OUT_F32_ATOMIC) && !getenv("MXL_GEMM_NO256")) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+        hipLaunchKernelGGL(gemm_nt256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, s, p);
+        MXL_LAUNCH_CHECK();
+        return MXL_OK;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, batch, ksplits), block(256);
 #define MXL_GEMM_LAUNCH(AT_, BT_)                                                                                          \
     do {                                                                                                                   \
         if (BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, 64>), grid, block, 2 * (TILE_BYTES + 64 * BK * 2), s, p); \

@@ -359,3 +359,36 @@ def test_gemm_skinny(dev, M, N, K):
     out32b = torch.empty_like(out32)
     ops.gemm_skinny(x.to(dev), w.to(dev), out32b, M, N, K, flags=ops.GEMM_OUT_F32)
     assert torch.equal(out32, out32b)     # deterministic reduction order
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K', [(256, 256, 32), (256, 192, 64), (512, 768, 96), (1000, 300, 160), (2048 + 17, 2304, 768),
+                                   (4096, 1190, 768)])
+def test_gemm_large_tile(dev, M, N, K):
+    """The 256x256x32 four-stage DMA kernel (NT form, M >= 256, N >= 192, K % 32 == 0): ragged edges, every epilogue, and
+    bit-identical repeats (a race in the LDS ring shows up as run-to-run differences)."""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(M + N + K)
+    x, w, b = bf(torch.randn(M, K) * 0.5), bf(torch.randn(N, K) * 0.5), torch.randn(N)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    ref = x.float() @ w.float().t()
+    c32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+    ops.gemm(xd, wd, c32, M, N, K, flags=ops.GEMM_OUT_F32)
+    assert rel_err(c32.cpu(), ref) < 1e-5
+    for _ in range(5):
+        again = torch.empty_like(c32)
+        ops.gemm(xd, wd, again, M, N, K, flags=ops.GEMM_OUT_F32)
+        assert torch.equal(again, c32)
+    y = ops.linear(xd, wd, bd, relu=True)
+    assert rel_err(y.cpu(), torch.relu(ref + b)) < 6e-3
+    y2 = ops.linear(xd, wd, bd, relu=True, drop_p=0.25, seed=5, site=3)
+    sel = (y2 != 0)
+    assert rel_err(y2[sel].cpu(), (y[sel].float() / 0.75).cpu()) < 8e-3
+    frac = 1 - ((y2 != 0) | (y == 0)).float().mean().item()
+    assert 0.09 < frac < 0.16
+    aux = bf(torch.randn(M, N)).to(dev)
+    z = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xd, wd, z, M, N, K, flags=ops.GEMM_RELU_BWD, aux=aux, alpha=0.5)
+    assert rel_err(z.cpu(), 0.5 * ref * (aux.float().cpu() > 0)) < 6e-3
+    ops.gemm(xd, wd, z, M, N, K, flags=ops.GEMM_ADD_AUX, aux=aux)
+    assert rel_err(z.cpu(), ref + aux.float().cpu()) < 6e-3
+
