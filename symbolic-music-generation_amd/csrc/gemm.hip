@@ -276,21 +276,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
 }
 
 // =====================================================================================================================
-// Large-tile kernel for the K-contiguous ("NT") form y = x W^T with M >= 256: the forward linears and, through the
-// transposed weight copies the engine keeps, the dX products.
+// Large-tile persistent kernel for the K-contiguous ("NT") form y = x W^T with M >= 256: the forward linears and, through
+// the transposed weight copies the engine keeps, the dX products.
 //
-//   tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 8 x 4 fragments: 12 KB of fragment reads per 32
-//   MFMAs (the 128^2 kernel above reads 16 KB per 32 and sits on the LDS-bandwidth roof).
+//   tile 256 x BN x 32 (BN = 256 or 192), 512 threads = 8 waves (2 x 4), wave tile 128 x BN/4 = 8 x NFN fragments: 12 (11)
+//   KB of fragment reads per 32 (24) MFMAs -- the 128^2 kernel above reads 16 KB per 32 and sits on the LDS-bandwidth roof.
 //   HBM/L2 -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write pass) into a FOUR-stage ring of 32 KB
 //   stages; the XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the LDS side of the DMA is
 //   lane-linear).  Loads run three K-steps ahead and stay in flight across the one raw s_barrier per K-step: counted
-//   s_waitcnt vmcnt(4), never 0 inside the loop.  Fragments are register double-buffered: the ds_reads of step t+1 are
-//   issued before the MFMAs of step t.
+//   s_waitcnt vmcnt(4), never 0 inside a tile.  Fragments are register double-buffered: the ds_reads of step g+1 are
+//   issued before the MFMAs of step g.
+//   One workgroup per CU walks tiles bid, bid + G, ...; the K-step sequence is flattened across tiles, so the first
+//   stages of the next tile are already in flight during a tile's epilogue.
+//   Measured (scripts/perf_gemm_table.py, perf_gemm_probe.py, C3 shapes, random operands): 600-880 TF/s at K = 768..3072,
+//   1.1 PF/s at K = 8192; the MFMA-only loop tops out at 1.42 PF/s and the DMA + fragment-read loop alone at 1.09 PF/s
+//   (L2 -> LDS traffic), so the remaining gap to hipBLASLt (0.8-1.2 / 1.55 PF/s) is the per-tile epilogue (all CUs store
+//   at once: ~10 us per round at the HBM write rate, not hidden) and operand traffic per flop.  A two-workgroup-per-CU
+//   256 x 128 variant and an LDS-transposed full-line epilogue were tried and measured no better.
 //
-//   step t:   glds(t+3) -> stage (t+3)&3     (last read by the fragment loads of step t-1, issued in step t-2)
-//             ds_read fragments(t+1)         (landed: waited at the end of step t-1, published by that barrier)
-//             32 MFMAs on fragments(t)
-//             s_waitcnt vmcnt(4)  [tile t+2 landed; tile t+3 may still fly]   lgkmcnt(0)   s_barrier
+//   step g:   glds(g+3) -> stage (g+3)&3     (last read by the fragment loads of step g-1, issued in step g-2)
+//             ds_read fragments(g+1)         (landed: waited at the end of step g-1, published by that barrier)
+//             32 MFMAs on fragments(g)
+//             s_waitcnt vmcnt(4)  [step g+2 landed; step g+3 may still fly]      s_barrier
+//   last step of a tile: vmcnt(0) instead (everything issued has landed), barrier, epilogue; the first step after an
+//   epilogue needs no vmcnt wait (its requirement was met by that drain) -- so the epilogue's stores, which share the
+//   counter, are not waited for until one step later.
 // =====================================================================================================================
 constexpr int G2_OP_BYTES = 256 * 32 * 2;      // one operand, one stage: [256 rows][32 k] bf16 = 16 KiB
 constexpr int G2_STAGE = 2 * G2_OP_BYTES;
@@ -299,103 +309,131 @@ constexpr int G2_SMEM = 4 * G2_STAGE;          // 128 KiB
 typedef __attribute__((address_space(1))) const void* g2_gptr;
 typedef __attribute__((address_space(3))) void* g2_lptr;
 
+template <int NFN>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
+    constexpr int BN = 64 * NFN;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
     int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    {   // XCD-aware remap of the launch slots: slots b, b+8, ... (one XCD) walk neighbouring tiles (same A row panels)
+        const int q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nk = p.K >> 5;
+    const int nk = p.K >> 5;                                  // even (host check)
+    const int my_tiles = (nwg - bid + G - 1) / G;
+    const int S = my_tiles * nk;                              // flattened K-steps of this workgroup
 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int wr = wid >> 2, wc = wid & 3;
 
-    // staging: DMA instruction i of wave w fills LDS rows (8i + w) * 16 .. +15 of the operand image (16 rows x 64 B,
-    // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ (l >> 4)
-    const bf16_t* ga[2];
-    const bf16_t* gb[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int row = (8 * i + wid) * 16 + (l >> 2);
+    // ---- issue side.  DMA instruction i of wave w fills LDS rows (8i + w) * 16 .. +15 of an operand image (16 rows x 64 B,
+    // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ (l >> 4).
+    // With BN = 192 the B image has 12 row groups: waves 4..7 issue three DMAs per step instead of four, and count their
+    // waits accordingly (`per_step`, wave-uniform).
+    unsigned ga[2], gb[2];          // element offsets of this lane's source rows (+ k-chunk): 32 bits (host check)
+    int gi = 0, i_t = 0, i_tile = bid;
+    auto set_ptrs = [&](int tile) {
+        const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
         const int kc = ((l & 3) ^ (l >> 4)) * 8;
-        ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kc;     // rows past the edge re-read the last row (never stored)
-        gb[i] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + kc;
-    }
-    auto issue = [&](int t) {
-        char* st = smem + (t & 3) * G2_STAGE;
-        const int k0 = t << 5;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((g2_gptr)(ga[i] + k0), (g2_lptr)(st + (8 * i + wid) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((g2_gptr)(gb[i] + k0), (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16, 0, 0);
+            const int row = (8 * i + wid) * 16 + (l >> 2);
+            ga[i] = (unsigned)min(tm * 256 + row, p.M - 1) * (unsigned)p.lda + kc;   // rows past the edge re-read the last row
+            gb[i] = (unsigned)min(tn * BN + row, p.N - 1) * (unsigned)p.ldb + kc;
         }
     };
-    // fragment addresses: row = base + (l & 15), k-group g = l >> 4 sits in slot g ^ ((row >> 2) & 3)
+    set_ptrs(i_tile);
+    auto issue_next = [&]() {
+        char* st = smem + (gi & 3) * G2_STAGE;
+        const int k0 = i_t << 5;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((g2_gptr)(p.A + (ga[i] + k0)), (g2_lptr)(st + (8 * i + wid) * 1024), 16, 0, 0);
+            if (NFN == 4 || i == 0 || wid < 4)
+                __builtin_amdgcn_global_load_lds((g2_gptr)(p.B + (gb[i] + k0)), (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16, 0, 0);
+        }
+        gi++;
+        if (++i_t == nk) {
+            i_t = 0;
+            i_tile += G;
+            if (i_tile < nwg) set_ptrs(i_tile);
+        }
+    };
+    // ---- fragment addresses: row = base + (l & 15), k-group g = l >> 4 sits in slot g ^ ((row >> 2) & 3)
     const int fsw = ((l >> 4) ^ ((l >> 2) & 3)) << 4;
     const int a_off = (wr * 128 + (l & 15)) * 64 + fsw;
-    const int b_off = G2_OP_BYTES + (wc * 64 + (l & 15)) * 64 + fsw;
-    auto frags = [&](int t, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) {
-        const char* st = smem + (t & 3) * G2_STAGE;
+    const int b_off = G2_OP_BYTES + (wc * (BN / 4) + (l & 15)) * 64 + fsw;
+    auto frags = [&](int g, bf16x8 (&fa)[8], bf16x8 (&fb)[NFN]) {
+        const char* st = smem + (g & 3) * G2_STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
+        for (int j = 0; j < NFN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
 #pragma unroll
         for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
     };
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // prologue: three tiles in flight, tiles 0 and 1 landed before the first barrier
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    f32x4 acc[8][NFN];
+    // prologue: three steps in flight, steps 0 and 1 landed before the first barrier
+    issue_next();
+    if (S > 1) issue_next();
+    if (S > 2) issue_next();
+    const bool three = (NFN == 3) && wid >= 4;          // this wave's DMAs per step: 3 instead of 4
+    if (S > 2) { if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    bf16x8 fa0[8], fb0[NFN], fa1[8], fb1[NFN];
     frags(0, fa0, fb0);
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): nothing outstanding at loop entry, so the loop body needs no wait before its MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): nothing outstanding at loop entry, the loop body needs no wait before its MFMAs
 
-    auto step = [&](int t, bf16x8 (&fa)[8], bf16x8 (&fb)[4], bf16x8 (&na)[8], bf16x8 (&nb)[4]) {
-        const bool more3 = t + 3 < nk;
-        if (more3) issue(t + 3);
-        if (t + 1 < nk) frags(t + 1, na, nb);
+    int g = 0;                              // flattened step being computed
+    auto step = [&](bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[8], bf16x8 (&fb)[NFN], bf16x8 (&na)[8],
+                    bf16x8 (&nb)[NFN]) {
+        const bool issued = gi < S;
+        if (issued) issue_next();
+        if (g + 1 < S) frags(g + 1, na, nb);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NFN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
                                                                     __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
-        if (more3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        // (the fragment reads of step g+1 need not finish before this barrier: their stage is not re-filled before the
+        // barrier of step g+1, and the MFMAs of step g+1 wait for them anyway)
+        if (last_of_tile || !issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!first_of_later_tile) {
+            if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
+        g++;
     };
-#pragma unroll 1
-    for (int t = 0; t < nk; t += 2) {
-        step(t, fa0, fb0, fa1, fb1);
-        if (t + 1 < nk) step(t + 1, fa1, fb1, fa0, fb0);
-    }
 
-    // epilogue.  acc[i][j][r]: m = m0 + wr*128 + i*16 + (l&15), n = n0 + wc*64 + j*16 + (l>>4)*4 + r
     const int flags = p.flags;
+#pragma unroll 1
+    for (int tile = bid; tile < nwg; tile += G) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int m = m0 + wr * 128 + i * 16 + (l & 15);
-        if (m >= p.M) continue;
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = n0 + wc * 64 + j * 16 + (l >> 4) * 4;
-            if (n >= p.N) continue;
-            epilogue_quad(p, flags, m, n, acc[i][j]);
+            for (int j = 0; j < NFN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 2) {
+            step(t == 0 && tile != bid, false, fa0, fb0, fa1, fb1);
+            step(false, t + 2 >= nk, fa1, fb1, fa0, fb0);
+        }
+        // epilogue.  acc[i][j][r]: m = m0 + wr*128 + i*16 + (l&15), n = n0 + wc*(BN/4) + j*16 + (l>>4)*4 + r
+        const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = m0 + wr * 128 + i * 16 + (l & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NFN; j++) {
+                const int n = n0 + wc * (BN / 4) + j * 16 + (l >> 4) * 4;
+                if (n >= p.N) continue;
+                epilogue_quad(p, flags, m, n, acc[i][j]);
+            }
         }
     }
 }
@@ -444,17 +482,33 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     }
     p.bdiv = bdiv; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2;
     hipStream_t s = (hipStream_t)stream;
-    if (!transA && !transB && batch == 1 && ksplits == 1 && (K % 32) == 0 && M >= 256 && N >= 192 &&
+    if (!transA && !transB && batch == 1 && ksplits == 1 && (K % 64) == 0 && M >= 256 && N >= 192 &&
+        (long long)M * lda < (1ll << 31) && (long long)N * ldb < (1ll << 31) &&
         !(flags & MXL_GEMM_OUT_F32_ATOMIC) && !getenv("MXL_GEMM_NO256")) {
         static bool attr_set = false;
+        static int n_cu = 256;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+            if (e != hipSuccess) return (int)e;
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
             attr_set = true;
         }
-        p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-        hipLaunchKernelGGL(gemm_nt256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, s, p);
+        // BN = 256 or 192: whichever wastes less of the chip (rounds of one tile per CU x tile width)
+        const int tm = (M + 255) / 256;
+        const int t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+        const long long c256 = (long long)((t256 + n_cu - 1) / n_cu) * 256, c192 = (long long)((t192 + n_cu - 1) / n_cu) * 192;
+        const bool use192 = c192 < c256;
+        p.tiles_m = tm; p.tiles_n = use192 ? (N + 191) / 192 : (N + 255) / 256;
+        const int ntile = p.tiles_m * p.tiles_n;
+        dim3 grid(ntile < n_cu ? ntile : n_cu);
+        if (use192) hipLaunchKernelGGL(gemm_nt256_kernel<3>, grid, dim3(512), G2_SMEM, s, p);
+        else hipLaunchKernelGGL(gemm_nt256_kernel<4>, grid, dim3(512), G2_SMEM, s, p);
         MXL_LAUNCH_CHECK();
         return MXL_OK;
     }
