@@ -303,6 +303,22 @@ __global__ void dropout_kernel(const bf16_t* x, bf16_t* y, long long n8, unsigne
     }
 }
 
+// dst[b][c][r] = src[b][r][c]: 64 x 64 bf16 tiles through LDS (row pitch 65 keeps both phases conflict-free).  Used to keep
+// [in][out] copies of the linear weights beside the [out][in] ones, so that dX = dY W runs in the K-contiguous GEMM form.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* src, bf16_t* dst, int rows, int cols, int ld_src,
+                                                             int ld_dst, long long sb, long long db) {
+    __shared__ bf16_t t[64][65];
+    src += (size_t)blockIdx.z * sb;
+    dst += (size_t)blockIdx.z * db;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = src[(size_t)(r0 + i) * ld_src + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * ld_dst + r0 + tx] = t[tx][i];
+}
+
 }  // namespace
 
 extern "C" int mxl_dropout_bf16(const void* x, void* y, long long n, float drop_p, unsigned long long seed, unsigned site,
@@ -406,6 +422,15 @@ extern "C" int mxl_mem_update(const void* mem, const void* hid, void* out, int B
     const long long n = (long long)B * M * (d / 8);
     hipLaunchKernelGGL(mem_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)mem, (const bf16_t*)hid, (bf16_t*)out, B, M, T, d);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, int batch,
+                                  long long src_bstride, long long dst_bstride, void* stream) {
+    MXL_CHECK_ARG(src && dst && src != dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows && batch >= 1);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, ld_dst, src_bstride, dst_bstride);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

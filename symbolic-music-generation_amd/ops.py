@@ -198,6 +198,16 @@ def cast_bf16(x: torch.Tensor, y: torch.Tensor):
     return y
 
 
+def transpose(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, *, ld_src=None, ld_dst=None, batch=1,
+              src_bstride=0, dst_bstride=0):
+    """dst[b][c][r] = src[b][r][c] (bf16)"""
+    _req(src, torch.bfloat16, 'src'); _req(dst, torch.bfloat16, 'dst')
+    check(lib().mxl_transpose_bf16(_p(src), _p(dst), rows, cols, ld_src if ld_src is not None else cols,
+                                   ld_dst if ld_dst is not None else rows, batch, src_bstride, dst_bstride, _stream()),
+          'mxl_transpose_bf16')
+    return dst
+
+
 def gemm_batched(a, b, c, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=False, flags=0, alpha=1.0, ksplits=1,
                  batch=1, bdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
     check(lib().mxl_gemm_bf16_batched(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,

@@ -97,6 +97,7 @@ class XLEngine:
         self.G: Optional[torch.Tensor] = None                              # grads (allocated on first train step)
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
+        self.WT: Optional[Dict[str, torch.Tensor]] = None                  # [in][out] weight copies (training only)
         self.step_count = 0
         self.base_seed = seed
         self._ws: Dict[Tuple, _WS] = {}
@@ -138,6 +139,30 @@ class XLEngine:
 
     def sync_weights(self):
         ops.cast_bf16(self.P, self.W)
+        self._refresh_wt()
+
+    # [in][out] copies of the layer Linear weights: dX = dY W then runs in the K-contiguous GEMM form (the DMA-fed large-tile
+    # kernel) instead of reading W through transposed LDS fragments.  (L, in, out) per weight kind, refreshed by four batched
+    # transposes whenever W changes; 2 x 14 MB per layer at C3.
+    _WT_KINDS = ('dec_attn.qkv_net.weight', 'dec_attn.o_net.weight', 'pos_ff.CoreNet.0.weight', 'pos_ff.CoreNet.3.weight')
+
+    def _refresh_wt(self, allocate: bool = False):
+        if self.WT is None and not allocate:
+            return
+        L = self.cfg.n_layer
+        if self.WT is None:
+            self.WT = {}
+            for kind in self._WT_KINDS:
+                o, i = self.layout.entries[f'transformer.layers.0.{kind}'][1]
+                self.WT[kind] = torch.empty(L, i, o, device=self.dev, dtype=torch.bfloat16)
+        for kind in self._WT_KINDS:
+            off0, (o, i) = self.layout.entries[f'transformer.layers.0.{kind}']
+            stride = (self.layout.entries[f'transformer.layers.1.{kind}'][0] - off0) if L > 1 else 0
+            assert all(self.layout.entries[f'transformer.layers.{l}.{kind}'][0] == off0 + l * stride for l in range(L))
+            ops.transpose(self.W[off0:], self.WT[kind], o, i, batch=L, src_bstride=stride, dst_bstride=i * o)
+
+    def _lwt(self, l, kind):
+        return self.WT[kind][l]
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         sd = OrderedDict()
@@ -327,6 +352,8 @@ class XLEngine:
         B, T, Kc, p, seed = ws.B, ws.T, ws.Kc, ws.p, ws.seed
         d, H, dh, L, M, Fi = c.d_model, c.n_head, c.d_head, c.n_layer, c.mem_len, c.d_inner
         V, cut = c.vocab_size, tuple(c.cutoffs)
+        if self.WT is None:
+            self._refresh_wt(allocate=True)
         N = B * T
         G = self.G
         nrow, nrow_p = self.layout.n_head_rows, self.layout.head_rows_padded
@@ -360,13 +387,13 @@ class XLEngine:
             ops.colsum(ws.dD, gw(l, 'pos_ff.CoreNet.3.bias'), N, d)
             ops.gemm(ws.dD, ws.a[l], gw(l, 'pos_ff.CoreNet.3.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi))
-            ops.gemm(ws.dD, self._lw(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, trans_b=True, flags=F.GEMM_RELU_BWD,
+            ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
                      aux=ws.a[l], alpha=dscale)
             # FFN1
             ops.colsum(ws.dF, gw(l, 'pos_ff.CoreNet.0.bias'), N, Fi)
             ops.gemm(ws.dF, ws.h1[l], gw(l, 'pos_ff.CoreNet.0.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d))
-            ops.gemm(ws.dF, self._lw(l, 'pos_ff.CoreNet.0.weight'), ws.dD, N, d, Fi, trans_b=True)
+            ops.gemm(ws.dF, self._lwt(l, 'pos_ff.CoreNet.0.weight'), ws.dD, N, d, Fi)
             # LN1 backward with both streams into h1: dC (residual) + dD (FFN1 dX)
             ops.ln_residual_bwd(ws.dC, ws.dD, ws.z1[l], ws.st1[l][0], ws.st1[l][1],
                                 self._lw(l, 'dec_attn.layer_norm.weight', self.P), ws.dA, ws.dB,
@@ -375,7 +402,7 @@ class XLEngine:
             # now dA = grad into h_in via residual, dB = grad into o_net output
             ops.gemm(ws.dB, ws.av[l], gw(l, 'dec_attn.o_net.weight'), d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, d))
-            ops.gemm(ws.dB, self._lw(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d, trans_b=True)   # d attn_vec
+            ops.gemm(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d)   # d attn_vec
             qkv, dqkv = ws.qkv[l], ws.dqkv
             ws.d_rd.zero_()
             ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
@@ -400,7 +427,7 @@ class XLEngine:
                 ops.gemm_batched(dqkv[:, M:], self._lw(l, 'dec_attn.qkv_net.weight'), ws.dB, T, d, 3 * d, lda=3 * d,
                                  ldb=d, ldc=d, trans_b=True, batch=B, bdiv=1, sA=(Kc * 3 * d, 0), sB=(0, 0), sC=(T * d, 0))
             else:
-                ops.gemm(dqkv.view(N, 3 * d), self._lw(l, 'dec_attn.qkv_net.weight'), ws.dB, N, d, 3 * d, trans_b=True)
+                ops.gemm(dqkv.view(N, 3 * d), self._lwt(l, 'dec_attn.qkv_net.weight'), ws.dB, N, d, 3 * d)
             dy, dy2 = ws.dA, ws.dB
             if layer_done is not None:
                 layer_done(l)
@@ -420,6 +447,7 @@ class XLEngine:
         ops.adamw_step(self.P, self.G, self.m, self.v, self.W, self.layout.n_decay, lr, betas[0], betas[1], eps,
                        weight_decay, self.step_count, self._sumsq if max_grad_norm else None, max_grad_norm or 0.0,
                        grad_scale)
+        self._refresh_wt()
 
     def grad_norm(self) -> torch.Tensor:
         return self._sumsq.sqrt()
