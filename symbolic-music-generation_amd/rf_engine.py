@@ -106,6 +106,7 @@ class RFEngine:
         self.P = torch.zeros(n, device=self.dev, dtype=torch.float32)
         self.W = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)
         self.G = self.m = self.v = None
+        self.WT = None                      # [in][out] weight copies for the dX GEMMs (training only; see XLEngine)
         self.step_count, self.base_seed = 0, seed
         self._ws: Dict = {}
         self._sumsq = torch.zeros(1, device=self.dev)
@@ -154,6 +155,25 @@ class RFEngine:
 
     def sync_weights(self):
         ops.cast_bf16(self.P, self.W)
+        self._refresh_wt()
+
+    def _wt_sources(self, l):
+        kind = self.cfg.attn_layers[l]
+        return {'proj': self._proj_w(l, kind), 'o': self._l(l, 'attention.output.dense.weight'),
+                'ff1': self._l(l, 'feed_forward.dense.dense.weight'), 'ff2': self._l(l, 'feed_forward.output.dense.weight')}
+
+    def _refresh_wt(self, allocate: bool = False):
+        if self.WT is None and not allocate:
+            return
+        first = self.WT is None
+        if first:
+            self.WT = {}
+        for l in range(len(self.cfg.attn_layers)):
+            for key, w in self._wt_sources(l).items():
+                o, i = w.shape
+                if first:
+                    self.WT[(l, key)] = torch.empty(i, o, device=self.dev, dtype=torch.bfloat16)
+                ops.transpose(w, self.WT[(l, key)], o, i)
 
     def state_dict(self):
         return OrderedDict((n, self.p32(n).detach().cpu().clone()) for n in self.layout.real_names())
@@ -349,6 +369,8 @@ class RFEngine:
         d, Fi, H, dh, n_h = c.hidden_size, c.feed_forward_size, c.num_attention_heads, c.attention_head_size, c.num_hashes
         L, V = len(c.attn_layers), c.vocab_size
         N = B * T
+        if self.WT is None:
+            self._refresh_wt(allocate=True)
         G, AT = self.G, F.GEMM_OUT_F32_ATOMIC
         dscale = 1.0 / (1.0 - p) if p > 0 else 1.0
         gl = lambda l, sfx: self._l(l, sfx, G)
@@ -379,12 +401,12 @@ class RFEngine:
             ops.colsum(dff, gl(l, 'feed_forward.output.dense.bias'), N, d)
             ops.gemm(dff, ws.a[l], gl(l, 'feed_forward.output.dense.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi))
-            ops.gemm(dff, self._l(l, 'feed_forward.output.dense.weight'), ws.dF, N, Fi, d, trans_b=True, flags=F.GEMM_RELU_BWD,
+            ops.gemm(dff, self.WT[(l, 'ff2')], ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
                      aux=ws.a[l], alpha=dscale)
             ops.colsum(ws.dF, gl(l, 'feed_forward.dense.dense.bias'), N, Fi)
             ops.gemm(ws.dF, ws.h2[l], gl(l, 'feed_forward.dense.dense.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d))
-            ops.gemm(ws.dF, self._l(l, 'feed_forward.dense.dense.weight'), t2, N, d, Fi, trans_b=True)
+            ops.gemm(ws.dF, self.WT[(l, 'ff1')], t2, N, d, Fi)
             # g1 <- g1 + LN2-backward(t2)            (y1 feeds the FF branch and the y1 output)
             ops.ln_bwd_add(t2, None, y1, ws.st2[l][0], ws.st2[l][1], self._l(l, 'feed_forward.layer_norm.weight', self.P), g1, t1,
                            gl(l, 'feed_forward.layer_norm.weight'), gl(l, 'feed_forward.layer_norm.bias'))
@@ -398,7 +420,7 @@ class RFEngine:
             ops.gemm(dao, ws.av[l], gl(l, 'attention.output.dense.weight'), d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, d))
             dav = ws.dF.view(-1)[:N * d].view(N, d)          # scratch
-            ops.gemm(dao, self._l(l, 'attention.output.dense.weight'), dav, N, d, d, trans_b=True)
+            ops.gemm(dao, self.WT[(l, 'o')], dav, N, d, d)
             nproj = 3 if kind == 'local' else 2
             qkv = ws.qkv[l].view(-1)[:N * nproj * d].view(N, nproj * d)
             dqkv = ws.dqkv.view(-1)[:N * nproj * d].view(N, nproj * d)
@@ -422,7 +444,7 @@ class RFEngine:
             ops.gemm(dqkv, ws.hn[l], self._proj_w(l, kind, G), nproj * d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(nproj * d, d))
             dhn = ws.dF.view(-1)[:N * d].view(N, d)
-            ops.gemm(dqkv, self._proj_w(l, kind), dhn, N, d, nproj * d, trans_b=True)
+            ops.gemm(dqkv, self.WT[(l, 'proj')], dhn, N, d, nproj * d)
             # g2 <- g2 + LN1-backward(dhn)
             ops.ln_bwd_add(dhn, None, x2, ws.st1[l][0], ws.st1[l][1], self._l(l, 'attention.layer_norm.weight', self.P), g2, t2,
                            gl(l, 'attention.layer_norm.weight'), gl(l, 'attention.layer_norm.bias'))
@@ -446,6 +468,7 @@ class RFEngine:
             ops.sumsq(self.G, self._sumsq)
         ops.adamw_step(self.P, self.G, self.m, self.v, self.W, self.layout.n_decay, lr, betas[0], betas[1], eps, weight_decay,
                        self.step_count, self._sumsq if max_grad_norm else None, max_grad_norm or 0.0, grad_scale)
+        self._refresh_wt()
 
     def grad_norm(self):
         return self._sumsq.sqrt()
