@@ -381,21 +381,6 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             const int dlo = iw0 - P - 64;
             const char* cK = sK + cur * G::K_BYTES;
             const char* cV = sV + cur * G::K_BYTES;
-            f32x16 s[2], dp[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                s[kb] = c_lse;
-                dp[kb] = c_dlt;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                                    __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(cV + G::koff(32 * kb + r, 2 * ks + hh));
-                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
-                                                                     __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp[kb], 0, 0, 0);
-                }
-            }
             auto gblock = [&](int gb, f16x4 (&dst)[4]) {
                 f32x16 g;
 #pragma unroll
@@ -432,39 +417,45 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 carry[grp] = b0[grp];
             }
             have_ring = true;
-            // P, dSr (lane = query); write dSr into the un-skew ring at column (i - p) & 127.  Scalar branch on the
-            // (readfirstlane) full-tile flag, otherwise hipcc if-converts the mask onto every tile.
+            // The two 32-key blocks run one after the other (S/dP chains, skew read, P and dSr, skew write, dQw products) with a
+            // scheduling fence between them: at most one block's scores are live, which keeps the kernel's working set in the
+            // architectural VGPRs (the accumulators sit in AGPRs) instead of shuttling values through v_accvgpr moves.
             const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
-            uint32_t dsw[2][8];       // dSr as bf16 pairs (2m, 2m+1): MFMA operand and skew-write source
-            auto grads = [&](auto masked) {
-                constexpr bool MASKED = decltype(masked)::value;
-#pragma unroll
-                for (int kb = 0; kb < 2; kb++) {
-                    uint32_t bdu[16];
-                    skew_read16(gRb - 64 * kb, bdu);
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        float pv = __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[j]));
-                        if (MASKED) {
-                            const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
-                            const bool valid = (d >= 0) && (d <= M - 1) && qok;
-                            pv = valid ? pv : 0.f;
-                        }
-                        s[kb][j] = pv * dp[kb][j];
-                    }
-#pragma unroll
-                    for (int m = 0; m < 8; m++) dsw[kb][m] = pack2bf(s[kb][2 * m], s[kb][2 * m + 1]);
-                    skew_write16p(dgWb - 64 * kb, dsw[kb]);
-                }
-            };
-            if (full) grads(std::false_type{}); else grads(std::true_type{});
-            // dQw^T += K^T . dSr^T   (A = K^T through transposed reads of the K image, accumulator-permuted k order)
             const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
+                f32x16 s = c_lse, dp = c_dlt;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, qw[ks]), s, 0, 0, 0);
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(cV + G::koff(32 * kb + r, 2 * ks + hh));
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
+                                                                 __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp, 0, 0, 0);
+                }
+                uint32_t bdu[16];
+                skew_read16(gRb - 64 * kb, bdu);
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) s[j] = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j])) * dp[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
+                        const bool valid = (d >= 0) && (d <= M - 1) && qok;
+                        const float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
+                        s[j] = valid ? pv * dp[j] : 0.f;
+                    }
+                }
+                uint32_t dsw[8];          // dSr as bf16 pairs (2m, 2m+1): MFMA operand and skew-write source
+#pragma unroll
+                for (int m = 0; m < 8; m++) dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]);
+                skew_write16p(dgWb - 64 * kb, dsw);
+                // dQw^T += K^T . dSr^T   (A = K^T through transposed reads of the K image, accumulator-permuted k order)
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
-                    const u32x4 pw = {dsw[kb][4 * st], dsw[kb][4 * st + 1], dsw[kb][4 * st + 2], dsw[kb][4 * st + 3]};
+                    const u32x4 pw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
                     for (int e = 0; e < EB; e++) {
@@ -480,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                                                                         __builtin_bit_cast(mfma_bf16x8, pf), aw[e], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // completed distance blocks 1 and 2 of the window: d in [dlo+32, dlo+95]
 #pragma unroll
