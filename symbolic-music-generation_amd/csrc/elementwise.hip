@@ -72,6 +72,7 @@ __global__ void embed_bwd_kernel(const long long* ids, const bf16_t* dout, const
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> d <= 64*8*4 = 2048
 
+template <int NCH>   // 8-element chunks per lane: 1 (d <= 512), 2 (d <= 1024) or NCH -- sizes the register arrays
 __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const bf16_t* res, const float* gamma,
                                                          const float* beta, bf16_t* y, bf16_t* z, float* mean,
                                                          float* rstd, int N, int d, float eps, unsigned thresh,
@@ -80,10 +81,10 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
     const int chunks = d >> 3;
-    float v[LN_MAXCH][8];
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int c = lane + i * 64;
         if (c < chunks) {
             const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * d + c * 8);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
     const float mu = s / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int c = lane + i * 64;
         if (c < chunks) {
 #pragma unroll
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
     const float rs = rsqrtf(q / (float)d + eps);
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int c = lane + i * 64;
         if (c < chunks) {
             float o[8];
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
 
 // backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dres = dz (+ dres_in);  dx = keep*dscale*dz
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy : per-block partials through LDS, then one fp32 atomic per column.
-constexpr int LNB_ROWS = 32;  // rows per block (4 waves x 8 rows)
+constexpr int LNB_ROWS = 64;  // rows per block (4 waves x 16 rows): 2d atomics per block
 
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, int N,
@@ -149,19 +151,19 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
     __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunks = d >> 3;
-    float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+    float ag[NCH][8], ab[NCH][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++)
+    for (int i = 0; i < NCH; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
     for (int rr = 0; rr < LNB_ROWS / 4; rr++) {
         const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
         if (row >= N) break;
         const float mu = mean[row], rs = rstd[row];
-        float g[LN_MAXCH][8], xh[LN_MAXCH][8];
+        float g[NCH][8], xh[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; i++) {
+        for (int i = 0; i < NCH; i++) {
             const int c = lane + i * 64;
             if (c < chunks) {
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * d + c * 8);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
         s1 = wave_sum(s1) / (float)d;
         s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; i++) {
+        for (int i = 0; i < NCH; i++) {
             const int c = lane + i * 64;
             if (c < chunks) {
                 float o[8], ox[8];
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
         }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int c = lane + i * 64;
         if (c < chunks) {
 #pragma unroll
@@ -378,7 +380,8 @@ extern "C" int mxl_ln_residual_fwd(const void* x, const void* res, const float* 
                                    void* z, float* mean, float* rstd, int N, int d, float eps, float drop_p,
                                    unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(x && gamma && beta && y && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
-    hipLaunchKernelGGL(ln_res_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    const auto kfn = d <= 512 ? ln_res_fwd_kernel<1> : d <= 1024 ? ln_res_fwd_kernel<2> : ln_res_fwd_kernel<LN_MAXCH>;
+    hipLaunchKernelGGL(kfn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (const bf16_t*)res, gamma, beta, (bf16_t*)y, (bf16_t*)z, mean, rstd, N, d, eps,
                        dropout_thresh(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site);
     MXL_LAUNCH_CHECK();
@@ -389,7 +392,8 @@ extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* 
                                    const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
                                    float drop_p, unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
-    hipLaunchKernelGGL(ln_res_bwd_kernel, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+    const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr);
@@ -401,7 +405,8 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
                                        const float* gamma, const void* dadd, void* dres, float* dgamma, float* dbeta, int N,
                                        int d, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dres && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
-    hipLaunchKernelGGL(ln_res_bwd_kernel, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+    const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
     MXL_LAUNCH_CHECK();
