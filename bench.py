@@ -105,12 +105,8 @@ def main():
             e.record()
             timed['ev'].append((s, e))
             if d_rd is not None:       # the dRd contraction, outside the bracket
-                H_, dh_, T_, M_, B_ = k['H'], k['dh'], k['T'], k['M'], k['B']
-                d_ = H_ * dh_
-                ops.add_rowbias(a[0], k['q_bs'], k['q_rs'], a[5].reshape(-1), qr, B_, T_, d_)
-                ops.gemm_batched(a[13], qr, d_rd, M_, dh_, T_, lda=M_, ldb=d_, ldc=d_, trans_a=True, trans_b=True,
-                                 flags=ops.GEMM_OUT_F32_ATOMIC, batch=B_ * H_, bdiv=H_, sA=(H_ * T_ * M_, T_ * M_),
-                                 sB=(T_ * d_, dh_), sC=(0, dh_))
+                ops.relattn_drd(a[0], a[5], a[13], d_rd, qr, B=k['B'], T=k['T'], H=k['H'], dh=k['dh'], M=k['M'],
+                                q_bs=k['q_bs'], q_rs=k['q_rs'])
         else:
             orig_bwd(*a, **k)
 

@@ -84,6 +84,12 @@ int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd,
                     long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                     float scale, void* stream);
 
+/* The contraction the caller owes after mxl_relattn_bwd, as one HBM-streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0;
+ * MXL_EUNSUPPORTED otherwise -- use mxl_gemm_bf16_batched):
+ *   d_rd[delta, h*dh + e] += sum_{b,i} dg[b,h,i,delta] * qr[b,i,h,e]      qr = (q + r_r_bias) in bf16, strides (qr_bs, qr_rs) */
+int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs,
+                    int qr_rs, int drd_ld, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.
  * ---------------------------------------------------------------------------------------------------------- */

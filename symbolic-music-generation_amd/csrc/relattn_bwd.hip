@@ -841,6 +841,122 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// d Rd[delta, h, :] += sum_{b,i} dG[b,h,i,delta] * Qr[b,i,h,:]       (Qr = q + r_r_bias, bf16)
+// An HBM-streaming contraction: 1.6 GB of dG per layer at C3 against 0.1 GFLOP per MB, so the kernel is a DMA ring with a
+// few MFMAs attached.  Workgroup = (256 distances, head, batch group): the wide distance tile keeps the re-reads of Qr (once
+// per distance tile) at a quarter of the dG bytes.  Per step one [32 i][256 delta] tile of dG and one [32 i][64 e] tile of
+// Qr (both contracted over their ROW index) go HBM -> LDS by global_load_lds into a four-stage ring (three steps in flight
+// across one raw barrier per step, counted vmcnt); fragments by transposed LDS reads (32-byte blocks XOR-swizzled on the
+// source side of the DMA).  80 KB LDS: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------
+struct DrdP {
+    const bf16_t* dg; const bf16_t* qr; float* drd;
+    int B, T, H, M, bgroup;            // bgroup = batches per workgroup
+    long long qr_bs; int qr_rs, drd_ld;
+};
+constexpr int DRD_A = 32 * 512;        // dG tile  [32 i][256 delta] bf16
+constexpr int DRD_B = 32 * 128;        // Qr tile  [32 i][64 e] bf16
+constexpr int DRD_STAGE = DRD_A + DRD_B;
+constexpr int DRD_SMEM = 4 * DRD_STAGE;                 // 80 KB: two workgroups per CU
+__device__ __forceinline__ int drd_swzA(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)); }
+
+__global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int d0 = blockIdx.x * 256, h = blockIdx.y, b0 = blockIdx.z * p.bgroup;
+    const int nb = min(p.bgroup, p.B - b0);
+    const int spb = p.T >> 5;                       // 32-row steps per batch item
+    const int S = nb * spb;
+
+    // dG tile: DMA instruction j (0..3) of wave w fills rows 2(4j + w), +1 (512-byte rows): lane -> row l >> 5, 16-byte slot
+    // l & 31; slot s of row k holds source block ((s >> 1) ^ drd_swzA(k)), half s & 1.  Qr tile: one instruction per wave, rows
+    // 8w .. 8w+7 (128-byte rows): lane -> row l >> 3, slot l & 7, block ((s >> 1) ^ (k & 3)).
+    int arow[4], acol[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        arow[j] = 2 * (4 * j + wid) + (l >> 5);
+        acol[j] = min(d0 + ((((l & 31) >> 1) ^ drd_swzA(arow[j])) << 4) + ((l & 1) << 3), p.M - 8);
+    }
+    const int brow = 8 * wid + (l >> 3);
+    const int bcol = ((((l & 7) >> 1) ^ (brow & 3)) << 4) + ((l & 1) << 3);
+    auto issue = [&](int g) {
+        char* st = smem + (g & 3) * DRD_STAGE;
+        const int b = b0 + g / spb, i0 = (g % spb) << 5;
+        const bf16_t* a = p.dg + (((size_t)b * p.H + h) * p.T + i0) * (size_t)p.M;
+        const bf16_t* q = p.qr + (size_t)b * p.qr_bs + (size_t)i0 * p.qr_rs + (size_t)h * 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a + (size_t)arow[j] * p.M + acol[j]), (lptr_t)(st + (4 * j + wid) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(q + (size_t)brow * p.qr_rs + bcol), (lptr_t)(st + DRD_A + wid * 1024), 16, 0, 0);
+    };
+    // transposed fragments for v_mfma_f32_16x16x32_bf16 (one K-step = 32 rows): lane (g = l >> 4, q = (l & 15) >> 2, pp = l & 3)
+    // addresses k-row 8g + q, columns rb + 4pp..+3; rows +0 / +4 give the lane its 8 k-values of output row rb + (l & 15)
+    const int fk = 8 * (l >> 4) + ((l & 15) >> 2);
+    int ao[4], bo[4];                                // wave tile: distances 64 wid .. +63 (4 fragments) x all 64 e (4 fragments)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int ca = 64 * wid + 16 * t + 4 * (l & 3), cb = 16 * t + 4 * (l & 3);
+        ao[t] = fk * 512 + (((ca >> 4) ^ drd_swzA(fk)) << 5) + ((ca & 15) << 1);
+        bo[t] = DRD_A + fk * 128 + (((cb >> 4) ^ (fk & 3)) << 5) + ((cb & 15) << 1);
+    }
+    auto trfrag = [&](const char* a, int pitch4) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a + pitch4));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (S > 1) issue(1);
+    if (S > 2) issue(2);
+    if (S > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int g = 0; g < S; g++) {
+        // stage (g + 3) & 3 == (g - 1) & 3 was read in step g - 1, before that step's barrier
+        const bool issued = g + 3 < S;
+        if (issued) issue(g + 3);
+        const char* st = smem + (g & 3) * DRD_STAGE;
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { fa[t] = trfrag(st + ao[t], 4 * 512); fb[t] = trfrag(st + bo[t], 4 * 128); }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        // step g + 1 must have landed before the next iteration reads it: leave the two youngest steps in flight
+        if (issued) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (g + 2 < S) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // acc[i][j][r]: distance d0 + 64 wid + 16i + (l & 15), e = 16j + 4*(l >> 4) + r   (MFMA issued (B, A))
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dd = d0 + 64 * wid + 16 * i + (l & 15);
+        if (dd >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float* o = p.drd + (size_t)dd * p.drd_ld + h * 64 + 16 * j + 4 * (l >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(o + r, acc[i][j][r]);
+        }
+    }
+}
+
 template <int DH>
 int launch_bwd(const BwdP& p, hipStream_t s) {
     static bool attr_set = false;
@@ -890,4 +1006,31 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
         case 64: return launch_bwd<64>(p, s);
         default: return MXL_EUNSUPPORTED;
     }
+}
+
+extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
+                               long long qr_bs, int qr_rs, int drd_ld, void* stream) {
+    MXL_CHECK_ARG(dg && qr && d_rd && B > 0 && T > 0 && H > 0 && M > 0);
+    if (dh != 64 || (T % 32) != 0 || (M % 8) != 0 || M < 8) return MXL_EUNSUPPORTED;
+    MXL_CHECK_ARG((qr_rs % 8) == 0 && (qr_bs % 8) == 0 && drd_ld >= H * dh && ((uintptr_t)dg % 16) == 0 && ((uintptr_t)qr % 16) == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_drd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DRD_SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    DrdP p;
+    p.dg = (const bf16_t*)dg; p.qr = (const bf16_t*)qr; p.drd = d_rd;
+    p.B = B; p.T = T; p.H = H; p.M = M; p.qr_bs = qr_bs; p.qr_rs = qr_rs; p.drd_ld = drd_ld;
+    // batch groups: fill the 512 resident workgroup slots about once (each workgroup ends with 64 KB of fp32 atomics)
+    const int tiles = ((M + 255) / 256) * H;
+    int groups = 512 / tiles;
+    if (groups < 1) groups = 1;
+    if (groups > B) groups = B;
+    p.bgroup = (B + groups - 1) / groups;
+    groups = (B + p.bgroup - 1) / p.bgroup;
+    hipLaunchKernelGGL(relattn_drd_kernel, dim3((M + 255) / 256, H, groups), dim3(256), DRD_SMEM, (hipStream_t)stream, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
 }

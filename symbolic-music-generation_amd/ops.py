@@ -232,11 +232,19 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
                                 q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale),
                                 _stream()), 'mxl_relattn_bwd')
     if d_rd is not None:
-        d = H * dh
-        add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
-        # per (b, h): d_rd[:, h*dh:(h+1)*dh] (M x dh) += dG[b,h]^T (M x T) @ qr[b,:,h,:] (T x dh)
+        relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, B=B, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs)
+
+
+def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs):
+    """d_rd[delta, h*dh:(h+1)*dh] (M x dh, fp32, +=) = sum_b dG[b,h]^T (M x T) @ (q + r_r_bias)[b,:,h,:] (T x dh)"""
+    d = H * dh
+    add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
+    rc = lib().mxl_relattn_drd(_p(dg), _p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d, _stream())
+    if rc == -2:      # MXL_EUNSUPPORTED shape: the batched GEMM form
         gemm_batched(dg, qr_buf, d_rd, M, dh, T, lda=M, ldb=d, ldc=d, trans_a=True, trans_b=True,
                      flags=GEMM_OUT_F32_ATOMIC, batch=B * H, bdiv=H, sA=(H * T * M, T * M), sB=(T * d, dh), sC=(0, dh))
+    else:
+        check(rc, 'mxl_relattn_drd')
 
 
 # ------------------------------------------------------------------ decode

@@ -403,3 +403,23 @@ def test_transpose_batched(dev):
     dst = torch.zeros(L, C, R, device=dev, dtype=torch.bfloat16)
     ops.transpose(src, dst, R, C, batch=L, src_bstride=(R + 5) * C, dst_bstride=C * R)
     assert torch.equal(dst.cpu(), src[:, :R].transpose(1, 2).contiguous().cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,H,M', [(5, 128, 3, 192), (3, 256, 2, 64), (16, 512, 12, 512)])
+def test_relattn_drd_streaming(dev, B, T, H, M):
+    """d Rd contraction kernel (dh = 64): d_rd[delta, h, :] += sum_{b,i} dG[b,h,i,delta] * qr[b,i,h,:], on top of existing
+    contents; compared with an fp32 einsum of the same bf16 operands."""
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd._lib import lib
+    torch.manual_seed(B + T + M)
+    dh = 64
+    d = H * dh
+    dg = bf(torch.randn(B, H, T, M) * 0.3).to(dev)
+    qr = bf(torch.randn(B, T, d)).to(dev)
+    out = torch.ones(M, d, device=dev, dtype=torch.float32)
+    rc = lib().mxl_relattn_drd(dg.data_ptr(), qr.data_ptr(), out.data_ptr(), B, T, H, dh, M, T * d, d, d,
+                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = 1 + torch.einsum('bhim,bihe->mhe', dg.float().cpu(), qr.float().cpu().view(B, T, H, dh)).reshape(M, d)
+    assert rel_err(out.cpu(), ref) < 2e-5
