@@ -63,9 +63,12 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('MXL_DIST_FORCE') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', device_id=dev)
     else:
         dist = None

@@ -7,14 +7,18 @@ Buckets are the engine's natural contiguous slices of the flat fp32 gradient buf
 overlaps the backward of layers l-1..0.  xGMI is point-to-point (7 links/GPU): a few large messages beat many small ones,
 hence no finer bucketing.  Averaging (1/world) is folded into the fused AdamW kernel (grad_scale).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 
+_FORCE = os.environ.get('MXL_DIST_FORCE') == '1'      # exercise the collective path on a single rank (hardware smoke test)
+
+
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size() -> int:

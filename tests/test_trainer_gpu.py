@@ -73,3 +73,23 @@ def test_reformer_train_eval(dev, tmp_path):
     tr.train()
     ev = [d for d in logs if 'eval_loss' in d]
     assert ev[-1]['eval_loss'] < 0.85 * ev[0]['eval_loss']
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_single_rank():
+    """bench.py under torch.distributed.run with the collective path forced on one rank: RCCL init, the per-layer async
+    gradient all-reduces overlapped with the backward, barrier + MAX-over-ranks timing, one JSON line."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MXL_DIST_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--workload', 'tiny', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['unit'] == 'tokens/s'
