@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int i0 = blockIdx.x * QB;
+    // longest-first: late query blocks see the most real keys (early ones mostly phantom distances), and they are dispatched
+    // first so the tail of the launch is made of short workgroups
+    const int i0 = (gridDim.x - 1 - blockIdx.x) * QB;
     const int iw0 = i0 + 32 * wid;
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;
