@@ -225,6 +225,18 @@ int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T
 int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r, float* dlse,
                         int B, int T, int H, int dh, int n_h, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Evaluation metrics: replaces `preprocess_logits_for_metrics` + ComputeMetrics / IkrMetric on gathered
+ * logits (musicnlp/trainer/train.py:265-284, musicnlp/trainer/metrics.py:45-117).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* ids[n] = argmax_v logits[n][v] (first maximum); logits (N, ld) f32, ids int64 */
+int mxl_argmax_rows(const float* logits, int ld, void* ids_out, int N, int V, void* stream);
+/* out14[b] = { pitch-class histogram[12] of predicted pitch tokens at non-ignored positions, #correct next tokens, #non-ignored
+ * next-token positions }.  preds int64 (B, T-1 if clm_pred_shifted else T), labels int64 (B, T), id2pc int8[V]: pitch class
+ * 0..11 of a pitch token id, -1 for every other id (rests and the rare-pitch token included). */
+int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_labels, const signed char* id2pc, int V,
+                    int* out14, int B, int T, int clm_pred_shifted, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

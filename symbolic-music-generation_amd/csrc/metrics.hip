@@ -1,0 +1,82 @@
+// Evaluation metrics on the device: greedy ids from the logits and the per-sequence counts behind next-token
+// accuracy and the in-key ratio, so that only (B, T) ids / (B, 14) integers ever leave the GPU (the reference gathers the full
+// (B, T, V) logits to the host: musicnlp/util/train/trainer_eval_wrap.py:310-314, then musicnlp/trainer/train.py:265-284 and
+// musicnlp/trainer/metrics.py:45-117 on numpy).
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+// ids[row] = argmax_v x[row][v], first maximum wins (numpy / torch.argmax on ties); one wave per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld, long long* out, int N, int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * ld;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+        const float f = xr[v];
+        if (f > best || (f == best && v < arg)) { best = f; arg = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) out[row] = (arg == 0x7fffffff) ? 0 : arg;      // all-NaN / -inf row: id 0
+}
+
+// One workgroup per sequence.  out[b] = { pitch-class histogram [12] of the predicted pitch tokens at non-ignored positions,
+// number of correct next-token predictions, number of non-ignored next-token positions }.
+//   labels (B, T);  preds (B, T - 1) when `shifted` (pred[j] answers label[j+1]), else (B, T) (pred[j] sits at position j,
+//   answers label[j+1]).   In-key positions (metrics.py:45-52): pred[j] where label'[j] != -100, label' = labels[:, 1:] if shifted.
+//   Accuracy positions (train.py:277-283): pairs (pred[j], label[j+1]), j < T - 1, label[j+1] != -100.
+__global__ __launch_bounds__(256) void eval_counts_kernel(const long long* preds, int ldp, const long long* labels, int ldl,
+                                                          const signed char* id2pc, int V, int* out, int T, int shifted) {
+    __shared__ int hist[14];
+    if (threadIdx.x < 14) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const long long* pr = preds + (size_t)b * ldp;
+    const long long* lb = labels + (size_t)b * ldl;
+    int correct = 0, total = 0;
+    const int np = shifted ? T - 1 : T;
+    for (int j = threadIdx.x; j < np; j += 256) {
+        const long long p = pr[j];
+        const long long lk = shifted ? lb[j + 1] : lb[j];              // in-key mask
+        if (lk != -100 && p >= 0 && p < V) {
+            const int pc = id2pc[p];
+            if (pc >= 0) atomicAdd(&hist[pc], 1);
+        }
+        if (j < T - 1) {
+            const long long ln = lb[j + 1];
+            if (ln != -100) { total++; correct += (p == ln) ? 1 : 0; }
+        }
+    }
+    correct = (int)wave_sum((float)correct);      // exact below 2^24 positions per wave
+    total = (int)wave_sum((float)total);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&hist[12], correct); atomicAdd(&hist[13], total); }
+    __syncthreads();
+    if (threadIdx.x < 14) out[b * 14 + threadIdx.x] = hist[threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" int mxl_argmax_rows(const float* logits, int ld, void* ids_out, int N, int V, void* stream) {
+    MXL_CHECK_ARG(logits && ids_out && N > 0 && V > 0 && ld >= V);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, (long long*)ids_out, N, V);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_labels, const signed char* id2pc,
+                               int V, int* out14, int B, int T, int clm_pred_shifted, void* stream) {
+    MXL_CHECK_ARG(preds && labels && id2pc && out14 && B > 0 && T > 1 && V > 0);
+    MXL_CHECK_ARG(ld_labels >= T && ld_preds >= (clm_pred_shifted ? T - 1 : T) && T < (1 << 24));
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)preds, ld_preds,
+                       (const long long*)labels, ld_labels, id2pc, V, out14, T, clm_pred_shifted);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

@@ -203,27 +203,42 @@ class MyTrainer:
         return dict(train_runtime=time.time() - t0, global_step=self.global_step)
 
     @torch.no_grad()
-    def evaluate(self) -> Dict:
-        """eval loss + next-token accuracy; argmax on device, only (B, T) ids cross ranks (the reference gathers the full
-        (B, T, V) logits: trainer_eval_wrap.py:310-314)."""
+    def evaluate(self, key_scores=None) -> Dict:
+        """eval loss + next-token accuracy (+ in-key ratio when `key_scores` (N_eval, 24) is given, the 'vanilla' IKR mode):
+        argmax and the per-token counting run on the device (metrics.py), only (B, 14) integers per batch reach the host and
+        only sums cross ranks (the reference gathers the full (B, T, V) logits: trainer_eval_wrap.py:310-314)."""
+        from .metrics import ComputeMetrics, max_out_logits
         self.model.eval()
         bsz = self.args['per_device_eval_batch_size']
-        tot_loss, tot_n, hit, cnt = 0.0, 0, 0.0, 0.0
+        cm = ComputeMetrics(self.tokenizer, mode='vanilla', clm_pred_shifted=False) if self.tokenizer is not None else None
+        tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n, row0 = 0.0, 0, 0.0, 0.0, 0.0, 0, 0
         for ids in self._batches(self.eval_dataset, bsz, 0, shuffle=False):
             ids, labels = collate_clm(ids, self.pad_id)
             out = self.model(input_ids=ids, labels=labels)
-            preds = out.logits.argmax(-1)
-            msk = labels[:, 1:] != PT_LOSS_PAD
-            hit += (preds[:, :-1][msk] == labels[:, 1:][msk]).float().sum().item()
-            cnt += msk.sum().item()
+            preds = max_out_logits(out.logits)
+            if cm is not None:
+                c = cm.counts(preds, labels).cpu().numpy()
+                hit += float(c[:, 12].sum()); cnt += float(c[:, 13].sum())
+                if key_scores is not None:
+                    ks = key_scores[row0:row0 + ids.shape[0]]
+                    ikr_sum += cm.ikr_from_counts(c, labels, ks) * ids.shape[0]
+                    ikr_n += ids.shape[0]
+            else:       # no tokenizer: accuracy only, still on device ids
+                msk = labels[:, 1:] != PT_LOSS_PAD
+                hit += (preds[:, :-1][msk] == labels[:, 1:][msk]).float().sum().item()
+                cnt += msk.sum().item()
+            row0 += ids.shape[0]
             tot_loss += out.loss.item() * ids.shape[0]
             tot_n += ids.shape[0]
-        stats = torch.tensor([tot_loss, tot_n, hit, cnt], dtype=torch.float64, device=self.model.device)
+        stats = torch.tensor([tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n], dtype=torch.float64, device=self.model.device)
         if mdist.is_dist():
             torch.distributed.all_reduce(stats)
         s = stats.tolist()
         self.model.train()
-        return dict(eval_loss=s[0] / max(s[1], 1), eval_ntp_acc=s[2] / max(s[3], 1))
+        res = dict(eval_loss=s[0] / max(s[1], 1), eval_ntp_acc=s[2] / max(s[3], 1))
+        if s[5] > 0:
+            res['eval_ikr'] = s[4] / s[5]
+        return res
 
     def save_model(self, path: str):
         self.model.save_pretrained(path)
