@@ -237,6 +237,18 @@ int mxl_argmax_rows(const float* logits, int ld, void* ids_out, int N, int V, vo
 int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_labels, const signed char* id2pc, int V,
                     int* out14, int B, int T, int clm_pred_shifted, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Input pipeline: the pad / truncate / label contract of `tokenizer(toks, padding='max_length',
+ * truncation=True)` (musicnlp/preprocess/dataset.py:361) + DataCollatorForLanguageModeling(mlm=False) (train.py:360),
+ * applied on the device to one packed run of pre-tokenised ids.
+ *   tokens  : elem_bytes = 2 (uint16) or 4 (int32) token ids, the B sequences back to back
+ *   offsets : int32[B+1] element offsets into `tokens` (sequence b = [offsets[b], offsets[b+1]); may be empty or longer
+ *             than max_length: truncated)
+ *   ids_out, labels_out : (B, max_length) int64; labels may be NULL.  labels = ids with every pad_id -> -100.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
+                       int max_length, long long pad_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,39 @@ extern "C" int mxl_eval_counts(const void* preds, int ld_preds, const void* labe
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Input pipeline: a batch arrives as ONE packed run of tokens (uint16 / int32, as stored in the pre-tokenised
+// file) plus B+1 offsets; this kernel produces what `tokenizer(toks, padding='max_length', truncation=True)`
+// (musicnlp/preprocess/dataset.py:361) followed by DataCollatorForLanguageModeling(mlm=False) (train.py:360) hands the model:
+//   ids[b][t]    = tok[off[b] + t]  for t < min(len_b, max_length), pad_id beyond
+//   labels[b][t] = ids[b][t], with every pad_id replaced by -100
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TOK>
+__global__ __launch_bounds__(256) void pack_clm_kernel(const TOK* tok, const int* off, long long* ids, long long* labels, int B,
+                                                       int L, long long pad_id) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)B * L) return;
+    const int b = (int)(gid / L), t = (int)(gid % L);
+    const int o0 = off[b], n = off[b + 1] - o0;
+    const long long v = (t < n) ? (long long)tok[o0 + t] : pad_id;
+    ids[gid] = v;
+    if (labels) labels[gid] = (v == pad_id) ? -100 : v;
+}
+}  // namespace
+
+extern "C" int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
+                                  int max_length, long long pad_id, void* stream) {
+    MXL_CHECK_ARG(tokens && offsets && ids_out && B > 0 && max_length > 0 && (elem_bytes == 2 || elem_bytes == 4));
+    const long long n = (long long)B * max_length;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(pack_clm_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)tokens,
+                           offsets, (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id);
+    else
+        hipLaunchKernelGGL(pack_clm_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, (const int*)tokens, offsets,
+                           (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

@@ -1,0 +1,68 @@
+"""Device batcher (pinned staging, side-stream H2D, pad/label kernel) vs the CPU statement of the reference's batch contract."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.data_ref import pad_and_label  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('vocab', [1190, 100000])
+def test_device_batcher_matches_contract(tmp_path, vocab):
+    from symbolic_music_generation_amd.data import DeviceBatcher, TokenFile, write_token_file
+    rng = np.random.default_rng(vocab)
+    lens = [0, 1, 63, 64, 65, 500, 3, 128, 129, 64, 7]
+    seqs = [rng.integers(0, vocab, size=n) for n in lens]
+    seqs[5][10] = 1                                            # a genuine pad id inside a sequence
+    write_token_file(str(tmp_path / 'c'), seqs, vocab_size=vocab)
+    tf = TokenFile(str(tmp_path / 'c'))
+    L, pad = 64, 1
+    db = DeviceBatcher(tf, batch_size=4, max_length=L, pad_id=pad, device='cuda:0')
+    assert len(db) == 3
+    for epoch in range(2):                                     # second pass re-uses the pinned slots
+        got_ids, got_lab = [], []
+        for ids, labels in db:
+            assert ids.dtype == torch.int64 and ids.shape[1] == L and ids.is_cuda
+            got_ids.append(ids.cpu().numpy()); got_lab.append(labels.cpu().numpy())
+        ref_ids, ref_lab = pad_and_label(seqs, L, pad)
+        assert np.array_equal(np.concatenate(got_ids), ref_ids) and np.array_equal(np.concatenate(got_lab), ref_lab)
+
+
+def test_device_batcher_shards_and_shuffles(tmp_path):
+    from symbolic_music_generation_amd.data import DeviceBatcher, TokenFile, write_token_file
+    rng = np.random.default_rng(1)
+    seqs = [np.full(rng.integers(1, 40), i + 2) for i in range(37)]       # sequence i is made of the id i + 2
+    write_token_file(str(tmp_path / 'c'), seqs, vocab_size=64)
+    tf = TokenFile(str(tmp_path / 'c'))
+    seen = []
+    for r in range(2):
+        db = DeviceBatcher(tf, batch_size=5, max_length=16, pad_id=1, device='cuda:0', shuffle=True, seed=3, rank=r, world=2)
+        rows = np.concatenate([ids.cpu().numpy() for ids, _ in db])
+        seen.append(rows[:, 0] - 2)
+    both = np.concatenate(seen)
+    assert sorted(both.tolist()) == list(range(37))             # the two ranks partition the corpus
+    assert seen[0].tolist() != sorted(seen[0].tolist())         # shuffled
+    order = np.arange(37); np.random.default_rng(3).shuffle(order)
+    assert seen[0].tolist() == order[0::2].tolist() and seen[1].tolist() == order[1::2].tolist()
+
+
+def test_batcher_feeds_the_model_on_reference_scores(tmp_path):
+    """the reference's real token streams through the whole path: file -> batcher -> model loss"""
+    from symbolic_music_generation_amd.data import DeviceBatcher, TokenFile, write_token_file
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample_score_ids.npz'))
+    ids = z['sample_full_degree'].astype(np.int64)
+    pieces = [ids[i:i + 300] for i in range(0, 2400, 300)]
+    write_token_file(str(tmp_path / 's'), pieces, vocab_size=1190)
+    db = DeviceBatcher(TokenFile(str(tmp_path / 's')), batch_size=4, max_length=256, pad_id=1, device='cuda:0')
+    cfg = MyTransfoXLConfig('debug', max_length=256, vocab_size=1190, n_layer=2, mem_len=256, cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=torch.device('cuda:0'), seed=1).eval()
+    losses = [model(input_ids=x, labels=y).loss.item() for x, y in db]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and all(5.0 < v < 9.0 for v in losses)     # ~ln(1190) at init
