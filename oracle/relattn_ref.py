@@ -6,7 +6,8 @@ in *position* coordinates, the form the HIP kernels implement:
 
 tests/test_oracle_cpu.py proves this equals the upstream formulation restated in oracle/transfoxl_ref.py
 (AC/BD einsums + pad/view `_rel_shift` + same_length mask), i.e. the rel-shift identity
-BD[i, j] = BDraw[i, j + qlen - 1 - i].  Parity of that upstream restatement itself is unpinned (see its header).
+BD[i, j] = BDraw[i, j + qlen - 1 - i].  Both forms are pinned on an external implementation: HuggingFace XLNet's
+`rel_attn_core` (tests/test_xlnet_pin_cpu.py, goldens from tests/golden/make_xlnet_relattn_goldens.py).
 """
 import math
 

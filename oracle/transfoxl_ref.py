@@ -5,7 +5,13 @@ of StefanHeng/Symbolic-Music-Generation.
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
 The product path (`symbolic-music-generation_amd/`) never does.
 
-PARITY STATUS: **parity unpinned**.  The arithmetic of this path lives in the un-vendored third-party
+PARITY STATUS: **attention core pinned on an external implementation, the rest parity unpinned**.  Pinned
+(tests/test_xlnet_pin_cpu.py, goldens from tests/golden/make_xlnet_relattn_goldens.py): the sinusoid [sin || cos] table
+with clamp_len, the pad/view rel-shift, and `RelPartialLearnableMultiHeadAttn`'s AC + BD -> scale -> same_length mask ->
+softmax -> .V against HuggingFace XLNet's `relative_positional_encoding` / `rel_shift_bnij` / `rel_attn_core` (installed
+transformers 5.15; XLNet inherits Transformer-XL's relative attention unchanged).  Unpinned: everything around that core
+(embedding scale, post-LN ordering, FFN, mems update, the projected adaptive softmax, the reference's loss reduction), for the
+reason below.  The arithmetic of this path lives in the un-vendored third-party
 dependency `transformers==4.25.1` (`/root/reference/requirements.txt:150`), modules
 `transformers/models/transfo_xl/modeling_transfo_xl.py` and `modeling_transfo_xl_utilities.py`.  That
 package is absent from /root/reference and from this image (transformers 5.15 dropped the model), and
