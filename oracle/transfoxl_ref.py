@@ -5,13 +5,16 @@ of StefanHeng/Symbolic-Music-Generation.
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
 The product path (`symbolic-music-generation_amd/`) never does.
 
-PARITY STATUS: **attention core pinned on an external implementation, the rest parity unpinned**.  Pinned
-(tests/test_xlnet_pin_cpu.py, goldens from tests/golden/make_xlnet_relattn_goldens.py): the sinusoid [sin || cos] table
-with clamp_len, the pad/view rel-shift, and `RelPartialLearnableMultiHeadAttn`'s AC + BD -> scale -> same_length mask ->
-softmax -> .V against HuggingFace XLNet's `relative_positional_encoding` / `rel_shift_bnij` / `rel_attn_core` (installed
-transformers 5.15; XLNet inherits Transformer-XL's relative attention unchanged).  Unpinned: everything around that core
-(embedding scale, post-LN ordering, FFN, mems update, the projected adaptive softmax, the reference's loss reduction), for the
-reason below.  The arithmetic of this path lives in the un-vendored third-party
+PARITY STATUS: **decoder layer and adaptive softmax pinned on external implementations, the glue around them unpinned**.
+Pinned (tests/test_xlnet_pin_cpu.py; goldens from tests/golden/make_xlnet_relattn_goldens.py, inputs + outputs only):
+  * sinusoid [sin || cos] table with clamp_len, the pad/view rel-shift, `RelPartialLearnableMultiHeadAttn`'s AC + BD -> scale ->
+    same_length mask -> softmax -> .V  against HuggingFace XLNet's `relative_positional_encoding` / `rel_shift_bnij` /
+    `rel_attn_core` (installed transformers 5.15; XLNet inherits Transformer-XL's relative attention unchanged);
+  * the whole `DecoderLayer` (qkv_net over cat(mems, h), r_net, o_net, post-LN residual, relu FFN, post-LN) against a whole
+    HuggingFace `XLNetLayer` carrying the same weights;
+  * `ProjectedAdaptiveLogSoftmax` (div_val = 1) against `torch.nn.AdaptiveLogSoftmaxWithLoss`.
+Unpinned: the glue -- embedding scale, dropout placement, mems update, the reference's label guard and loss reduction (these
+follow the reference's own file line by line) -- for the reason below.  The arithmetic of this path lives in the un-vendored third-party
 dependency `transformers==4.25.1` (`/root/reference/requirements.txt:150`), modules
 `transformers/models/transfo_xl/modeling_transfo_xl.py` and `modeling_transfo_xl_utilities.py`.  That
 package is absent from /root/reference and from this image (transformers 5.15 dropped the model), and
