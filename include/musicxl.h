@@ -207,11 +207,14 @@ int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* rotations, i
 /* stable sort of the S = n_h*T slots of each of the BH rows by bucket: sorted_idx (slot -> element), sorted_pos = idx % T */
 int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, int S, int T, int n_buckets_total, void* stream);
 /* chunked attention: local (lsh=0, sorted_pos NULL, n_h=1; separate q/k/v) or LSH (lsh=1; k == q == shared qk).
- * out rows (b, round, pos) x (H*dh) bf16; lse (B, n_h, H, T) f32; T % 64 == 0, T > 64; probs dropout drop_p */
+ * out rows (b, round, pos) x (H*dh) bf16; lse (B, n_h, H, T) f32; probs dropout drop_p.
+ * T > 64: T % 64 == 0 (chunks of 64 with one look-back chunk).  T <= 64: the single-chunk case -- HF's plain causal attention
+ * over the T tokens (no look-back, sorted_pos ignored, n_h must be 1; for lsh the shared-QK key normalisation and the
+ * self mask still apply). */
 int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, const int* sorted_pos, void* out, float* lse, int B, int T,
                        int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed,
                        unsigned site, void* stream);
-/* backward: dq, dk, dv (B,T,H*dh) f32 are ACCUMULATED (atomics); for lsh, dk is w.r.t. the normalised key (see keynorm_bwd);
+/* backward: dq, dk, dv (B,T,H*dh) f32 are ACCUMULATED (atomics; written when T <= 64); for lsh, dk is w.r.t. the normalised key (see keynorm_bwd);
  * dout has out's layout; dlse (B,n_h,H,T) f32 or NULL */
 int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out, const float* lse,
                        const void* dout, const float* dlse, float* dq, float* dk, float* dv, int B, int T, int H, int dh,

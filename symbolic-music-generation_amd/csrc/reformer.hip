@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64) void lsh_sort_kernel(const int* buckets, int* s
 // masks on ORIGINAL positions: causal (q_pos >= k_pos) else -1e9; LSH self mask (q_pos == k_pos) -> -1e5 afterwards.
 // lane = query ("swapped" S^T = K Q^T), single pass over the 128 keys.
 // =====================================================================================================================
+constexpr int SC_MAXT = 64;      // sequences up to one chunk take the single-chunk kernels
 struct ChunkP {
     const bf16_t *q, *k, *v;
     const int* spos;            // (B,H,S) or null (identity)
@@ -773,15 +774,137 @@ int launch_chunk(const ChunkP& p, int mode, hipStream_t s) {
 int fill_chunk(ChunkP& p, const void* q, const void* k, const void* v, const int* spos, void* out, float* lse, int B, int T,
                int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed, unsigned site) {
     if (!(q && k && v && out && lse)) return MXL_EINVAL;
-    if (!(B > 0 && T > 0 && H > 0 && n_h >= 1 && (T % 64) == 0 && T > 64)) return MXL_EINVAL;
+    if (!(B > 0 && T > 0 && H > 0 && n_h >= 1)) return MXL_EINVAL;
+    if (T <= SC_MAXT) { if (n_h != 1) return MXL_EINVAL; }     // single chunk: one plain attention, no hash rounds
+    else if ((T % 64) != 0) return MXL_EINVAL;
     if ((rs % 8) || (bs % 8)) return MXL_EINVAL;
     if (n_h > 1 && !lsh) return MXL_EINVAL;
-    if (lsh && !spos) return MXL_EINVAL;
+    if (lsh && !spos && T > SC_MAXT) return MXL_EINVAL;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.spos = spos; p.out = (bf16_t*)out; p.lse = lse;
     p.dout = nullptr; p.dlse = nullptr; p.dq = p.dk = p.dv = nullptr;
     p.bs = bs; p.rs = rs; p.B = B; p.T = T; p.H = H; p.S = n_h * T; p.n_h = n_h; p.lsh = lsh;
     p.scale = 1.f / sqrtf((float)dh);
     p.thresh = dropout_thresh(drop_p); p.dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.site = site;
+    return MXL_OK;
+}
+
+// =====================================================================================================================
+// Single-chunk path (T <= chunk length): HF does plain causal attention over the T tokens -- no hashing, no sort, no look-back
+// chunk (HF515:547-549, 1244-1262 `do_standard_self_attention`; local layers the same, HF515:1424-1437).  Sizes are tiny
+// (the reference's `debug` preset, max_length 64): one workgroup per (b, h), everything in LDS as fp32, no MFMA.
+//   local: s_ij = q_i . k_j * scale                     LSH: s_ij = qk_i . (qk_j * rsqrt(mean(qk_j^2) + 1e-6) * scale), self -> -1e5
+//   causal -1e9, softmax, dropout on the probabilities, out_i = sum_j p_ij v_j
+// Backward writes dq, dk (LSH: w.r.t. the normalised key, like the chunked kernels), dv in fp32 (plain stores).
+// =====================================================================================================================
+template <int DH, bool BWD>
+__global__ __launch_bounds__(256) void single_attn_kernel(ChunkP p) {
+    constexpr int LD = DH + 1;
+    extern __shared__ float sm[];
+    float* sq = sm;                       // [64][LD]
+    float* sk = sq + SC_MAXT * LD;        // [64][LD]  (already multiplied by its per-key factor)
+    float* sv = sk + SC_MAXT * LD;        // [64][LD]
+    float* sp = sv + SC_MAXT * LD;        // [64][65]  probabilities (pre-dropout)
+    float* sdo = sp + SC_MAXT * 65;       // [64][LD]  (backward) dO
+    float* sds = sdo + SC_MAXT * LD;      // [64][65]  (backward) dS
+    const int h = blockIdx.x, b = blockIdx.y, T = p.T, d = p.H * DH, tid = threadIdx.x;
+    for (int i = tid; i < T * DH; i += 256) {
+        const int t = i / DH, e = i % DH;
+        const size_t off = (size_t)b * p.bs + (size_t)t * p.rs + h * DH + e;
+        sq[t * LD + e] = bf2f(p.q[off]);
+        sk[t * LD + e] = bf2f(p.k[off]);
+        sv[t * LD + e] = bf2f(p.v[off]);
+        if (BWD) sdo[t * LD + e] = bf2f(p.dout[((size_t)b * T + t) * d + h * DH + e]);
+    }
+    __syncthreads();
+    if (tid < T) {                         // per-key factor folded into the key rows
+        float f = p.scale;
+        if (p.lsh) {
+            float ss = 0.f;
+            for (int e = 0; e < DH; e++) ss += sk[tid * LD + e] * sk[tid * LD + e];
+            f = rsqrtf(ss / (float)DH + 1e-6f) * p.scale;
+        }
+        for (int e = 0; e < DH; e++) sk[tid * LD + e] *= f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * T; idx += 256) {
+        const int i = idx / T, j = idx % T;
+        float a = 0.f;
+        for (int e = 0; e < DH; e++) a += sq[i * LD + e] * sk[j * LD + e];
+        a = (i >= j) ? a : -1e9f;
+        if (p.lsh) a = (i != j) ? a : -1e5f;
+        sp[i * 65 + j] = a;
+    }
+    __syncthreads();
+    if (tid < T) {
+        float m = -INFINITY, z = 0.f;
+        for (int j = 0; j < T; j++) m = fmaxf(m, sp[tid * 65 + j]);
+        for (int j = 0; j < T; j++) z += __expf(sp[tid * 65 + j] - m);
+        const float l = m + __logf(z);
+        for (int j = 0; j < T; j++) sp[tid * 65 + j] = __expf(sp[tid * 65 + j] - l);
+        if (!BWD && p.lse) p.lse[((size_t)b * p.H + h) * T + tid] = l;
+    }
+    __syncthreads();
+    auto keep = [&](int i, int j) -> float {
+        if (!p.thresh) return 1.f;
+        return dropout_keep(p.seed, p.site, (((uint64_t)b * p.H + h) * T + i) * 64 + j, p.thresh) ? p.dscale : 0.f;
+    };
+    if (!BWD) {
+        for (int idx = tid; idx < T * DH; idx += 256) {
+            const int i = idx / DH, e = idx % DH;
+            float a = 0.f;
+            for (int j = 0; j <= i; j++) a += sp[i * 65 + j] * keep(i, j) * sv[j * LD + e];
+            p.out[((size_t)b * T + i) * d + h * DH + e] = f2bf(a);
+        }
+        return;
+    }
+    // g_ij = keep * dO_i . v_j ;  dS_ij = p_ij (g_ij - sum_j' p_ij' g_ij')
+    for (int idx = tid; idx < T * T; idx += 256) {
+        const int i = idx / T, j = idx % T;
+        float a = 0.f;
+        for (int e = 0; e < DH; e++) a += sdo[i * LD + e] * sv[j * LD + e];
+        sds[i * 65 + j] = a * keep(i, j);
+    }
+    __syncthreads();
+    if (tid < T) {
+        float dl = 0.f;
+        for (int j = 0; j < T; j++) dl += sp[tid * 65 + j] * sds[tid * 65 + j];
+        for (int j = 0; j < T; j++) {
+            const bool live = (tid >= j) && !(p.lsh && tid == j);
+            sds[tid * 65 + j] = live ? sp[tid * 65 + j] * (sds[tid * 65 + j] - dl) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * DH; idx += 256) {
+        const int t = idx / DH, e = idx % DH;
+        float aq = 0.f, ak = 0.f, av = 0.f;
+        for (int j = 0; j < T; j++) {
+            aq += sds[t * 65 + j] * sk[j * LD + e];                       // dq_t  = sum_j dS_tj k'_j
+            ak += sds[j * 65 + t] * sq[j * LD + e];                       // dk'_t = sum_i dS_it q_i
+            av += sp[j * 65 + t] * keep(j, t) * sdo[j * LD + e];          // dv_t  = sum_i pd_it dO_i
+        }
+        const size_t o = ((size_t)b * T + t) * d + h * DH + e;
+        p.dq[o] = aq;
+        p.dk[o] = p.lsh ? ak : ak * p.scale;      // local: the factor was folded into k', undo to get d k
+        p.dv[o] = av;
+    }
+}
+
+template <int DH>
+int launch_single(const ChunkP& p, int bwd, hipStream_t s) {
+    const size_t smem = (size_t)(4 * SC_MAXT * (DH + 1) + 2 * SC_MAXT * 65) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&single_attn_kernel<DH, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&single_attn_kernel<DH, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (bwd) hipLaunchKernelGGL((single_attn_kernel<DH, true>), dim3(p.H, p.B), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((single_attn_kernel<DH, false>), dim3(p.H, p.B), dim3(256), smem, s, p);
+    MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
 
@@ -844,6 +967,14 @@ extern "C" int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, c
     ChunkP p;
     int rc = fill_chunk(p, q, k, v, sorted_pos, out, lse, B, T, H, dh, n_h, lsh, bs, rs, drop_p, seed, site);
     if (rc) return rc;
+    if (T <= SC_MAXT) {
+        switch (dh) {
+            case 16: return launch_single<16>(p, 0, (hipStream_t)stream);
+            case 32: return launch_single<32>(p, 0, (hipStream_t)stream);
+            case 64: return launch_single<64>(p, 0, (hipStream_t)stream);
+            default: return MXL_EUNSUPPORTED;
+        }
+    }
     switch (dh) {
         case 16: return launch_chunk<16>(p, 0, (hipStream_t)stream);
         case 32: return launch_chunk<32>(p, 0, (hipStream_t)stream);
@@ -861,6 +992,14 @@ extern "C" int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, c
     if (rc) return rc;
     MXL_CHECK_ARG(dout && dq && dk && dv);
     p.dout = (const bf16_t*)dout; p.dlse = dlse; p.dq = dq; p.dk = dk; p.dv = dv;
+    if (T <= SC_MAXT) {
+        switch (dh) {
+            case 16: return launch_single<16>(p, 1, (hipStream_t)stream);
+            case 32: return launch_single<32>(p, 1, (hipStream_t)stream);
+            case 64: return launch_single<64>(p, 1, (hipStream_t)stream);
+            default: return MXL_EUNSUPPORTED;
+        }
+    }
     switch (dh) {
         case 16: return launch_chunk<16>(p, 1, (hipStream_t)stream);
         case 32: return launch_chunk<32>(p, 1, (hipStream_t)stream);

@@ -255,18 +255,22 @@ class RFEngine:
                 buckets_override: Optional[Dict[int, torch.Tensor]] = None):
         c = self.cfg
         B, T = input_ids.shape
-        if T % 64 != 0 or T <= 64:
-            raise NotImplementedError('HIP Reformer path: sequence length must be a multiple of the chunk length 64 and > 64 '
-                                      '(single-chunk "standard attention" inputs are not covered yet)')
+        single = T <= 64          # HF's standard-attention case: no hashing, no sort, no look-back chunk (HF515:547-549)
+        if not single and T % 64 != 0:
+            raise NotImplementedError('HIP Reformer path: sequences longer than one chunk must be a multiple of the chunk '
+                                      'length 64 (HF pads them in eval mode and refuses them in training)')
         A0, A1 = c.axial_pos_shape
         if train and A0 * A1 != T:
             raise ValueError(f'If training, prod(axial_pos_shape) {A0 * A1} must equal the sequence length {T} (HF515:231-238)')
         if T > A0 * A1:
             raise ValueError('sequence longer than max_position_embeddings')
         d, Fi, H, dh, n_h = c.hidden_size, c.feed_forward_size, c.num_attention_heads, c.attention_head_size, c.num_hashes
+        if single:
+            n_h = 1
         L, V = len(c.attn_layers), c.vocab_size
         N = B * T
         ws = self._workspace(B, T, train)
+        ws.single = single
         p = float(c.hidden_dropout_prob) if train else 0.0
         p_loc = float(c.local_attention_probs_dropout_prob) if train else 0.0
         p_lsh = float(c.lsh_attention_probs_dropout_prob) if train else 0.0
@@ -279,7 +283,7 @@ class RFEngine:
         ops.axial_embed_fwd(ids, self.w16('reformer.embeddings.word_embeddings.weight'), W0, W1, ws.x1[0].view(B, T, d), A0, A1,
                             drop_p=p, seed=seed, site_emb=self.SITE_EMB, site_pos=self.SITE_POS)
         ws.x2[0].copy_(ws.x1[0])
-        factors = self._factors(T)
+        factors = self._factors(T) if not single else [2]
         NB = math.prod(factors)
         ws.rot = {}
         for l, kind in enumerate(c.attn_layers):
@@ -296,6 +300,9 @@ class RFEngine:
             if kind == 'local':
                 ops.chunk_attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], None, ws.av[s], ws.lse[s], B, T, H, dh, 1, 0, bs, rs,
                                    drop_p=p_loc, seed=seed, site=self._site(l, 0))
+            elif single:
+                ops.chunk_attn_fwd(qkv, qkv, qkv[:, d:], None, ws.av[s], ws.lse[s], B, T, H, dh, 1, 1, bs, rs,
+                                   drop_p=p_lsh, seed=seed, site=self._site(l, 0))
             else:
                 if buckets_override is not None and l in buckets_override:
                     ws.buckets.copy_(buckets_override[l].to(torch.int32).view(B, H, n_h * T))
@@ -367,6 +374,8 @@ class RFEngine:
         ws, c = self._last, self.cfg
         B, T, p, seed = ws.B, ws.T, ws.p, ws.seed
         d, Fi, H, dh, n_h = c.hidden_size, c.feed_forward_size, c.num_attention_heads, c.attention_head_size, c.num_hashes
+        if getattr(ws, 'single', False):
+            n_h = 1
         L, V = len(c.attn_layers), c.vocab_size
         N = B * T
         if self.WT is None:
@@ -436,7 +445,8 @@ class RFEngine:
                     o_in, do_in, dl_in = ws.out_r[l], ws.dout_r, ws.dlse
                 else:
                     o_in, do_in, dl_in = ws.av[l], dav, None
-                ops.chunk_attn_bwd(qkv, qkv, qkv[:, d:], ws.spos[l], o_in, ws.lse[l], do_in, dl_in, ws.dq, ws.dk, ws.dv, B, T, H,
+                ops.chunk_attn_bwd(qkv, qkv, qkv[:, d:], None if getattr(ws, 'single', False) else ws.spos[l], o_in, ws.lse[l], do_in,
+                                   dl_in, ws.dq, ws.dk, ws.dv, B, T, H,
                                    dh, n_h, 1, bs, rs, drop_p=ws.p_lsh, seed=seed, site=self._site(l, 0))
                 dqk16 = t2          # free here: its previous contents (dao / FF gradient) are consumed
                 ops.lsh_keynorm_bwd(qkv, bs, rs, ws.dq, ws.dk, dqk16, B, T, H, dh)

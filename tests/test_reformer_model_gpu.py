@@ -87,3 +87,57 @@ def test_train_loop_with_dropout_decreases_loss(dev):
         first = o.loss.item() if step == 0 else first
         last = o.loss.item()
     assert torch.isfinite(torch.tensor(last)) and last < 0.8 * first, (first, last)
+
+
+def test_single_chunk_forward_vs_hf_golden(dev):
+    """T <= chunk length: HF's standard-attention path (no hashing, no look-back) -- the `debug` preset's shape"""
+    blob = _load('single_chunk')
+    m = _model(dev, blob).eval()
+    ids, labels = blob['ids'].to(dev), blob['labels'].to(dev)
+    out = m(input_ids=ids, labels=labels)
+    err = (out.logits.float().cpu() - blob['logits']).abs().max().item()
+    assert err < 6e-2, err
+    assert abs(out.loss.item() - blob['loss'].item()) / blob['loss'].item() < 1e-2
+
+
+def test_single_chunk_gradients_vs_oracle(dev):
+    from oracle.reformer_ref import RefReformerConfig, RefReformer, param_shapes
+    blob = _load('single_chunk')
+    m = _model(dev, blob, hidden_dropout_prob=0.0, local_attention_probs_dropout_prob=0.0,
+               lsh_attention_probs_dropout_prob=0.0).train()
+    cfg = RefReformerConfig(**blob['config'])
+    sd = {k: blob['state_dict'][k].clone().to(torch.bfloat16).float().requires_grad_(True) for k in param_shapes(cfg)}
+    m.load_state_dict({k: v.detach() for k, v in sd.items()})
+    ids, labels = blob['ids'], blob['labels']
+    ref = RefReformer(cfg, sd)
+    m.zero_grad()
+    out = m(input_ids=ids.to(dev), labels=labels.to(dev))
+    m.backward()
+    torch.cuda.synchronize()
+    _, rloss = ref.forward(ids, None, labels)
+    rloss.backward()
+    assert abs(out.loss.item() - rloss.item()) / rloss.item() < 1e-2
+    worst = 0.0
+    for name in param_shapes(cfg):
+        got = m.engine.layout.view(m.engine.G, name).float().cpu().reshape(-1)
+        want = sd[name].grad.reshape(-1)
+        if want.norm() < 1e-8:
+            continue
+        cos = torch.dot(got, want) / (got.norm() * want.norm() + 1e-12)
+        worst = max(worst, ((got - want).norm() / (want.norm() + 1e-12)).item())
+        assert cos > 0.99, (name, cos.item())
+    assert worst < 0.12, worst
+
+
+def test_single_chunk_ragged_length_vs_oracle(dev):
+    """eval forward at a length below one chunk that is not a multiple of anything (T = 50)"""
+    from oracle.reformer_ref import RefReformerConfig, RefReformer, param_shapes
+    blob = _load('single_chunk')
+    m = _model(dev, blob).eval()
+    cfg = RefReformerConfig(**blob['config'])
+    sd = {k: blob['state_dict'][k].clone().to(torch.bfloat16).float() for k in param_shapes(cfg)}
+    m.load_state_dict(sd)
+    ids = blob['ids'][:, :50]
+    out = m(input_ids=ids.to(dev))
+    rlogits, _ = RefReformer(cfg, sd).forward(ids, None, None)
+    assert (out.logits.float().cpu() - rlogits).abs().max().item() < 6e-2
