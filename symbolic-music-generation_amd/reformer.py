@@ -161,5 +161,49 @@ class MyReformerModelWithLMHead:
     def zero_grad(self):
         self.engine.zero_grad()
 
-    def generate(self, *a, **k):
-        raise NotImplementedError('Reformer incremental decoding (HF ReformerDynamicCache path) is not built yet; see DESIGN.md')
+    @torch.no_grad()
+    def generate(self, input_ids=None, max_length: Optional[int] = None, do_sample: bool = False, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, temperature: float = 1.0, seed: int = 77, **unsupported):
+        """`model.generate(...)` as the reference drives it (musicnlp/trainer/eval.py:277-333): greedy, or sampling with
+        top-k / top-p / temperature.  Every step is a full forward over the tokens so far -- the result HF's cached decoding
+        reproduces for local layers and, for LSH layers, the same procedure with the hash rotations redrawn each forward (what
+        HF does with `hash_seed=None`).  Beyond one chunk the sequence is right-padded to a multiple of the chunk length as HF
+        does in eval mode (`_pad_to_mult_of_chunk_length`); pads sit after every real token, so the causal mask alone keeps
+        them out of the real positions.  Token selection runs on the device (the TransfoXL decoder's sampler kernel)."""
+        from . import ops
+        if unsupported:
+            bad = [k for k, v in unsupported.items() if v not in (None, False, 1, 1.0)]
+            if bad:
+                raise NotImplementedError(f'generation options not covered: {bad}')
+        c = self.config
+        was_training = self.training
+        self.eval()
+        ids0 = input_ids.to(self.device)
+        B, Tp = ids0.shape
+        A0, A1 = c.axial_pos_shape
+        max_length = int(max_length or A0 * A1)
+        if max_length > A0 * A1:
+            raise ValueError('max_length exceeds max_position_embeddings')
+        if max_length <= Tp:
+            return ids0[:, :max_length]
+        V = c.vocab_size
+        pad = getattr(c, 'pad_token_id', None)
+        pad = 0 if pad is None else int(pad)
+        buf = torch.full((B, max_length + 64), pad, device=self.device, dtype=torch.int64)
+        buf[:, :Tp] = ids0
+        t_dev = torch.full((1,), Tp - 1, device=self.device, dtype=torch.int32)
+        rng = torch.zeros(1, device=self.device, dtype=torch.int64)
+        logp = torch.empty(B, V, device=self.device, dtype=torch.float32)
+        for cur in range(Tp, max_length):
+            Tf = cur if cur <= 64 else (cur + 63) // 64 * 64
+            out = self.engine.forward(buf[:, :Tf].contiguous(), labels=None, train=False)
+            last = out['logits'][:, cur - 1].contiguous()
+            ops.adaptive_logprob(last, logp, B, V, ())
+            ops.sample(logp, buf, t_dev, rng, seed, do_sample=do_sample, top_k=top_k or 0,
+                       top_p=top_p if top_p is not None else 1.0, temperature=temperature)
+            ops.decode_advance(t_dev, rng)
+            if Tf > cur:
+                buf[:, cur + 1:Tf] = pad          # keep the padding clean (the sampler wrote position `cur` only)
+        if was_training:
+            self.train()
+        return buf[:, :max_length].clone()

@@ -141,3 +141,38 @@ def test_single_chunk_ragged_length_vs_oracle(dev):
     out = m(input_ids=ids.to(dev))
     rlogits, _ = RefReformer(cfg, sd).forward(ids, None, None)
     assert (out.logits.float().cpu() - rlogits).abs().max().item() < 6e-2
+
+
+def test_generate_greedy_matches_oracle_loop(dev):
+    """greedy decoding across the one-chunk boundary (prompt 30 -> 100 tokens: single-chunk steps, then right-padded chunked
+    steps) against the oracle run the same way (full forward per step, argmax of the last position); local layers only, so the
+    comparison has no hash randomness in it"""
+    from oracle.reformer_ref import RefReformerConfig, RefReformer, param_shapes
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    base = dict(_load('chunked_h1')['config'])
+    base.update(attn_layers=['local', 'local'], max_position_embeddings=128, axial_pos_shape=(8, 16))
+    torch.manual_seed(0)
+    m = MyReformerModelWithLMHead(MyReformerConfig('debug', **base), device=dev).eval()
+    sd = {k: (v * 4.0).to(torch.bfloat16).float() for k, v in m.state_dict().items()}      # sharper logits: no near-ties
+    m.load_state_dict(sd)
+    cfg = RefReformerConfig(**base)
+    ref = RefReformer(cfg, {k: sd[k] for k in param_shapes(cfg)})
+    prompt = torch.randint(2, base['vocab_size'], (2, 30))
+    got = m.generate(input_ids=prompt.to(dev), max_length=100).cpu()
+    assert got.shape == (2, 100) and torch.equal(got[:, :30], prompt)
+    ids = prompt.clone()
+    agree = 0
+    for cur in range(30, 100):
+        Tf = cur if cur <= 64 else (cur + 63) // 64 * 64
+        x = torch.zeros(2, Tf, dtype=torch.int64); x[:, :cur] = got[:, :cur]                  # teacher-forced on the HIP tokens
+        logits, _ = ref.forward(x, None, None)
+        nxt = logits[:, cur - 1].argmax(-1)
+        agree += (nxt == got[:, cur]).sum().item()
+        top2 = logits[:, cur - 1].topk(2).values
+        for b in range(2):                         # any disagreement must be a genuine near-tie of the fp32 reference
+            if nxt[b] != got[b, cur]:
+                assert (top2[b, 0] - logits[b, cur - 1, got[b, cur]]).item() < 0.05
+    assert agree >= 2 * 70 - 3
+    # sampling path runs and respects top-k = 1 == greedy
+    s1 = m.generate(input_ids=prompt.to(dev), max_length=70, do_sample=True, top_k=1).cpu()
+    assert torch.equal(s1, got[:, :70])
