@@ -1,0 +1,114 @@
+"""Size-independent properties at the FULL benchmark sizes (BASELINE.json configs[2] = SURVEY C3: 12L / 768d / H12 / dh64, T = M =
+2048, V = 1190; token matrices of 32768 rows), where the CPU oracle is out of reach: checksums for the GEMMs, normalisation
+and causality for the attention kernel, normalisation / causality / segmentation invariance / batch equivariance for the
+whole model."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T = M = 2048
+D, H, DH, F, V = 768, 12, 64, 3072, 1190
+NTOK = 16 * T
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize('name,O,K', [('qkv', 3 * D, D), ('o', D, D), ('ffn1', F, D), ('ffn2', D, F)])
+def test_gemm_checksums_at_c3_shapes(dev, name, O, K):
+    """sum_m C[m, :] == (sum_m A[m, :]) W^T for y = x W^T, dX = dY W and dW = dY^T X (row / column checksums computed in
+    fp64 from the same bf16 operands): a wrong tile, a dropped K-step or a lost atomic shows up at any size"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(K + O)
+    x = (torch.randn(NTOK, K, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(O, K, device=dev) * 0.05).to(torch.bfloat16)
+    y = torch.empty(NTOK, O, device=dev, dtype=torch.float32)
+    ops.gemm(x, w, y, NTOK, O, K, flags=ops.GEMM_OUT_F32)                       # old kernel (fp32 out)
+    yb = torch.empty(NTOK, O, device=dev, dtype=torch.bfloat16)
+    ops.gemm(x, w, yb, NTOK, O, K)                                              # persistent DMA kernel (bf16 out)
+    col = x.double().sum(0) @ w.double().t()                                    # column checksum of Y
+    assert _rel(y.double().sum(0), col) < 1e-5
+    assert _rel(yb.double().sum(0), col) < 2e-3                                 # bf16 rounding of 32768 outputs per column
+    row = x.double() @ w.double().sum(0)                                        # row checksum of Y
+    assert _rel(yb.double().sum(1), row) < 2e-3
+    # dX = dY W (through the [in][out] copy, as the engine does) and dW = dY^T X (split-K atomics)
+    wt = torch.empty(K, O, device=dev, dtype=torch.bfloat16)
+    ops.transpose(w, wt, O, K)
+    dx = torch.empty(NTOK, K, device=dev, dtype=torch.bfloat16)
+    ops.gemm(yb, wt, dx, NTOK, K, O)
+    assert _rel(dx.double().sum(0), yb.double().sum(0) @ w.double()) < 2e-3
+    dw = torch.zeros(O, K, device=dev, dtype=torch.float32)
+    ops.gemm(yb, x, dw, O, K, NTOK, trans_a=True, trans_b=True, flags=ops.GEMM_OUT_F32_ATOMIC, ksplits=4)
+    assert _rel(dw.double().sum(0), yb.double().sum(1) @ x.double()) < 1e-5     # column checksum: (sum_o dY[:, o])^T X
+    assert _rel(dw.double().sum(1), yb.double().t() @ x.double().sum(1)) < 1e-5
+
+
+def _attn_inputs(dev, B, Kc, seed=0):
+    torch.manual_seed(seed)
+    d = H * DH
+    qkv = torch.randn(B, Kc, 3 * d, device=dev).to(torch.bfloat16)
+    rd = torch.randn(M, d, device=dev).to(torch.bfloat16)
+    rwb = torch.randn(H, DH, device=dev) * 0.1
+    rrb = torch.randn(H, DH, device=dev) * 0.1
+    st = dict(B=B, T=T, H=H, dh=DH, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d, o_bs=T * d, o_rs=d)
+    return qkv, rd, rwb, rrb, st, d
+
+
+def test_attention_normalisation_and_causality_at_c3(dev):
+    from symbolic_music_generation_amd import ops
+    B, Kc = 2, T + M
+    qkv, rd, rwb, rrb, st, d = _attn_inputs(dev, B, Kc)
+    qkv[:, :, 2 * d:] = 1.0                                   # V = 1: the output is the softmax mass, exactly 1 per (query, head)
+    out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16); lse = torch.zeros(B, H, T, device=dev)
+    run = lambda: ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], rd, rwb, rrb, out, lse, **st)
+    run()
+    assert (out.float() - 1.0).abs().max().item() < 8e-3      # bf16 P, bf16 output
+    # causality / window: perturbing key position p (row p + M of the Kc stored rows) changes queries i in [p, p + M - 1] only
+    qkv2, *_ = _attn_inputs(dev, B, Kc, seed=0)
+    base = torch.zeros_like(out)
+    ops.relattn_fwd(qkv2[:, Kc - T:, :d], qkv2[:, :, d:2 * d], qkv2[:, :, 2 * d:], rd, rwb, rrb, base, lse, **st)
+    p = 700
+    qkv2[:, p + M, d:] += 1.0                                 # k and v of key position p
+    pert = torch.zeros_like(out)
+    ops.relattn_fwd(qkv2[:, Kc - T:, :d], qkv2[:, :, d:2 * d], qkv2[:, :, 2 * d:], rd, rwb, rrb, pert, lse, **st)
+    same = (pert == base).view(B, T, -1).all(-1).all(0)       # per query position, over batch / heads / channels
+    assert same[:p].all() and (~same[p:p + 64]).any()         # earlier queries bit-identical, the next ones see the change
+    # a key in the memory region leaves the window of late queries: position q0 = -M + 100 is visible to i <= q0 + M - 1 = 99
+    qkv3, *_ = _attn_inputs(dev, B, Kc, seed=0)
+    qkv3[:, 100, d:] += 1.0
+    pert2 = torch.zeros_like(out)
+    ops.relattn_fwd(qkv3[:, Kc - T:, :d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:], rd, rwb, rrb, pert2, lse, **st)
+    same2 = (pert2 == base).view(B, T, -1).all(-1).all(0)
+    assert same2[100:].all() and (~same2[:100]).any()
+
+
+def test_model_properties_at_c3(dev):
+    """the 12L / 768d model at T = M = 2048: log-prob normalisation, causality, segmentation invariance, batch equivariance"""
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    cfg = MyTransfoXLConfig('base', max_length=T, vocab_size=V, n_layer=12, mem_len=M, cutoffs=[])
+    m = MyTransfoXLLMHeadModel(cfg, device=dev, seed=5).eval()
+    with torch.no_grad():                                     # 3x the init scale: non-trivial attention / softmax
+        sd = {k: (v * 3.0 if v.dim() > 1 and 'layer_norm' not in k else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    torch.manual_seed(1)
+    ids = torch.randint(4, V, (2, T), device=dev)
+    o = m(input_ids=ids)
+    lp = o.prediction_scores.float()
+    assert lp.shape == (2, T, V)
+    assert (lp.exp().sum(-1) - 1.0).abs().max().item() < 2e-3
+    # causality: changing token t leaves every earlier position bit-identical
+    t = 1500
+    ids2 = ids.clone(); ids2[:, t] = (ids2[:, t] + 7) % (V - 4) + 4
+    lp2 = m(input_ids=ids2).prediction_scores.float()
+    assert torch.equal(lp2[:, :t], lp[:, :t]) and not torch.equal(lp2[:, t:], lp[:, t:])
+    # batch equivariance (bit-exact: no cross-sequence arithmetic)
+    lp_sw = m(input_ids=ids.flip(0)).prediction_scores.float()
+    assert torch.equal(lp_sw.flip(0), lp)
+    # segmentation invariance: two 1024-token segments with carried mems == one 2048-token pass (bf16 noise only)
+    o1 = m(input_ids=ids[:, :1024])
+    o2 = m(input_ids=ids[:, 1024:], mems=o1.mems)
+    seg = torch.cat([o1.prediction_scores, o2.prediction_scores], 1).float()
+    assert (seg - lp).abs().max().item() < 8e-2
+    assert (seg - lp).abs().mean().item() < 1e-2        # log-probs are O(10): 1e-3 relative, 12 layers of bf16 activations
