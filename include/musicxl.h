@@ -172,7 +172,8 @@ int mxl_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_sr
 int mxl_decode_embed(const void* ids, int ld_ids, const int* t_dev, const void* E, void* out, int B, int d, int V,
                      float scale, void* stream);
 /* cache[b][t mod M] <- k, v of the (B, 3d) qkv rows of the current token */
-int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, int dh, void* stream);
+int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, int dh,
+                  const float* r_r_bias, void* qr_out, void* stream);   /* qr_out (B, d) bf16 = q + r_r_bias, or NULL */
 /* after the prompt forward: cache slots <- K/V rows of the last min(T, M) positions of a (B, T, 3d) qkv buffer */
 int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, int dh, void* stream);
 /* single-query relative attention over the ring, distances 0..M-1.  bd (B, H, M) f32 = (q + r_r_bias) . rd[dist], the

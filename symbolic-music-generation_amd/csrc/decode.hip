@@ -31,11 +31,21 @@ __global__ void decode_embed_kernel(const long long* ids, int ld_ids, const int*
 // cache[b][t mod M] = (k, v) of the current token (rows of the (B, 3d) qkv buffer)
 // ring layout is head-major (B, H, M, dh): the attention kernel of one (b, h) then streams one contiguous 2*M*dh-byte
 // region instead of 128-byte pieces at a d-element stride (DRAM page locality)
-__global__ void kv_append_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, const int* t_dev, int B, int M, int d, int dh) {
+// optionally also qr[b][:] = q + r_r_bias (bf16), the operand of the per-step BD product -- one launch instead of two
+__global__ void kv_append_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, const int* t_dev, int B, int M, int d, int dh,
+                                 const float* rrb, bf16_t* qr) {
     const int chunks = d >> 3;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= B * chunks) return;
     const int b = gid / chunks, c = gid % chunks;
+    if (qr) {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qkv + (size_t)b * 3 * d + c * 8);
+        u32x4 w;
+        bf16_t* wp = reinterpret_cast<bf16_t*>(&w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) wp[j] = f2bf(bf2f((bf16_t)qv[j]) + rrb[c * 8 + j]);
+        *reinterpret_cast<u32x4*>(qr + (size_t)b * d + c * 8) = w;
+    }
     const int slot = (*t_dev) % M;
     const int h = (c * 8) / dh, e = (c * 8) % dh, H = d / dh;
     const u32x4 k = *reinterpret_cast<const u32x4*>(qkv + (size_t)b * 3 * d + d + c * 8);
@@ -200,6 +210,48 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
         idx[i] = i;
     }
     __syncthreads();
+    // Small supports (greedy, or top-k <= 64) need only the first few entries of the sorted order: take them by repeated
+    // workgroup arg-max (same order as the sort: value descending, ties by ascending index) -- 2 barriers per entry instead of
+    // the 66 barrier stages of the full sort.
+    const int nsel = !do_sample ? 1 : ((top_k > 0 && top_k <= 64 && top_k < V) ? top_k : 0);
+    if (nsel > 0) {
+        __shared__ float wbest[4];
+        __shared__ int warg[4];
+        float vals[SORT_N / 256];
+#pragma unroll
+        for (int e = 0; e < SORT_N / 256; e++) vals[e] = key[tid + 256 * e];
+        __syncthreads();                                  // everyone has its copy before key[] is overwritten with the selection
+        for (int rnd = 0; rnd < nsel; rnd++) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < SORT_N / 256; e++) {
+                const int gi = tid + 256 * e;
+                if (gi < V && (vals[e] > bv || (vals[e] == bv && gi < bi))) { bv = vals[e]; bi = gi; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((tid & 63) == 0) { wbest[tid >> 6] = bv; warg[tid >> 6] = bi; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float ov = wbest[w];
+                const int oi = warg[w];
+                if (w == 0 || ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bi == 0x7fffffff) bi = 0;                 // every remaining value is -inf
+            if ((bi & 255) == tid) {
+#pragma unroll
+                for (int e = 0; e < SORT_N / 256; e++) if (e == (bi >> 8)) vals[e] = -INFINITY;
+            }
+            if (tid == 0) { key[rnd] = bv; idx[rnd] = bi; }
+            __syncthreads();
+        }
+    } else
     // bitonic sort, descending by key, ties by ascending index
     for (int k = 2; k <= SORT_N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -280,11 +332,12 @@ extern "C" int mxl_decode_embed(const void* ids, int ld_ids, const int* t_dev, c
 }
 
 extern "C" int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev, int B, int M, int d, int dh,
-                             void* stream) {
+                             const float* r_r_bias, void* qr_out, void* stream) {
     MXL_CHECK_ARG(qkv && kcache && vcache && t_dev && B > 0 && M > 0 && (d % 8) == 0 && dh > 0 && (dh % 8) == 0 && (d % dh) == 0);
+    MXL_CHECK_ARG(!qr_out || r_r_bias);
     const int n = B * (d / 8);
     hipLaunchKernelGGL(kv_append_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)kcache, (bf16_t*)vcache, t_dev, B, M, d, dh);
+                       (bf16_t*)kcache, (bf16_t*)vcache, t_dev, B, M, d, dh, r_r_bias, (bf16_t*)qr_out);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

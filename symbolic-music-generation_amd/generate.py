@@ -100,9 +100,10 @@ class XLDecoder:
         for l in range(L):
             h_in, h_out = self.h[l & 1], self.h[(l + 1) & 1]
             G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
-            ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev)
+            rrb = e._lw(l, 'dec_attn.r_r_bias', e.P)
+            ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev, rrb=rrb.reshape(-1), qr_out=self.qr)
             ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
-                               e._lw(l, 'dec_attn.r_r_bias', e.P), self.av, self.t_dev, H, dh, self.qr, self.bd)
+                               rrb, self.av, self.t_dev, H, dh, self.qr, self.bd, qr_ready=True)
             G(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
             ops.ln_residual_fwd(self.tmp, h_in, e._lw(l, 'dec_attn.layer_norm.weight', e.P),
                                 e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)

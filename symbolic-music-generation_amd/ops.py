@@ -254,10 +254,12 @@ def decode_embed(ids, t_dev, E, out, scale):
                                  _stream()), 'mxl_decode_embed')
 
 
-def kv_append(qkv, kc, vc, t_dev):
-    """kc / vc: head-major rings (B, H, M, dh)"""
+def kv_append(qkv, kc, vc, t_dev, rrb=None, qr_out=None):
+    """kc / vc: head-major rings (B, H, M, dh).  With `rrb` (H*dh f32) and `qr_out` (B, H*dh) bf16 the same launch also writes
+    q + r_r_bias, the operand of the step's BD product (then pass qr_ready=True to relattn_decode)."""
     B, H, M, dh = kc.shape
-    check(lib().mxl_kv_append(_p(qkv), _p(kc), _p(vc), _p(t_dev), B, M, H * dh, dh, _stream()), 'mxl_kv_append')
+    check(lib().mxl_kv_append(_p(qkv), _p(kc), _p(vc), _p(t_dev), B, M, H * dh, dh, _p(rrb), _p(qr_out), _stream()),
+          'mxl_kv_append')
 
 
 def kv_fill(qkv, kc, vc, T):
@@ -265,12 +267,14 @@ def kv_fill(qkv, kc, vc, T):
     check(lib().mxl_kv_fill(_p(qkv), _p(kc), _p(vc), B, T, M, H * dh, dh, _stream()), 'mxl_kv_fill')
 
 
-def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf, scale=None):
-    """qr_buf (B, H*dh) bf16 and bd_buf (B, H, M) f32 are scratch: BD = (q + r_r_bias) . rd^T for the whole batch."""
+def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf, scale=None, qr_ready=False):
+    """qr_buf (B, H*dh) bf16 and bd_buf (B, H, M) f32 are scratch: BD = (q + r_r_bias) . rd^T for the whole batch.
+    qr_ready: qr_buf already holds q + r_r_bias (written by kv_append)."""
     B, _, M, _ = kc.shape
     d = H * dh
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
-    add_rowbias(qkv, 3 * d, 3 * d, rrb.reshape(-1), qr_buf, B, 1, d)
+    if not qr_ready:
+        add_rowbias(qkv, 3 * d, 3 * d, rrb.reshape(-1), qr_buf, B, 1, d)
     gemm_batched(qr_buf, rd, bd_buf, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=GEMM_OUT_F32, batch=H, bdiv=1,
                  sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
     check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(bd_buf), _p(rwb), _p(out), _p(t_dev), B, H, dh, M,
