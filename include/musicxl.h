@@ -249,9 +249,12 @@ int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_
  *   offsets : int32[B+1] element offsets into `tokens` (sequence b = [offsets[b], offsets[b+1]); may be empty or longer
  *             than max_length: truncated)
  *   ids_out, labels_out : (B, max_length) int64; labels may be NULL.  labels = ids with every pad_id -> -100.
+ *   remap (n_tables, v_src) int32 + row_table int32[B] (or both NULL): token v of row b becomes remap[row_table[b]][v]
+ *             (row_table[b] < 0: unchanged) -- the reference's step -> degree PitchShift (musicnlp/preprocess/transform.py:
+ *             154-237) is one such table per key.
  * ---------------------------------------------------------------------------------------------------------- */
 int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
-                       int max_length, long long pad_id, void* stream);
+                       int max_length, long long pad_id, const int* remap, const int* row_table, int v_src, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,28 +91,35 @@ extern "C" int mxl_eval_counts(const void* preds, int ld_preds, const void* labe
 namespace {
 template <typename TOK>
 __global__ __launch_bounds__(256) void pack_clm_kernel(const TOK* tok, const int* off, long long* ids, long long* labels, int B,
-                                                       int L, long long pad_id) {
+                                                       int L, long long pad_id, const int* remap, const int* row_table, int Vsrc) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)B * L) return;
     const int b = (int)(gid / L), t = (int)(gid % L);
     const int o0 = off[b], n = off[b + 1] - o0;
-    const long long v = (t < n) ? (long long)tok[o0 + t] : pad_id;
+    long long v = pad_id;
+    if (t < n) {
+        v = (long long)tok[o0 + t];
+        // step-pitch -> degree-pitch (and any other vocabulary change) as a table look-up: table row_table[b] of `remap`
+        if (remap && row_table[b] >= 0 && v >= 0 && v < Vsrc) v = remap[(size_t)row_table[b] * Vsrc + v];
+    }
     ids[gid] = v;
     if (labels) labels[gid] = (v == pad_id) ? -100 : v;
 }
 }  // namespace
 
 extern "C" int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
-                                  int max_length, long long pad_id, void* stream) {
+                                  int max_length, long long pad_id, const int* remap, const int* row_table, int v_src,
+                                  void* stream) {
     MXL_CHECK_ARG(tokens && offsets && ids_out && B > 0 && max_length > 0 && (elem_bytes == 2 || elem_bytes == 4));
+    MXL_CHECK_ARG(!remap || (row_table && v_src > 0));
     const long long n = (long long)B * max_length;
     const dim3 grid((unsigned)((n + 255) / 256));
     if (elem_bytes == 2)
         hipLaunchKernelGGL(pack_clm_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)tokens,
-                           offsets, (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id);
+                           offsets, (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id, remap, row_table, v_src);
     else
         hipLaunchKernelGGL(pack_clm_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, (const int*)tokens, offsets,
-                           (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id);
+                           (long long*)ids_out, (long long*)labels_out, B, max_length, pad_id, remap, row_table, v_src);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

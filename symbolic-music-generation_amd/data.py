@@ -11,6 +11,10 @@ asynchronous H2D copy on a side stream, and padded / truncated / labelled on the
                                                          the contract of dataset.py:361 + the collator at train.py:360
 
 Under data parallelism rank r takes the strided shard r, r + world, ... of the (optionally shuffled) order.
+
+On-the-fly augmentation happens on ids, not strings (`Augment`): RandomCrop at `<bar>` boundaries
+(musicnlp/preprocess/transform.py:59-114) is a choice of slice, KeyInsert (:138-151) one inserted id, and the step -> degree
+PitchShift (:154-237) an id -> id table per key applied by the pack kernel.
 """
 import json
 import os
@@ -20,6 +24,7 @@ import numpy as np
 import torch
 
 from ._lib import lib, check, MusicXLError
+from .vocab import KEY_NAMES
 
 
 def write_token_file(path: str, sequences: Iterable[Sequence[int]], vocab_size: int) -> int:
@@ -57,22 +62,107 @@ class TokenFile:
         return np.diff(self.offsets)
 
 
+
+_T0 = dict(C=0, D=1, E=2, F=3, G=4, A=5, B=6)            # musicnlp/preprocess/key_finder.py:199-207
+
+
+def pitch_shift_tables(vocab_step, vocab_degree) -> np.ndarray:
+    """(24, V_step) int32: table[key ordinal][step-vocabulary id] = degree-vocabulary id.  Pitch tokens `p_i/o_S` become
+    `p_i'/o'_deg` with deg = (t0[S] - t0[tonic letter]) % 7 + 1 (ScaleDegreeFinder.map_single, key_finder.py:245-262) and the
+    two out-of-range step tokens folded back by an octave (transform.py:184-191); every other token keeps its string and
+    changes id space only."""
+    import re
+    pat = re.compile(r'^p_(-?\d+)/(-?\d+)_([A-G])$')
+    V = len(vocab_step)
+    tab = np.zeros((len(KEY_NAMES), V), dtype=np.int32)
+    for o, key in enumerate(KEY_NAMES):
+        k0 = _T0[key[0]]
+        for i in range(V):
+            tok = vocab_step.i2t(i)
+            m = pat.match(tok)
+            if m is None:
+                tab[o, i] = vocab_degree.t2i(tok)
+                continue
+            midi = int(m.group(1)) - 1 + (int(m.group(2)) + 1) * 12
+            midi = midi + 12 if midi == -12 else (midi - 12 if midi == 131 else midi)
+            deg = (_T0[m.group(3)] - k0) % 7 + 1
+            tab[o, i] = vocab_degree.t2i(f'p_{(midi % 12) + 1}/{midi // 12 - 1}_{deg}')
+    return tab
+
+
+class Augment:
+    """Per-sequence augmentation on ids.  `keys[i]`: key name of sequence i ('CMajor', ...) or a {name: weight} dict to sample
+    from (KeyInsert with `pt_sample`); needed for key insertion and pitch shift."""
+
+    def __init__(self, tokenizer, random_crop: bool = False, min_seg_length: int = 16, crop_mult: int = 1,
+                 insert_key: bool = False, keys=None, pitch_shift: bool = False, tokenizer_degree=None, seed: int = 0):
+        v = tokenizer.vocab
+        self.bar_id, self.omit_id = v.t2i(v.start_of_bar), v.t2i(v.omitted_segment)
+        self.random_crop, self.min_seg_length, self.crop_mult = random_crop, min_seg_length, crop_mult
+        self.insert_key, self.keys, self.pitch_shift = insert_key, keys, pitch_shift
+        if (insert_key or pitch_shift) and keys is None:
+            raise ValueError('key insertion / pitch shift need the key(s) of every sequence')
+        if pitch_shift and not insert_key:
+            raise ValueError('PitchShift reads the key token at position 2: enable insert_key (transform.py:219-221)')
+        self.key_id = {k: v.t2i(f'Key_{k}') for k in KEY_NAMES}
+        self.tables = pitch_shift_tables(v, tokenizer_degree.vocab) if pitch_shift else None
+        self.rng = np.random.default_rng(seed)
+
+    def crop_high(self, n_bar: int) -> int:
+        if n_bar <= self.min_seg_length:
+            return 0
+        high = n_bar - self.min_seg_length
+        if self.crop_mult == 1:
+            return high
+        return high // self.crop_mult if high >= self.crop_mult else 0
+
+    def pieces(self, i: int, seq: np.ndarray, crop_idx: Optional[int] = None, key: Optional[str] = None):
+        """-> (list of int arrays whose concatenation is the augmented sequence, key ordinal or -1).  `crop_idx` / `key`
+        override the random draws (tests)."""
+        parts = [seq]
+        if self.random_crop:
+            bars = np.flatnonzero(seq == self.bar_id)
+            high = self.crop_high(len(bars))
+            if crop_idx is None:
+                crop_idx = int(self.rng.integers(0, high + 1)) * (1 if self.crop_mult == 1 else self.crop_mult) if high > 0 else 0
+            if high > 0 and crop_idx != 0:
+                parts = [seq[:bars[0]], np.asarray([self.omit_id], dtype=seq.dtype), seq[bars[crop_idx]:]]
+        ordinal = -1
+        if self.insert_key:
+            if key is None:
+                k = self.keys[i]
+                if isinstance(k, dict):
+                    names = list(k)
+                    w = np.asarray([k[n] for n in names], dtype=np.float64)
+                    k = names[int(self.rng.choice(len(names), p=w / w.sum()))]
+                key = k
+            ordinal = KEY_NAMES.index(key)
+            head = parts[0]
+            parts = [head[:2], np.asarray([self.key_id[key]], dtype=seq.dtype), head[2:]] + parts[1:]
+        return parts, (ordinal if self.pitch_shift else -1)
+
 class DeviceBatcher:
     """Double-buffered: while the model works on batch k, batch k+1 is being gathered into the other pinned buffer and copied."""
 
     def __init__(self, tf: TokenFile, batch_size: int, max_length: int, pad_id: int, device, shuffle: bool = False,
-                 seed: int = 0, rank: int = 0, world: int = 1, drop_last: bool = False):
+                 seed: int = 0, rank: int = 0, world: int = 1, drop_last: bool = False, augment: Optional[Augment] = None):
         if not torch.cuda.is_available():
             raise MusicXLError('DeviceBatcher needs a GPU (the pad/label step is a device kernel; no CPU fallback)')
         self.tf, self.B, self.L, self.pad_id = tf, batch_size, max_length, pad_id
         self.dev = torch.device(device)
         self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, seed, rank, world, drop_last
+        self.augment = augment
         self.epoch = 0
         tdt = torch.uint16 if tf.dtype == np.uint16 else torch.int32
         self._pin_tok = [torch.empty(batch_size * max_length, dtype=tdt).pin_memory() for _ in range(2)]
         self._pin_off = [torch.empty(batch_size + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
         self._dev_tok = [torch.empty(batch_size * max_length, dtype=tdt, device=self.dev) for _ in range(2)]
         self._dev_off = [torch.empty(batch_size + 1, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self._pin_tab = [torch.empty(batch_size, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._dev_tab = [torch.empty(batch_size, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self._remap = None
+        if augment is not None and augment.tables is not None:
+            self._remap = torch.from_numpy(augment.tables).to(self.dev)
         self._copy_stream = torch.cuda.Stream(device=self.dev)
         self._done = [torch.cuda.Event(), torch.cuda.Event()]       # buffer consumed by the pack kernel
         self._first = [True, True]
@@ -96,14 +186,25 @@ class DeviceBatcher:
         off = self._pin_off[slot].numpy()
         pos = 0
         off[0] = 0
+        tab = self._pin_tab[slot].numpy()
         for j, i in enumerate(rows):
-            a = self.tf[int(i)][:self.L]
-            tok[pos:pos + a.size] = a
-            pos += a.size
+            if self.augment is None:
+                parts, tab[j] = [self.tf[int(i)]], -1
+            else:
+                parts, tab[j] = self.augment.pieces(int(i), self.tf[int(i)])
+            room = self.L
+            for a in parts:                                   # truncation=True: the first max_length tokens of the result
+                a = a[:room]
+                tok[pos:pos + a.size] = a
+                pos += a.size
+                room -= a.size
+                if room == 0:
+                    break
             off[j + 1] = pos
         with torch.cuda.stream(self._copy_stream):
             self._dev_tok[slot][:max(pos, 1)].copy_(self._pin_tok[slot][:max(pos, 1)], non_blocking=True)
             self._dev_off[slot][:len(rows) + 1].copy_(self._pin_off[slot][:len(rows) + 1], non_blocking=True)
+            self._dev_tab[slot][:len(rows)].copy_(self._pin_tab[slot][:len(rows)], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
         return ev, len(rows)
@@ -124,6 +225,9 @@ class DeviceBatcher:
             labels = torch.empty_like(ids)
             check(lib().mxl_pack_clm_batch(self._dev_tok[slot].data_ptr(), self.tf.dtype.itemsize, self._dev_off[slot].data_ptr(),
                                            ids.data_ptr(), labels.data_ptr(), nrow, self.L, self.pad_id,
+                                           self._remap.data_ptr() if self._remap is not None else None,
+                                           self._dev_tab[slot].data_ptr() if self._remap is not None else None,
+                                           self._remap.shape[1] if self._remap is not None else 0,
                                            torch.cuda.current_stream(self.dev).cuda_stream), 'mxl_pack_clm_batch')
             self._done[slot].record(torch.cuda.current_stream(self.dev))
             yield ids, labels

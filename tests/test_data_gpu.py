@@ -66,3 +66,31 @@ def test_batcher_feeds_the_model_on_reference_scores(tmp_path):
     model = MyTransfoXLLMHeadModel(cfg, device=torch.device('cuda:0'), seed=1).eval()
     losses = [model(input_ids=x, labels=y).loss.item() for x, y in db]
     assert len(losses) == 2 and all(np.isfinite(losses)) and all(5.0 < v < 9.0 for v in losses)     # ~ln(1190) at init
+
+
+def test_device_batcher_with_augmentation(tmp_path):
+    """crop + key insert on the host slices, step -> degree table on the device: the batch equals the string-level transforms of
+    the reference followed by the pad / label contract"""
+    from oracle import augment_ref as A
+    from symbolic_music_generation_amd.data import Augment, DeviceBatcher, TokenFile, write_token_file
+    from symbolic_music_generation_amd.vocab import MusicTokenizer
+    ts, td = MusicTokenizer(pitch_kind='step'), MusicTokenizer(pitch_kind='degree')
+    ids = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample_score_ids.npz'))['sample_full_step'].astype(np.int64)
+    songs = [ids, ids[:1500], ids[:400]]
+    keys = ['GMajor', 'EbMinor', 'CMajor']
+    write_token_file(str(tmp_path / 'st'), songs, vocab_size=len(ts.vocab))
+    aug = Augment(ts, random_crop=True, insert_key=True, keys=keys, pitch_shift=True, tokenizer_degree=td, seed=9)
+    L, pad = 1024, td.vocab.t2i('[PAD]')
+    db = DeviceBatcher(TokenFile(str(tmp_path / 'st')), batch_size=3, max_length=L, pad_id=pad, device='cuda:0', augment=aug)
+    # replay the batcher's random crop draws with an identically seeded generator
+    rng = np.random.default_rng(9)
+    want = []
+    for s, key in zip(songs, keys):
+        toks = [ts.vocab.i2t(int(i)) for i in s]
+        high = A.crop_high(toks)
+        idx = int(rng.integers(0, high + 1)) if high > 0 else 0
+        out = A.pitch_shift(A.key_insert(A.random_crop(toks, idx), key))
+        want.append([td.vocab.t2i(t) for t in out])
+    ref_ids, ref_lab = pad_and_label(want, L, pad)
+    (got_ids, got_lab), = list(db)
+    assert np.array_equal(got_ids.cpu().numpy(), ref_ids) and np.array_equal(got_lab.cpu().numpy(), ref_lab)
