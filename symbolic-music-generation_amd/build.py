@@ -14,6 +14,11 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libmusicxl.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-ffp-contract=fast']
+# per-file extras.  relattn_bwd.hip: the query-owner kernel runs one workgroup per CU with > 256 registers; by default hipcc then
+# gives EVERY MFMA an AGPR destination and pays ~220 v_accvgpr_write/read per tile to zero the S / dP / G accumulators and to bring
+# the results back for the VALU work.  With VGPR-form MFMAs the AGPRs only hold the few values that do not fit (593 -> 204 such
+# moves in the kernel, 338 -> 303 registers, no scratch).
+EXTRA_FLAGS = {'relattn_bwd.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _newer(src, dst, deps):
@@ -33,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')
         objs.append(obj)
         if force or _newer(src, obj, hdrs):
-            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
