@@ -14,11 +14,13 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libmusicxl.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-ffp-contract=fast']
-# per-file extras.  relattn_bwd.hip: the query-owner kernel runs one workgroup per CU with > 256 registers; by default hipcc then
-# gives EVERY MFMA an AGPR destination and pays ~220 v_accvgpr_write/read per tile to zero the S / dP / G accumulators and to bring
-# the results back for the VALU work.  With VGPR-form MFMAs the AGPRs only hold the few values that do not fit (593 -> 204 such
-# moves in the kernel, 338 -> 303 registers, no scratch).
-EXTRA_FLAGS = {'relattn_bwd.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+# VGPR-form MFMAs everywhere.  By default hipcc gives every MFMA of a kernel that exceeds 256 registers an AGPR destination; the
+# attention-backward query-owner kernel (one workgroup per CU, > 256 registers) then pays ~220 v_accvgpr_write/read per tile to
+# zero the S / dP / G accumulators and to bring the results back for the VALU work.  With VGPR-form MFMAs the AGPRs only hold the
+# few values that do not fit (593 -> 204 such moves in that kernel, 338 -> 303 registers, no scratch); the other kernels are
+# unchanged or slightly better.
+FLAGS += ['-mllvm', '-amdgpu-mfma-vgpr-form']
+EXTRA_FLAGS = {}
 
 
 def _newer(src, dst, deps):
