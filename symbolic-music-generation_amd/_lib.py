@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmusicxl.so')
+LIB_PATH = os.environ.get('MXL_LIB_PATH') or os.path.join(_HERE, 'libmusicxl.so')   # override: A/B builds of the library
 HEADER_PATH = os.path.join(_HERE, '..', 'include', 'musicxl.h')
 
 _lib = None
