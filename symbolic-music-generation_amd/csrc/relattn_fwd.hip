@@ -97,6 +97,14 @@ __device__ __forceinline__ float add_f16(float s, uint32_t h16) {
     return r;
 }
 
+// max(a, b, c) in one issue, without the canonicalising v_max_f32 x, x that fmaxf() gets in front of values produced by inline
+// asm (the scores come out of v_fma_mix): 16 instead of 56 VALU issues for the 32 scores of a tile
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 constexpr float RESCALE_THRESH = 8.0f;   // log2 units: accumulators are re-based when a score exceeds the reference by 2^8
 
 template <int DH>
@@ -259,9 +267,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                             g[j] = valid ? g[j] : NEG_BIG;
                         }
                     }
-                    float mx = fmaxf(g[0], g[1]);
+                    float mx = NEG_BIG;
 #pragma unroll
-                    for (int j = 2; j < 16; j += 2) mx = fmaxf(mx, fmaxf(g[j], g[j + 1]));
+                    for (int j = 0; j < 16; j += 2) mx = max3(mx, g[j], g[j + 1]);
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     const bool unset = m_run == NEG_BIG;
                     const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                         s[kb][j] = val;
                     }
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) mx = fmaxf(mx, fmaxf(s[kb][j], s[kb][j + 1]));
+                    for (int j = 0; j < 16; j += 2) mx = max3(mx, s[kb][j], s[kb][j + 1]);
                 }
             };
             if (full) scores(std::false_type{}); else scores(std::true_type{});
