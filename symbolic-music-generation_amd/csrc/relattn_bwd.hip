@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
     bf16_t* myDG = sDG + wid * 32 * DGS + r * DGS;                 // row of this lane's query
     const uint32_t dgWb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(myDG + r + 64 - 4 * hh - 27);
     f16x4 carry[4];
+    // Rd ring fragments: slot = (16-aligned window base + r) & 255, so the XOR-swizzle term of its row depends on the lane only
+    int rswz[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) rswz[ks] = (DH == 64) ? (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4) : ((2 * ks + hh) << 4);
 
     const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
     const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                     const int slot = (dblk + r) & 255;
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
                         g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                     __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                     }
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                 const int slot = (dlo + 32 * gb + r) & 255;
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                 __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                 }

@@ -133,6 +133,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     // LDS byte address of column (r - 4hh + 64 - 27) for skew_read16 (key block kb subtracts 32 columns = 64 bytes)
     const uint32_t gRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(gR - 27);
     f16x4 carry[4];   // block 0 of the previous tile (= block 2 of this one), kept in registers
+    // Rd ring fragments: slot = (16-aligned window base + r) & 255, so the XOR-swizzle term of its row depends on the lane only
+    int rswz[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) rswz[ks] = (DH == 64) ? (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4) : ((2 * ks + hh) << 4);
 
     const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
     const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     const int slot = (dblk + r) & 255;
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
                         g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                     __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                     }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 const int slot = (dlo + 32 * gb + r) & 255;
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + G::koff(slot, 2 * ks + hh));
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                 __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                 }
