@@ -94,3 +94,23 @@ def test_rel_shift_identity_and_window():
         a, la = relattn_dense(q, zk, zv, rd, att.r_w_bias, att.r_r_bias, M)
         b_, lb = relattn_dense(q, zk[:, M:], zv[:, M:], rd, att.r_w_bias, att.r_r_bias, M)
     assert torch.allclose(a, b_, atol=1e-6) and torch.allclose(la, lb, atol=1e-6)
+
+
+def test_oracle_reproduces_its_committed_selfgolden():
+    """tests/golden/xl_c1_selfgolden.pt (made by tests/golden/make_xl_selfgoldens.py) freezes the restatement's outputs: an edit
+    to the oracle has to show up here"""
+    import os
+    import torch
+    from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
+    blob = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'xl_c1_selfgolden.pt'), weights_only=False)
+    m = RefTransfoXLLMHeadModel(RefXLConfig.from_preset('debug', **blob['config'])).eval()
+    m.load_state_dict(blob['state_dict'])
+    ids, labels = blob['ids'], blob['labels']
+    with torch.no_grad():
+        o1 = m(ids[:, :64], labels=labels[:, :64])
+        o2 = m(ids[:, 64:], mems=o1.mems, labels=labels[:, 64:])
+        gen = m.greedy_generate(ids[:, :24], max_length=88)
+    assert (o1.prediction_scores - blob['logp1'].float()).abs().max().item() < 2e-2      # stored in fp16
+    assert (o2.prediction_scores - blob['logp2'].float()).abs().max().item() < 2e-2
+    assert abs(o1.loss.item() - blob['loss1'].item()) < 1e-5 and abs(o2.loss.item() - blob['loss2'].item()) < 1e-5
+    assert torch.equal(gen, blob['greedy'])
