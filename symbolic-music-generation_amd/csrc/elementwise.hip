@@ -136,10 +136,11 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
 
 // backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dres = dz (+ dres_in);  dx = keep*dscale*dz
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy : per-block partials through LDS, then one fp32 atomic per column.
-constexpr int LNB_ROWS = 64;  // rows per block (4 waves x 16 rows): 2d atomics per block
+constexpr int LNB_ROWS = 64;  // rows per block (8 waves x 8 rows): 2d atomics per block, 4096 waves for the 32768-row C3 matrices
+constexpr int LNB_THREADS = 512;
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
+__global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, int N,
                                                          int d, unsigned thresh, float dscale, unsigned long long seed,
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [d] dgamma partial
     float* sb = sg + d;                              // [d] dbeta partial
-    for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * d; i += LNB_THREADS) sg[i] = 0.f;
     __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunks = d >> 3;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
     for (int i = 0; i < NCH; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
-    for (int rr = 0; rr < LNB_ROWS / 4; rr++) {
-        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
+    for (int rr = 0; rr < LNB_ROWS / (LNB_THREADS / 64); rr++) {
+        const int row = blockIdx.x * LNB_ROWS + rr * (LNB_THREADS / 64) + wid;
         if (row >= N) break;
         const float mu = mean[row], rs = rstd[row];
         float g[NCH][8], xh[NCH][8];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const bf16_t* dy, const
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += 256) {
+    for (int i = threadIdx.x; i < d; i += LNB_THREADS) {
         atomicAdd(dgamma + i, sg[i]);
         atomicAdd(dbeta + i, sb[i]);
     }
@@ -393,7 +394,7 @@ extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* 
                                    float drop_p, unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
     const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
-    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr);
@@ -406,7 +407,7 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
                                        int d, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dres && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
     const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
-    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 2 * d * sizeof(float),
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
     MXL_LAUNCH_CHECK();
