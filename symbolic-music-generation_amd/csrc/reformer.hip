@@ -61,6 +61,7 @@ __global__ void axial_embed_bwd_kernel(const long long* ids, const bf16_t* dout,
 constexpr int MAX_R2 = 64;
 struct HashGeom { int nfac; int fac[4]; };
 
+template <int RP>   // accumulators per thread: R2 rounded up to 16 / 32 / 64 (the C4 shape, 256 buckets = 16 x 16, has R2 = 16)
 __global__ __launch_bounds__(256) void lsh_hash_kernel(const bf16_t* qk, long long bs, int rs, const float* rot, int* buckets,
                                                        int B, int T, int H, int dh, int n_h, int R2, int NB, HashGeom g) {
     extern __shared__ float srot[];  // [dh][R2] for this (h, round)
@@ -72,15 +73,22 @@ __global__ __launch_bounds__(256) void lsh_hash_kernel(const bf16_t* qk, long lo
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    float acc[MAX_R2];
+    float acc[RP];
 #pragma unroll
-    for (int c = 0; c < MAX_R2; c++) acc[c] = 0.f;
+    for (int c = 0; c < RP; c++) acc[c] = 0.f;
     const bf16_t* x = qk + (size_t)b * bs + (size_t)t * rs + h * dh;
-    for (int e = 0; e < dh; e++) {
-        const float xv = bf2f(x[e]);
+    // the row is read in 16-byte pieces (2-byte loads at a row pitch fetch one cache line per element); the FMA order over e
+    // is unchanged, so bucket ids do not move
+    for (int e8 = 0; e8 < dh; e8 += 8) {
+        const bf16x8 xq = *reinterpret_cast<const bf16x8*>(x + e8);
 #pragma unroll
-        for (int c = 0; c < MAX_R2; c++)
-            if (c < R2) acc[c] = fmaf(xv, srot[e * R2 + c], acc[c]);
+        for (int j = 0; j < 8; j++) {
+            const float xv = bf2f((bf16_t)xq[j]);
+            const float* rr = srot + (e8 + j) * R2;
+#pragma unroll
+            for (int c = 0; c < RP; c++)
+                if (c < R2) acc[c] = fmaf(xv, rr[c], acc[c]);
+        }
     }
     int bucket = 0, cur = 0, prod = 1;
     for (int f = 0; f < g.nfac; f++) {
@@ -89,10 +97,10 @@ __global__ __launch_bounds__(256) void lsh_hash_kernel(const bf16_t* qk, long lo
         float best = -INFINITY;
         int arg = 0;
 #pragma unroll
-        for (int c = 0; c < MAX_R2; c++)
+        for (int c = 0; c < RP; c++)
             if (c >= cur && c < cur + half) { const float v = acc[c]; if (v > best) { best = v; arg = c - cur; } }
 #pragma unroll
-        for (int c = 0; c < MAX_R2; c++)
+        for (int c = 0; c < RP; c++)
             if (c >= cur && c < cur + half) { const float v = -acc[c]; if (v > best) { best = v; arg = half + c - cur; } }
         bucket += prod * arg;
         prod *= g.fac[f];
@@ -946,7 +954,8 @@ extern "C" int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* r
         g.fac[i] = factors_host[i]; R2 += factors_host[i] / 2; NB *= factors_host[i];
     }
     MXL_CHECK_ARG(R2 <= MAX_R2 && (size_t)dh * R2 * 4 <= 48 * 1024);
-    hipLaunchKernelGGL(lsh_hash_kernel, dim3((T + 255) / 256, H * n_h, B), dim3(256), (size_t)dh * R2 * 4, (hipStream_t)stream,
+    const auto kfn = R2 <= 16 ? lsh_hash_kernel<16> : R2 <= 32 ? lsh_hash_kernel<32> : lsh_hash_kernel<64>;
+    hipLaunchKernelGGL(kfn, dim3((T + 255) / 256, H * n_h, B), dim3(256), (size_t)dh * R2 * 4, (hipStream_t)stream,
                        (const bf16_t*)qk, bs, rs, rotations, buckets, B, T, H, dh, n_h, R2, NB, g);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
