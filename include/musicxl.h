@@ -180,12 +180,14 @@ int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M
  * positional term for the whole batch (one mxl_gemm_bf16_batched per layer over heads); out (B, H*dh) bf16 */
 int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
                        void* out, const int* t_dev, int B, int H, int dh, int M, float scale, void* stream);
-/* next token from log-probs (B, ldl): greedy argmax (do_sample=0) or temperature -> top-k -> top-p -> renormalise ->
- * multinomial (do_sample=1), as HF's logits warpers with renormalize_logits=True (musicnlp/trainer/eval.py:277-326).
+/* next token from log-probs (B, ldl): repetition penalty over the ids already in the row (positions 0..*t_dev; HF's
+ * RepetitionPenaltyLogitsProcessor, 1.0 = off), then greedy argmax (do_sample=0) or temperature -> top-k -> top-p ->
+ * typical-p (HF's TypicalLogitsWarper, 1.0 = off) -> renormalise -> multinomial (do_sample=1), as HF's logits warpers with
+ * renormalize_logits=True -- the `sample` strategy's accepted keys at musicnlp/trainer/eval.py:277-326.
  * V <= 2048.  out_probs (B, V) f32 optional: the renormalised distribution actually sampled from (test hook). */
 int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, const int* t_dev,
                unsigned long long* rng_ctr, unsigned long long seed, int B, int do_sample, int top_k, float top_p,
-               float temperature, float* out_probs, void* stream);
+               float temperature, float repetition_penalty, float typical_p, float* out_probs, void* stream);
 /* t_dev += 1; rng_ctr += 1 */
 int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream);
 

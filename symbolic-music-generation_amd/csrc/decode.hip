@@ -190,16 +190,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// sampler: HF GenerationMixin.sample / greedy_search on log-probs (B, V): temperature -> top-k -> top-p ->
-// renormalise -> multinomial (musicnlp/trainer/eval.py:277-333 builds these arguments).  One workgroup per row;
-// bitonic sort of (value, index) in LDS (V <= 2048).  greedy = argmax (ties -> lowest index, like torch.argmax).
+// sampler: HF GenerationMixin.sample / greedy_search on log-probs (B, V): repetition penalty (logits processor, over every
+// token already in the row) -> temperature -> top-k -> top-p -> typical-p -> renormalise -> multinomial
+// (musicnlp/trainer/eval.py:277-333 builds these arguments).  One workgroup per row; bitonic sort of (value, index) in LDS
+// (V <= 2048).  greedy = argmax (ties -> lowest index, like torch.argmax).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int SORT_N = 2048;
 
 __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl, int V, long long* ids, int ld_ids,
                                                      const int* t_dev, unsigned long long* rng_ctr, unsigned long long seed,
                                                      int do_sample, int top_k, float top_p, float temperature,
-                                                     float* out_probs) {
+                                                     float repetition_penalty, float typical_p, float* out_probs) {
     __shared__ float key[SORT_N];
     __shared__ int idx[SORT_N];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -210,6 +211,21 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
         idx[i] = i;
     }
     __syncthreads();
+    if (repetition_penalty != 1.f) {
+        // HF RepetitionPenaltyLogitsProcessor: every id present in the row so far (prompt + generated, positions 0..t) has its
+        // raw score multiplied (score < 0) or divided (score >= 0) by the penalty, once however often it occurs -- the writes
+        // below all store the same value, so duplicates are harmless.
+        const int tcur = *t_dev;
+        const long long* hist = ids + (size_t)b * ld_ids;
+        for (int j = tid; j <= tcur; j += 256) {
+            const long long tok = hist[j];
+            if (tok >= 0 && tok < V) {
+                const float v = row[tok];
+                key[tok] = (v < 0.f ? v * repetition_penalty : v / repetition_penalty) * invt;
+            }
+        }
+        __syncthreads();
+    }
     // Small supports (greedy, or top-k <= 64) need only the first few entries of the sorted order: take them by repeated
     // workgroup arg-max (same order as the sort: value descending, ties by ascending index) -- 2 barriers per entry instead of
     // the 66 barrier stages of the full sort.
@@ -277,6 +293,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
         return;
     }
     int keep = (top_k > 0 && top_k < V) ? top_k : V;
+    __shared__ int sh_keep;
+    __shared__ float sh_sum, sh_max;       // the head of the order can itself be dropped as atypical: keep its value
     // softmax over the kept prefix (max is key[0]); serial prefix over <= V terms by one thread is negligible here
     if (tid == 0) {
         const float m = key[0];
@@ -295,17 +313,76 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
             s = 0.f;
             for (int i = 0; i < keep; i++) s += __expf(key[i] - m);
         }
+        sh_keep = keep;
+        sh_sum = s;
+        sh_max = m;
+    }
+    if (typical_p > 0.f && typical_p < 1.f) {
+        // HF TypicalLogitsWarper on the surviving support: order the tokens by |-log p - H| ascending and keep the shortest
+        // prefix of that order whose mass reaches typical_p, i.e. token i stays iff the mass of the tokens ordered before it
+        // is below typical_p.  No second sort: each thread accumulates that "mass before" for its own entries.
+        __shared__ float pp[SORT_N], dev[SORT_N];
+        __shared__ float red[4];
+        __syncthreads();
+        keep = sh_keep;
+        const float m = sh_max, logs = __logf(sh_sum);
+        float part = 0.f;
+        for (int i = tid; i < keep; i += 256) {
+            const float nl = key[i] - m - logs;
+            const float p = __expf(nl);
+            pp[i] = p;
+            if (p > 0.f) part -= p * nl;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        const float ent = red[0] + red[1] + red[2] + red[3];
+        for (int i = tid; i < keep; i += 256) dev[i] = fabsf(-(key[i] - m - logs) - ent);
+        __syncthreads();
+        bool drop[SORT_N / 256];
+#pragma unroll
+        for (int e = 0; e < SORT_N / 256; e++) {
+            const int i = tid + 256 * e;
+            drop[e] = false;
+            if (i < keep) {
+                const float di = dev[i];
+                float before = 0.f;
+                for (int j = 0; j < keep; j++) {
+                    const float dj = dev[j];
+                    before += (dj < di || (dj == di && j < i)) ? pp[j] : 0.f;
+                }
+                drop[e] = before >= typical_p;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < SORT_N / 256; e++)
+            if (drop[e]) key[tid + 256 * e] = -INFINITY;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int i = 0; i < keep; i++) s += __expf(key[i] - m);
+            sh_sum = s;
+        }
+    }
+    if (tid == 0) {
+        keep = sh_keep;
+        const float m = sh_max, s = sh_sum;
         // uniform in [0,1) from a counter-based hash (counter advanced by the advance kernel)
         const unsigned long long ctr = *rng_ctr;
         const uint32_t h1 = mxl_hash32((uint32_t)(ctr * 0x9E3779B97F4A7C15ULL >> 32) ^ mxl_hash32((uint32_t)b + 0x85ebca6bU * (uint32_t)seed));
         const uint32_t h2 = mxl_hash32(h1 + (uint32_t)ctr + (uint32_t)(seed >> 32));
         const float u = (float)(h2 >> 8) * (1.0f / 16777216.0f);
         float c = 0.f;
-        int pick = keep - 1;
+        int pick = -1, last = 0;
         for (int i = 0; i < keep; i++) {
-            c += __expf(key[i] - m) / s;
-            if (u < c) { pick = i; break; }
+            const float p = __expf(key[i] - m) / s;
+            if (p > 0.f) last = i;
+            c += p;
+            if (u < c && p > 0.f) { pick = i; break; }
         }
+        if (pick < 0) pick = last;
         *dst = idx[pick];
         if (out_probs) {   // diagnostic / test hook: renormalised probabilities of the kept support, in vocab order
             for (int i = 0; i < V; i++) out_probs[(size_t)b * V + i] = 0.f;
@@ -374,10 +451,11 @@ extern "C" int mxl_relattn_decode(const void* qkv, const void* kcache, const voi
 
 extern "C" int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, const int* t_dev,
                           unsigned long long* rng_ctr, unsigned long long seed, int B, int do_sample, int top_k, float top_p,
-                          float temperature, float* out_probs, void* stream) {
+                          float temperature, float repetition_penalty, float typical_p, float* out_probs, void* stream) {
     MXL_CHECK_ARG(logprobs && ids && t_dev && rng_ctr && B > 0 && V > 0 && V <= SORT_N && temperature > 0.f);
+    MXL_CHECK_ARG(repetition_penalty > 0.f && typical_p > 0.f);
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logprobs, ldl, V, (long long*)ids, ld_ids,
-                       t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature, out_probs);
+                       t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature, repetition_penalty, typical_p, out_probs);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

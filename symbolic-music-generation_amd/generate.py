@@ -6,8 +6,8 @@ reference calls it (musicnlp/trainer/eval.py:277-333; HF 4.25.1 GenerationMixin.
             -> sampler -> advance]            one hipGraph replay per token, no host round trip
 
 Strategies mirrored from `MusicGenerator` (eval.py:277-326): greedy (do_sample=False) and sampling with
-`top_k`, `top_p`, `temperature` and renormalised logits.  `repetition_penalty` / `typical_p` / beam / contrastive search
-are accepted by the reference's argument checker but are out of this round's scope and raise.
+`top_k`, `top_p`, `typical_p`, `temperature`, `repetition_penalty` and renormalised logits -- every key the `sample`
+strategy accepts (eval.py:279).  Beam / contrastive search are out of this round's scope and raise.
 """
 import math
 from typing import Optional
@@ -124,13 +124,15 @@ class XLDecoder:
 
     # ---------------------------------------------------------------- loop
     def generate(self, prompt: torch.Tensor, max_length: int, do_sample: bool = False, top_k: Optional[int] = None,
-                 top_p: Optional[float] = None, temperature: float = 1.0, use_graph: bool = True) -> torch.Tensor:
+                 top_p: Optional[float] = None, temperature: float = 1.0, repetition_penalty: Optional[float] = None,
+                 typical_p: Optional[float] = None, use_graph: bool = True) -> torch.Tensor:
         """Returns (B, max_length) ids = prompt + continuation.  Like the reference (eos_token_id stays HF's default 0 =
         [OMIT]) decoding runs to max_length."""
         if max_length > self.Tmax:
             raise MusicXLError(f'max_length {max_length} exceeds the decoder buffer {self.Tmax}')
         sampling = dict(do_sample=do_sample, top_k=top_k or 0, top_p=top_p if top_p is not None else 1.0,
-                        temperature=temperature)
+                        temperature=temperature, repetition_penalty=1.0 if repetition_penalty is None else repetition_penalty,
+                        typical_p=1.0 if typical_p is None else typical_p)
         Tp = prompt.shape[1]
         n_new = max_length - Tp
         if n_new <= 0:

@@ -281,11 +281,13 @@ def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf,
                                    float(scale), _stream()), 'mxl_relattn_decode')
 
 
-def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=1.0, temperature=1.0, out_probs=None):
+def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=1.0, temperature=1.0,
+           repetition_penalty=1.0, typical_p=1.0, out_probs=None):
     B, V = logprobs.shape
     check(lib().mxl_sample(_p(logprobs), logprobs.stride(0), V, _p(ids), ids.stride(0), _p(t_dev), _p(rng_ctr), seed, B,
                            int(do_sample), int(top_k or 0), float(top_p if top_p is not None else 1.0),
-                           float(temperature), _p(out_probs), _stream()), 'mxl_sample')
+                           float(temperature), float(repetition_penalty if repetition_penalty is not None else 1.0),
+                           float(typical_p if typical_p is not None else 1.0), _p(out_probs), _stream()), 'mxl_sample')
 
 
 def decode_advance(t_dev, rng_ctr):

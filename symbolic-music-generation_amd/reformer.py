@@ -163,9 +163,10 @@ class MyReformerModelWithLMHead:
 
     @torch.no_grad()
     def generate(self, input_ids=None, max_length: Optional[int] = None, do_sample: bool = False, top_k: Optional[int] = None,
-                 top_p: Optional[float] = None, temperature: float = 1.0, seed: int = 77, **unsupported):
+                 top_p: Optional[float] = None, temperature: float = 1.0, repetition_penalty: Optional[float] = None,
+                 typical_p: Optional[float] = None, seed: int = 77, **unsupported):
         """`model.generate(...)` as the reference drives it (musicnlp/trainer/eval.py:277-333): greedy, or sampling with
-        top-k / top-p / temperature.  Every step is a full forward over the tokens so far -- the result HF's cached decoding
+        top-k / top-p / typical-p / temperature / repetition penalty (applied, as HF does, to the raw logits).  Every step is a full forward over the tokens so far -- the result HF's cached decoding
         reproduces for local layers and, for LSH layers, the same procedure with the hash rotations redrawn each forward (what
         HF does with `hash_seed=None`).  Beyond one chunk the sequence is right-padded to a multiple of the chunk length as HF
         does in eval mode (`_pad_to_mult_of_chunk_length`); pads sit after every real token, so the causal mask alone keeps
@@ -193,14 +194,13 @@ class MyReformerModelWithLMHead:
         buf[:, :Tp] = ids0
         t_dev = torch.full((1,), Tp - 1, device=self.device, dtype=torch.int32)
         rng = torch.zeros(1, device=self.device, dtype=torch.int64)
-        logp = torch.empty(B, V, device=self.device, dtype=torch.float32)
         for cur in range(Tp, max_length):
             Tf = cur if cur <= 64 else (cur + 63) // 64 * 64
             out = self.engine.forward(buf[:, :Tf].contiguous(), labels=None, train=False)
             last = out['logits'][:, cur - 1].contiguous()
-            ops.adaptive_logprob(last, logp, B, V, ())
-            ops.sample(logp, buf, t_dev, rng, seed, do_sample=do_sample, top_k=top_k or 0,
-                       top_p=top_p if top_p is not None else 1.0, temperature=temperature)
+            ops.sample(last, buf, t_dev, rng, seed, do_sample=do_sample, top_k=top_k or 0,
+                       top_p=top_p if top_p is not None else 1.0, temperature=temperature,
+                       repetition_penalty=repetition_penalty, typical_p=typical_p)
             ops.decode_advance(t_dev, rng)
             if Tf > cur:
                 buf[:, cur + 1:Tf] = pad          # keep the padding clean (the sampler wrote position `cur` only)

@@ -212,8 +212,6 @@ class MyTransfoXLLMHeadModel:
         from .generate import XLDecoder
         if num_beams != 1 or penalty_alpha is not None:
             raise NotImplementedError('beam / contrastive search are out of scope for the HIP decode path (SURVEY 8: A10)')
-        if typical_p is not None or (repetition_penalty not in (None, 1.0)):
-            raise NotImplementedError('typical_p / repetition_penalty are not implemented in the on-device sampler')
         max_length = max_length or self.config.max_length_
         B = input_ids.shape[0]
         dec = getattr(self, '_decoder', None)
@@ -221,7 +219,8 @@ class MyTransfoXLLMHeadModel:
             dec = self._decoder = XLDecoder(self.engine, B, max_length, seed=seed)
         dec.invalidate_tables()
         return dec.generate(input_ids.to(self.device), max_length, do_sample=do_sample, top_k=top_k, top_p=top_p,
-                            temperature=temperature, use_graph=use_graph)
+                            temperature=temperature, repetition_penalty=repetition_penalty, typical_p=typical_p,
+                            use_graph=use_graph)
 
     # -- training hooks used by the trainer
     def backward(self, grad_scale: float = 1.0, layer_done=None):

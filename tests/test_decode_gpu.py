@@ -85,3 +85,70 @@ def test_sampler_distribution(dev):
     # greedy = argmax
     ops.sample(lp, ids, t, rng, 7, do_sample=False)
     assert torch.equal(ids[:, 1].cpu(), logp.argmax(-1))
+
+
+def test_sampler_repetition_penalty_and_typical_p_vs_hf_processors(dev):
+    """The remaining keys of the reference's `sample` strategy (eval.py:279): the sampler's filtered distribution against HF's
+    own RepetitionPenaltyLogitsProcessor / TypicalLogitsWarper (the installed `transformers`, an external implementation),
+    chained in GenerationMixin's order: penalty -> temperature -> top-k -> top-p -> typical-p -> softmax."""
+    lp_mod = pytest.importorskip('transformers.generation.logits_process')
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(1)
+    B, V, Th = 4, 1190, 40
+    logp = torch.log_softmax(torch.randn(B, V) * 2.5, -1)
+    lp = logp.to(dev)
+    hist = torch.randint(0, V, (B, Th))
+    hist[:, 5] = hist[:, 6]                                  # a repeated id is penalised once
+    hist[0, :8] = logp[0].topk(8).indices                    # make sure the penalty hits the head of the distribution
+    ids = torch.zeros(B, Th + 8, dtype=torch.int64); ids[:, :Th] = hist
+    ids_d = ids.to(dev)
+    t = torch.full((1,), Th - 1, device=dev, dtype=torch.int32)
+    rng = torch.zeros(1, device=dev, dtype=torch.int64)
+    probs = torch.zeros(B, V, device=dev)
+    cases = [dict(rp=1.3, typ=1.0, k=0, p=1.0, temp=1.0), dict(rp=1.0, typ=0.6, k=0, p=1.0, temp=1.0),
+             dict(rp=1.2, typ=0.9, k=64, p=0.9, temp=0.8), dict(rp=1.0, typ=0.2, k=16, p=1.0, temp=1.4),
+             dict(rp=1.5, typ=0.95, k=0, p=0.7, temp=1.0)]
+    for c in cases:
+        ops.sample(lp, ids_d, t, rng, 5, do_sample=True, top_k=c['k'], top_p=c['p'], temperature=c['temp'],
+                   repetition_penalty=c['rp'], typical_p=c['typ'], out_probs=probs)
+        s = logp.clone()
+        if c['rp'] != 1.0:
+            s = lp_mod.RepetitionPenaltyLogitsProcessor(c['rp'])(hist, s)
+        if c['temp'] != 1.0:
+            s = lp_mod.TemperatureLogitsWarper(c['temp'])(hist, s)
+        if c['k']:
+            s = lp_mod.TopKLogitsWarper(c['k'])(hist, s)
+        if c['p'] < 1.0:
+            s = lp_mod.TopPLogitsWarper(c['p'])(hist, s)
+        if c['typ'] < 1.0:
+            s = lp_mod.TypicalLogitsWarper(mass=c['typ'])(hist, s)
+        want = s.softmax(-1)
+        got = probs.cpu()
+        assert ((got > 0) == (want > 0)).all(), c
+        assert (got - want).abs().max().item() < 2e-5, c
+        tok = ids_d[:, Th].cpu()
+        assert (want.gather(1, tok[:, None]) > 0).all(), c
+    # greedy with a penalty: argmax of the penalised scores
+    ops.sample(lp, ids_d, t, rng, 5, do_sample=False, repetition_penalty=5.0)
+    want = lp_mod.RepetitionPenaltyLogitsProcessor(5.0)(hist, logp.clone()).argmax(-1)
+    assert torch.equal(ids_d[:, Th].cpu(), want)
+    assert (want[0] != logp[0].argmax()).item()             # the penalty did move row 0's choice
+
+
+def test_generate_with_repetition_penalty_runs_in_graph(dev):
+    """model.generate(..., repetition_penalty, typical_p) end to end: eager == hipGraph replay (the penalty reads the id
+    history through the device-side step counter, so it must stay correct under replay)"""
+    ref, m = _pair(dev, n_layer=2, mem_len=64, max_length=96, seed=3)
+    m.eval()
+    prompt = torch.randint(4, 1190, (2, 12)).to(dev)
+    kw = dict(max_length=80, do_sample=True, top_k=32, top_p=0.9, typical_p=0.8, repetition_penalty=1.3)
+    a = m.generate(input_ids=prompt, use_graph=False, **kw).cpu()
+    m._decoder.rng.zero_()                                   # the draw counter runs on across calls; rewind it
+    b = m.generate(input_ids=prompt, use_graph=True, **kw).cpu()
+    assert torch.equal(a, b)
+    g0 = m.generate(input_ids=prompt, max_length=80, do_sample=False).cpu()
+    g1 = m.generate(input_ids=prompt, max_length=80, do_sample=False, repetition_penalty=3.0).cpu()
+    assert not torch.equal(g0, g1)
+    # with a strong penalty greedy decoding repeats less
+    rep = lambda x: sum(len(r.tolist()) - len(set(r.tolist())) for r in x[:, 12:])
+    assert rep(g1) <= rep(g0)
