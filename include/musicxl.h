@@ -258,6 +258,12 @@ int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_
 int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
                        int max_length, long long pad_id, const int* remap, const int* row_table, int v_src, void* stream);
 
+/* Post-decode / prompt id ops: out[b] = position of the last (which < 0) or which-th (0-based) occurrence
+ * of `token` in row b of ids (B, T) int64, -1 if absent.  With token = the start-of-bar id this is the cut point of
+ * MusicGenerator._truncate_last_bar (musicnlp/trainer/eval.py:178-185, which = -1) and of truncate_first_n_bar
+ * (eval.py:187-198, which = n_bar). */
+int mxl_find_token(const void* ids, int ld_ids, int B, int T, long long token, int which, int* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,7 +105,40 @@ __global__ __launch_bounds__(256) void pack_clm_kernel(const TOK* tok, const int
     ids[gid] = v;
     if (labels) labels[gid] = (v == pad_id) ? -100 : v;
 }
+
+// out[b] = index of the last (which < 0) or the which-th (0-based) occurrence of `token` in row b, -1 if there is none; one wave
+// per row, 64 positions per ballot
+__global__ __launch_bounds__(64) void find_token_kernel(const long long* ids, int ld, int T, long long token, int which, int* out) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    const long long* row = ids + (size_t)b * ld;
+    int seen = 0, res = -1;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + l;
+        const bool hit = t < T && row[t] == token;
+        const unsigned long long m = __ballot(hit);
+        if (which < 0) {
+            if (m) res = t0 + 63 - __clzll(m);
+        } else {
+            const int c = __popcll(m);
+            if (res < 0 && seen + c > which) {
+                unsigned long long mm = m;
+                for (int i = which - seen; i > 0; i--) mm &= mm - 1;      // drop the lower set bits
+                res = t0 + __ffsll((long long)mm) - 1;
+            }
+            seen += c;
+        }
+    }
+    if (l == 0) out[b] = res;
+}
 }  // namespace
+
+extern "C" int mxl_find_token(const void* ids, int ld_ids, int B, int T, long long token, int which, int* out, void* stream) {
+    MXL_CHECK_ARG(ids && out && B > 0 && T > 0 && ld_ids >= T);
+    hipLaunchKernelGGL(find_token_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)ids, ld_ids, T, token, which,
+                       out);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
 
 extern "C" int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, void* ids_out, void* labels_out, int B,
                                   int max_length, long long pad_id, const int* remap, const int* row_table, int v_src,

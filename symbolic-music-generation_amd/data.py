@@ -62,6 +62,55 @@ class TokenFile:
         return np.diff(self.offsets)
 
 
+class MixedTokenFiles:
+    """`ProportionMixingDataset` (musicnlp/preprocess/dataset.py:367-453) over token files: the concatenation of several
+    datasets with every one larger than `k` capped at `k` sequences, the kept ones re-drawn by `sample()` (meant to be called
+    once per epoch, dataset.py:422-431).  Index order as the reference: dataset 0's (sub-sampled) entries, then dataset 1's, ...
+    Quacks like a `TokenFile` for `DeviceBatcher` (`len`, `[i]`, `dtype`, `vocab_size`); `flat_index(i)` is the position of
+    entry i in the plain concatenation of the full datasets (what per-sequence side tables such as `Augment.keys` are indexed by).
+    The draw is `torch.randperm(size)[:k]` on torch's global generator, as in the reference, unless a generator is passed."""
+
+    def __init__(self, files: Sequence[TokenFile], k: int, generator: Optional[torch.Generator] = None):
+        assert k is not None and len(files) > 0
+        self.files, self.k, self.generator = list(files), int(k), generator
+        if len({f.dtype for f in self.files}) != 1 or len({f.vocab_size for f in self.files}) != 1:
+            raise ValueError('mixed token files must share one vocabulary and id width')
+        self.dtype, self.vocab_size = self.files[0].dtype, self.files[0].vocab_size
+        self.sizes = [min(len(f), self.k) for f in self.files]
+        self._starts = np.concatenate([[0], np.cumsum(self.sizes)])
+        self._full_starts = np.concatenate([[0], np.cumsum([len(f) for f in self.files])])
+        self._sampled: list = [None] * len(self.files)
+        self.sample()
+
+    def sample(self):
+        for j, f in enumerate(self.files):
+            if len(f) > self.k:
+                self._sampled[j] = torch.randperm(len(f), generator=self.generator)[:self.k].numpy()
+
+    def __len__(self):
+        return int(self._starts[-1])
+
+    def locate(self, i: int) -> Tuple[int, int]:
+        """global index -> (dataset, index inside that dataset)"""
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        j = int(np.searchsorted(self._starts, i, side='right')) - 1
+        loc = i - int(self._starts[j])
+        if self._sampled[j] is not None:
+            loc = int(self._sampled[j][loc])
+        return j, loc
+
+    def flat_index(self, i: int) -> int:
+        j, loc = self.locate(i)
+        return int(self._full_starts[j]) + loc
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        j, loc = self.locate(int(i))
+        return self.files[j][loc]
+
+    def lengths(self) -> np.ndarray:
+        return np.asarray([len(self[i]) for i in range(len(self))], dtype=np.int64)
+
 
 _T0 = dict(C=0, D=1, E=2, F=3, G=4, A=5, B=6)            # musicnlp/preprocess/key_finder.py:199-207
 
@@ -191,7 +240,8 @@ class DeviceBatcher:
             if self.augment is None:
                 parts, tab[j] = [self.tf[int(i)]], -1
             else:
-                parts, tab[j] = self.augment.pieces(int(i), self.tf[int(i)])
+                src = self.tf.flat_index(int(i)) if hasattr(self.tf, 'flat_index') else int(i)
+                parts, tab[j] = self.augment.pieces(src, self.tf[int(i)])
             room = self.L
             for a in parts:                                   # truncation=True: the first max_length tokens of the result
                 a = a[:room]

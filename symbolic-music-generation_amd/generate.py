@@ -167,3 +167,31 @@ class XLDecoder:
                 for _ in range(steps):
                     self.step(sampling)
         return self.ids[:, :max_length].clone()
+
+
+# -------------------------------------------------------------------- bar-aligned cuts around generation
+def truncate_last_bar(ids: torch.Tensor, sob_token_id: int):
+    """`MusicGenerator._truncate_last_bar` (musicnlp/trainer/eval.py:178-185) for a batch: every generated row cut just before
+    its last start-of-bar token, so a bar broken off by `max_length` is not rendered.  ids: (T,) or (B, T) int64 on the GPU;
+    returns a list of ints (1-D input, as the reference) or a list of such lists.  Like the reference it refuses a row with no
+    start-of-bar token."""
+    one = ids.dim() == 1
+    x = ids.view(1, -1) if one else ids
+    x = x.contiguous()
+    cut = ops.find_token(x, sob_token_id, -1).tolist()
+    if min(cut) < 0:
+        raise MusicXLError('no start-of-bar token found in a sequence to truncate')
+    host = x.cpu()
+    rows = [host[b, :c].tolist() for b, c in enumerate(cut)]
+    return rows[0] if one else rows
+
+
+def truncate_first_n_bar(ids: torch.Tensor, sob_token_id: int, n_bar: int = 8) -> torch.Tensor:
+    """`MusicGenerator.truncate_first_n_bar` (eval.py:187-198) on ids: the prefix of one song up to (not including) its
+    start-of-bar number `n_bar` (0-based, i.e. the song header plus the first `n_bar` bars), with a start-of-bar appended as the
+    prompt for generation.  ids: (T,) int64 on the GPU; returns a (n,) int64 device tensor."""
+    assert ids.dim() == 1
+    cut = int(ops.find_token(ids.view(1, -1).contiguous(), sob_token_id, n_bar).item())
+    if cut < 0:
+        raise MusicXLError(f'the sequence has fewer than {n_bar + 1} bars')     # the reference raises IndexError here
+    return torch.cat([ids[:cut], ids.new_tensor([sob_token_id])])

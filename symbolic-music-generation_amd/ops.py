@@ -290,6 +290,14 @@ def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=
                            float(typical_p if typical_p is not None else 1.0), _p(out_probs), _stream()), 'mxl_sample')
 
 
+def find_token(ids: torch.Tensor, token: int, which: int = -1) -> torch.Tensor:
+    """(B,) int32: index of the last (which < 0) / which-th occurrence of `token` per row of ids (B, T) int64, -1 if none"""
+    B, T = ids.shape
+    out = torch.empty(B, device=ids.device, dtype=torch.int32)
+    check(lib().mxl_find_token(_p(ids), ids.stride(0), B, T, int(token), int(which), _p(out), _stream()), 'mxl_find_token')
+    return out
+
+
 def decode_advance(t_dev, rng_ctr):
     check(lib().mxl_decode_advance(_p(t_dev), _p(rng_ctr), _stream()), 'mxl_decode_advance')
 

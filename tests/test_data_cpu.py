@@ -28,3 +28,48 @@ def test_pad_and_label_contract():
     assert ids.tolist() == [[5, 6, 7, 1], [1, 1, 1, 1], [1, 2, 3, 4]]
     # every pad id becomes -100 in the labels -- including a genuine pad token inside a sequence (the HF collator's behaviour)
     assert labels.tolist() == [[5, 6, 7, -100], [-100] * 4, [-100, 2, 3, 4]]
+
+
+def test_mixed_token_files_match_proportion_mixing(tmp_path):
+    """MixedTokenFiles vs the restated ProportionMixingDataset under the same torch seed: same length, same entries in the same
+    order, before and after a re-draw; flat_index points at the entry in the plain concatenation"""
+    import torch
+    from oracle.data_ref import ProportionMixingRef
+    from symbolic_music_generation_amd.data import MixedTokenFiles, TokenFile, write_token_file
+    rng = np.random.default_rng(3)
+    corpora = [[rng.integers(0, 1190, size=rng.integers(1, 40)) for _ in range(n)] for n in (5, 37, 12, 60)]
+    files = []
+    for j, c in enumerate(corpora):
+        write_token_file(str(tmp_path / f'c{j}'), c, vocab_size=1190)
+        files.append(TokenFile(str(tmp_path / f'c{j}')))
+    k = 12
+    torch.manual_seed(11)
+    mix = MixedTokenFiles(files, k)
+    torch.manual_seed(11)
+    ref = ProportionMixingRef([[list(map(int, s)) for s in c] for c in corpora], k)
+    assert len(mix) == len(ref) == 5 + 12 + 12 + 12
+    flat = [s for c in corpora for s in c]
+    for rnd in range(2):
+        got = [list(map(int, mix[i])) for i in range(len(mix))]
+        assert got == [ref[i] for i in range(len(ref))]
+        assert all(list(map(int, flat[mix.flat_index(i)])) == got[i] for i in range(len(mix)))
+        # the capped datasets really are sub-samples without repetition
+        assert len({mix.locate(i) for i in range(len(mix))}) == len(mix)
+        torch.manual_seed(12 + rnd)
+        mix.sample()
+        torch.manual_seed(12 + rnd)
+        ref.sample()
+    try:
+        mix[len(mix)]
+        assert False
+    except IndexError:
+        pass
+
+
+def test_bar_cut_restatements():
+    from oracle.data_ref import truncate_first_n_bar_ref, truncate_last_bar_ref
+    sob = 2
+    ids = [9, 8, 2, 5, 6, 2, 7, 2, 4, 4]
+    assert truncate_last_bar_ref(ids, sob) == [9, 8, 2, 5, 6, 2, 7]
+    assert truncate_first_n_bar_ref(ids, sob, 1) == [9, 8, 2, 5, 6, 2]
+    assert truncate_first_n_bar_ref(ids, sob, 0) == [9, 8, 2]

@@ -94,3 +94,60 @@ def test_device_batcher_with_augmentation(tmp_path):
     ref_ids, ref_lab = pad_and_label(want, L, pad)
     (got_ids, got_lab), = list(db)
     assert np.array_equal(got_ids.cpu().numpy(), ref_ids) and np.array_equal(got_lab.cpu().numpy(), ref_lab)
+
+
+def test_find_token_and_bar_cuts_vs_oracle(dev):
+    """mxl_find_token + the bar-aligned cuts of eval.py:178-198 on the reference's real degree-pitch stream and on edge rows"""
+    from oracle.data_ref import truncate_first_n_bar_ref, truncate_last_bar_ref
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd._lib import MusicXLError
+    from symbolic_music_generation_amd.generate import truncate_first_n_bar, truncate_last_bar
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample_score_ids.npz'))
+    from symbolic_music_generation_amd.vocab import MusicTokenizer
+    song = z['sample_full_degree'].astype(np.int64)
+    sob = MusicTokenizer(pitch_kind='degree').sob_token_id
+    assert (song[:800] == sob).sum() > 12
+    T = 700
+    rows = np.stack([song[:T], song[100:100 + T], np.full(T, sob), np.concatenate([[sob], np.zeros(T - 1, np.int64) + sob + 1])])
+    x = torch.from_numpy(rows).to(dev)
+    last = ops.find_token(x, sob, -1).cpu().tolist()
+    for b in range(4):
+        want = [i for i, t in enumerate(rows[b]) if t == sob]
+        assert last[b] == want[-1]
+        for n in sorted({0, min(1, len(want) - 1), min(5, len(want) - 1), len(want) - 1}):
+            assert ops.find_token(x, sob, n).cpu().tolist()[b] == want[n]
+        assert ops.find_token(x, sob, len(want)).cpu().tolist()[b] == -1
+    cut = truncate_last_bar(x, sob)
+    assert cut == [truncate_last_bar_ref(rows[b].tolist(), sob) for b in range(4)]
+    assert truncate_last_bar(x[0], sob) == truncate_last_bar_ref(rows[0].tolist(), sob)
+    p = truncate_first_n_bar(x[0], sob, n_bar=8).cpu().tolist()
+    assert p == truncate_first_n_bar_ref(rows[0].tolist(), sob, 8)
+    none = torch.full((2, 130), sob + 1, device=dev, dtype=torch.int64)
+    assert ops.find_token(none, sob, -1).cpu().tolist() == [-1, -1]
+    with pytest.raises(MusicXLError):
+        truncate_last_bar(none, sob)
+    with pytest.raises(MusicXLError):
+        truncate_first_n_bar(x[3], sob, n_bar=4)
+
+
+def test_device_batcher_over_mixed_files(tmp_path):
+    """the batcher over a ProportionMixing-style mix == the batch contract applied to the restated mix, epoch after re-draw"""
+    from oracle.data_ref import ProportionMixingRef
+    from symbolic_music_generation_amd.data import DeviceBatcher, MixedTokenFiles, TokenFile, write_token_file
+    rng = np.random.default_rng(5)
+    corpora = [[rng.integers(2, 1190, size=rng.integers(1, 90)) for _ in range(n)] for n in (7, 40, 23)]
+    files = []
+    for j, c in enumerate(corpora):
+        write_token_file(str(tmp_path / f'm{j}'), c, vocab_size=1190)
+        files.append(TokenFile(str(tmp_path / f'm{j}')))
+    torch.manual_seed(2)
+    mix = MixedTokenFiles(files, k=10)
+    torch.manual_seed(2)
+    ref = ProportionMixingRef([[list(map(int, s)) for s in c] for c in corpora], 10)
+    db = DeviceBatcher(mix, batch_size=8, max_length=64, pad_id=1, device='cuda:0')
+    for epoch in range(2):
+        got = np.concatenate([ids.cpu().numpy() for ids, _ in db])
+        want, _ = pad_and_label([ref[i] for i in range(len(ref))], 64, 1)
+        assert got.shape == (27, 64) and np.array_equal(got, want)
+        torch.manual_seed(30); mix.sample()
+        torch.manual_seed(30); ref.sample()
