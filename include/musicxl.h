@@ -217,15 +217,18 @@ int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, i
 int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, const int* sorted_pos, void* out, float* lse, int B, int T,
                        int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed,
                        unsigned site, void* stream);
-/* backward: dq, dk, dv (B,T,H*dh) f32 are ACCUMULATED (atomics; written when T <= 64); for lsh, dk is w.r.t. the normalised key (see keynorm_bwd);
- * dout has out's layout; dlse (B,n_h,H,T) f32 or NULL */
+/* backward: dq, dk, dv (B,T,H*dh) f32.  n_h > 1: ACCUMULATED with atomics (zero them first).  n_h == 1: every element is written
+ * exactly once (no pre-zeroing), and each of the three may instead go out as bf16 through dq16 / dk16 / dv16 (rows of ld16
+ * elements; NULL = use the f32 destination) -- e.g. straight into the (N, 3d) operand of the projection-gradient GEMMs.
+ * For lsh, dk is w.r.t. the normalised key (see keynorm_bwd); dout has out's layout; dlse (B,n_h,H,T) f32 or NULL */
 int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out, const float* lse,
-                       const void* dout, const float* dlse, float* dq, float* dk, float* dv, int B, int T, int H, int dh,
-                       int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed, unsigned site,
-                       void* stream);
-/* dqk (B,T,H*dh) bf16 = dq + chain rule of k = qk * rsqrt(mean(qk^2)+1e-6)/sqrt(dh) applied to dk_eff */
-int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int B, int T,
-                        int H, int dh, void* stream);
+                       const void* dout, const float* dlse, float* dq, float* dk, float* dv, void* dq16, void* dk16, void* dv16,
+                       int ld16, int B, int T, int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p,
+                       unsigned long long seed, unsigned site, void* stream);
+/* dqk (B*T rows of ld_dqk elements, H*dh used) bf16 = dq + chain rule of k = qk * rsqrt(mean(qk^2)+1e-6)/sqrt(dh) applied to
+ * dk_eff */
+int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int ld_dqk, int B,
+                        int T, int H, int dh, void* stream);
 /* hash-round merge: out = sum_r softmax_r(lse) * out_r, and its backward (dout_r, dlse) */
 int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T, int H, int dh, int n_h, void* stream);
 int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r, float* dlse,

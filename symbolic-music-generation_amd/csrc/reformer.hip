@@ -179,6 +179,8 @@ struct ChunkP {
     const bf16_t* dout;         // backward: same layout as out
     const float* dlse;          // (B, n_h, H, T) or null
     float *dq, *dk, *dv;        // f32 (B, T, d) accumulators (atomicAdd)
+    bf16_t *dq16, *dk16, *dv16; // n_h == 1 only: bf16 destinations (row stride ld16) that replace the f32 one when non-null
+    int ld16;
     long long bs; int rs;       // q/k/v strides (elements)
     int B, T, H, S, n_h, lsh;
     float scale;
@@ -461,7 +463,17 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
             }
         }
     float* dqp = p.dq + ((size_t)b * p.T + qpos) * d + h * DH;
-    if (p.n_h == 1) {   // every (position, head) occurs once: plain 16-byte stores, no atomics, no pre-zeroing needed
+    if (p.dq16) {       // n_h == 1, bf16 straight into the projection-gradient operand
+        bf16_t* o16 = p.dq16 + ((size_t)b * p.T + qpos) * p.ld16 + h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH)
+                    *reinterpret_cast<u32x2*>(o16 + e0) = u32x2{pack2bf(aq[e][4 * grp], aq[e][4 * grp + 1]), pack2bf(aq[e][4 * grp + 2], aq[e][4 * grp + 3])};
+            }
+    } else if (p.n_h == 1) {   // every (position, head) occurs once: plain 16-byte stores, no atomics, no pre-zeroing needed
 #pragma unroll
         for (int e = 0; e < EB; e++)
 #pragma unroll
@@ -659,8 +671,11 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
                         vv[t] = av[e][4 * grp + t] + red[64 * RS + krow * RS + e0 + t];
                     }
                     if (p.n_h == 1) {
-                        *reinterpret_cast<f32x4*>(dkp + e0) = vk;
-                        *reinterpret_cast<f32x4*>(dvp + e0) = vv;
+                        const size_t o16 = ((size_t)b * p.T + kpos) * p.ld16 + h * DH + e0;
+                        if (p.dk16) *reinterpret_cast<u32x2*>(p.dk16 + o16) = u32x2{pack2bf(vk[0], vk[1]), pack2bf(vk[2], vk[3])};
+                        else *reinterpret_cast<f32x4*>(dkp + e0) = vk;
+                        if (p.dv16) *reinterpret_cast<u32x2*>(p.dv16 + o16) = u32x2{pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3])};
+                        else *reinterpret_cast<f32x4*>(dvp + e0) = vv;
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; t++) { atomicAdd(dkp + e0 + t, vk[t]); atomicAdd(dvp + e0 + t, vv[t]); }
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
 // =====================================================================================================================
 // dqk[n][h][:] = dq + f * dk' - x * (sum_e dk'_e x_e) * (m + eps)^(-3/2) / dh^(3/2),  m = mean(x^2),  f = (m+eps)^(-1/2)/sqrt(dh)
 __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, const float* dq, const float* dkp, bf16_t* dqk,
-                                       int B, int T, int H, int dh) {
+                                       int ld_dqk, int B, int T, int H, int dh) {
     // dh/8 consecutive lanes own one (b, t, h) vector: 16-byte bf16 loads, 2 x 16-byte fp32 loads per operand
     const int lpv = dh >> 3;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -705,7 +720,7 @@ __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, c
 #pragma unroll
         for (int j = 0; j < 8; j++) r[j] = dqv[j] + f * dk[j] - x[j] * cc;
         u32x4 w = {pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7])};
-        *reinterpret_cast<u32x4*>(dqk + o) = w;
+        *reinterpret_cast<u32x4*>(dqk + (size_t)n * ld_dqk + (size_t)h * dh + c * 8) = w;
     }
 }
 
@@ -790,6 +805,7 @@ int fill_chunk(ChunkP& p, const void* q, const void* k, const void* v, const int
     if (lsh && !spos && T > SC_MAXT) return MXL_EINVAL;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.spos = spos; p.out = (bf16_t*)out; p.lse = lse;
     p.dout = nullptr; p.dlse = nullptr; p.dq = p.dk = p.dv = nullptr;
+    p.dq16 = p.dk16 = p.dv16 = nullptr; p.ld16 = 0;
     p.bs = bs; p.rs = rs; p.B = B; p.T = T; p.H = H; p.S = n_h * T; p.n_h = n_h; p.lsh = lsh;
     p.scale = 1.f / sqrtf((float)dh);
     p.thresh = dropout_thresh(drop_p); p.dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.site = site;
@@ -891,9 +907,11 @@ __global__ __launch_bounds__(256) void single_attn_kernel(ChunkP p) {
             av += sp[j * 65 + t] * keep(j, t) * sdo[j * LD + e];          // dv_t  = sum_i pd_it dO_i
         }
         const size_t o = ((size_t)b * T + t) * d + h * DH + e;
-        p.dq[o] = aq;
-        p.dk[o] = p.lsh ? ak : ak * p.scale;      // local: the factor was folded into k', undo to get d k
-        p.dv[o] = av;
+        const size_t o16 = ((size_t)b * T + t) * p.ld16 + h * DH + e;
+        ak = p.lsh ? ak : ak * p.scale;           // local: the factor was folded into k', undo to get d k
+        if (p.dq16) p.dq16[o16] = f2bf(aq); else p.dq[o] = aq;
+        if (p.dk16) p.dk16[o16] = f2bf(ak); else p.dk[o] = ak;
+        if (p.dv16) p.dv16[o16] = f2bf(av); else p.dv[o] = av;
     }
 }
 
@@ -993,14 +1011,17 @@ extern "C" int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, c
 }
 
 extern "C" int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out,
-                                  const float* lse, const void* dout, const float* dlse, float* dq, float* dk, float* dv, int B,
+                                  const float* lse, const void* dout, const float* dlse, float* dq, float* dk, float* dv,
+                                  void* dq16, void* dk16, void* dv16, int ld16, int B,
                                   int T, int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p,
                                   unsigned long long seed, unsigned site, void* stream) {
     ChunkP p;
     int rc = fill_chunk(p, q, k, v, sorted_pos, (void*)out, (float*)lse, B, T, H, dh, n_h, lsh, bs, rs, drop_p, seed, site);
     if (rc) return rc;
-    MXL_CHECK_ARG(dout && dq && dk && dv);
+    MXL_CHECK_ARG(dout && (dq || dq16) && (dk || dk16) && (dv || dv16));
+    if (dq16 || dk16 || dv16) MXL_CHECK_ARG(n_h == 1 && ld16 >= H * dh && (ld16 % 4) == 0);
     p.dout = (const bf16_t*)dout; p.dlse = dlse; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.dq16 = (bf16_t*)dq16; p.dk16 = (bf16_t*)dk16; p.dv16 = (bf16_t*)dv16; p.ld16 = ld16;
     if (T <= SC_MAXT) {
         switch (dh) {
             case 16: return launch_single<16>(p, 1, (hipStream_t)stream);
@@ -1017,13 +1038,13 @@ extern "C" int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, c
     }
 }
 
-extern "C" int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int B,
-                                   int T, int H, int dh, void* stream) {
-    MXL_CHECK_ARG(qk && dq && dk_eff && dqk && B > 0 && T > 0 && H > 0 && dh > 0);
+extern "C" int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk,
+                                   int ld_dqk, int B, int T, int H, int dh, void* stream) {
+    MXL_CHECK_ARG(qk && dq && dk_eff && dqk && B > 0 && T > 0 && H > 0 && dh > 0 && ld_dqk >= H * dh && (ld_dqk % 8) == 0);
     MXL_CHECK_ARG((dh % 8) == 0 && (64 % (dh / 8)) == 0);
     const long long n = (long long)B * T * H * (dh / 8);
     hipLaunchKernelGGL(lsh_keynorm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, B, T, H, dh);
+                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, ld_dqk, B, T, H, dh);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -334,14 +334,18 @@ def chunk_attn_fwd(q, k, v, spos, out, lse, B, T, H, dh, n_h, lsh, bs, rs, drop_
                                    float(drop_p), seed, site, _stream()), 'mxl_chunk_attn_fwd')
 
 
-def chunk_attn_bwd(q, k, v, spos, out, lse, dout, dlse, dq, dk, dv, B, T, H, dh, n_h, lsh, bs, rs, drop_p=0.0, seed=0, site=0):
+def chunk_attn_bwd(q, k, v, spos, out, lse, dout, dlse, dq, dk, dv, B, T, H, dh, n_h, lsh, bs, rs, drop_p=0.0, seed=0, site=0,
+                   dq16=None, dk16=None, dv16=None, ld16=0):
+    """dq / dk / dv: f32 (B*T, d) (may be None when the matching bf16 destination is given; n_h == 1 only)"""
     check(lib().mxl_chunk_attn_bwd(_p(q), _p(k), _p(v), _p(spos), _p(out), _p(lse), _p(dout), _p(dlse), _p(dq), _p(dk), _p(dv),
+                                   _p(dq16), _p(dk16), _p(dv16), int(ld16),
                                    B, T, H, dh, n_h, int(lsh), bs, rs, float(drop_p), seed, site, _stream()),
           'mxl_chunk_attn_bwd')
 
 
-def lsh_keynorm_bwd(qk, bs, rs, dq, dk_eff, dqk, B, T, H, dh):
-    check(lib().mxl_lsh_keynorm_bwd(_p(qk), bs, rs, _p(dq), _p(dk_eff), _p(dqk), B, T, H, dh, _stream()), 'mxl_lsh_keynorm_bwd')
+def lsh_keynorm_bwd(qk, bs, rs, dq, dk_eff, dqk, B, T, H, dh, ld_dqk=None):
+    check(lib().mxl_lsh_keynorm_bwd(_p(qk), bs, rs, _p(dq), _p(dk_eff), _p(dqk), int(ld_dqk or H * dh), B, T, H, dh, _stream()),
+          'mxl_lsh_keynorm_bwd')
 
 
 def lsh_combine(out_r, lse, out, B, T, H, dh, n_h):

@@ -434,23 +434,26 @@ class RFEngine:
             qkv = ws.qkv[l].view(-1)[:N * nproj * d].view(N, nproj * d)
             dqkv = ws.dqkv.view(-1)[:N * nproj * d].view(N, nproj * d)
             rs, bs = nproj * d, T * nproj * d
-            ws.dq.zero_(); ws.dk.zero_(); ws.dv.zero_()
             if kind == 'local':
-                ops.chunk_attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], None, ws.av[l], ws.lse[l], dav, None, ws.dq, ws.dk, ws.dv,
-                                   B, T, H, dh, 1, 0, bs, rs, drop_p=ws.p_loc, seed=seed, site=self._site(l, 0))
-                dqkv[:, :d].copy_(ws.dq); dqkv[:, d:2 * d].copy_(ws.dk); dqkv[:, 2 * d:].copy_(ws.dv)
+                # one round: every gradient element is written once, in bf16, straight into the (N, 3d) GEMM operand
+                ops.chunk_attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], None, ws.av[l], ws.lse[l], dav, None, None, None, None,
+                                   B, T, H, dh, 1, 0, bs, rs, drop_p=ws.p_loc, seed=seed, site=self._site(l, 0),
+                                   dq16=dqkv, dk16=dqkv[:, d:], dv16=dqkv[:, 2 * d:], ld16=3 * d)
             else:
                 if n_h > 1:
                     ops.lsh_combine_bwd(ws.out_r[l], ws.lse[l], ws.av[l], dav, ws.dout_r, ws.dlse, B, T, H, dh, n_h)
                     o_in, do_in, dl_in = ws.out_r[l], ws.dout_r, ws.dlse
                 else:
                     o_in, do_in, dl_in = ws.av[l], dav, None
+                if n_h > 1:
+                    ws.dq.zero_(); ws.dk.zero_(); ws.dv.zero_()          # accumulated over the hash rounds with atomics
                 ops.chunk_attn_bwd(qkv, qkv, qkv[:, d:], None if getattr(ws, 'single', False) else ws.spos[l], o_in, ws.lse[l], do_in,
-                                   dl_in, ws.dq, ws.dk, ws.dv, B, T, H,
-                                   dh, n_h, 1, bs, rs, drop_p=ws.p_lsh, seed=seed, site=self._site(l, 0))
-                dqk16 = t2          # free here: its previous contents (dao / FF gradient) are consumed
-                ops.lsh_keynorm_bwd(qkv, bs, rs, ws.dq, ws.dk, dqk16, B, T, H, dh)
-                dqkv[:, :d].copy_(dqk16); dqkv[:, d:].copy_(ws.dv)
+                                   dl_in, ws.dq, ws.dk, ws.dv if n_h > 1 else None, B, T, H,
+                                   dh, n_h, 1, bs, rs, drop_p=ws.p_lsh, seed=seed, site=self._site(l, 0),
+                                   dv16=None if n_h > 1 else dqkv[:, d:], ld16=0 if n_h > 1 else 2 * d)
+                ops.lsh_keynorm_bwd(qkv, bs, rs, ws.dq, ws.dk, dqkv, B, T, H, dh, ld_dqk=2 * d)
+                if n_h > 1:
+                    dqkv[:, d:].copy_(ws.dv)
             ops.gemm(dqkv, ws.hn[l], self._proj_w(l, kind, G), nproj * d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(nproj * d, d))
             dhn = ws.dF.view(-1)[:N * d].view(N, d)

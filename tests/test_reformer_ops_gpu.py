@@ -113,6 +113,19 @@ def test_chunk_attention_fwd_bwd(dev, B, T, H, dh, n_h, lsh):
     else:
         assert rel_err(dq.cpu(), c['qh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
         assert rel_err(dk.cpu(), c['kh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
+    if n_h == 1:
+        # one round: the bf16 destinations (strided rows of a wider matrix, as the engine passes them) hold exactly the rounded
+        # f32 results, and need no zero-fill
+        wide = torch.full((B * T, 3 * d + 8), float('nan'), device=dev, dtype=torch.bfloat16)
+        ops.chunk_attn_bwd(qd, kd, vd, sp, out, lse, dout.to(dev), None, None, None, None, B, T, H, dh, 1, lsh, T * d, d,
+                           dq16=wide, dk16=wide[:, d:], dv16=wide[:, 2 * d:], ld16=3 * d + 8)
+        assert torch.equal(wide[:, :d], dq.view(B * T, d).to(torch.bfloat16))
+        assert torch.equal(wide[:, d:2 * d], dk.view(B * T, d).to(torch.bfloat16))
+        assert torch.equal(wide[:, 2 * d:3 * d], dv.view(B * T, d).to(torch.bfloat16))
+        assert torch.isnan(wide[:, 3 * d:].float()).all()
+        if lsh:
+            ops.lsh_keynorm_bwd(qd, T * d, d, dq, dk, wide, B, T, H, dh, ld_dqk=3 * d + 8)
+            assert torch.equal(wide[:, :d], dqk.view(B * T, d)) and torch.isnan(wide[:, 3 * d:].float()).all()
 
 
 def test_chunk_attention_dropout_consistency(dev):
