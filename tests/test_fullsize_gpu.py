@@ -1,7 +1,8 @@
 """Size-independent properties at the FULL benchmark sizes (BASELINE.json configs[2] = SURVEY C3: 12L / 768d / H12 / dh64, T = M =
 2048, V = 1190; token matrices of 32768 rows), where the CPU oracle is out of reach: checksums for the GEMMs, normalisation
 and causality for the attention kernel, normalisation / causality / segmentation invariance / batch equivariance for the
-whole model."""
+whole model.  The same for the Reformer at configs[3] = SURVEY C4 (T = 8192): sortedness / permutation of the LSH sort, softmax mass
+and the exact reach of a key in the chunked attention, and whole-model equivariance / causality."""
 import pytest
 import torch
 
@@ -112,3 +113,88 @@ def test_model_properties_at_c3(dev):
     seg = torch.cat([o1.prediction_scores, o2.prediction_scores], 1).float()
     assert (seg - lp).abs().max().item() < 8e-2
     assert (seg - lp).abs().mean().item() < 1e-2        # log-probs are O(10): 1e-3 relative, 12 layers of bf16 activations
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Reformer at SURVEY C4 sizes (BASELINE.json configs[3]): 6L (3 local + 3 LSH) / 512d / H8 / dh64, T = 8192, buckets [16, 16]
+# ----------------------------------------------------------------------------------------------------------------------
+RT, RD, RH = 8192, 512, 8
+
+
+def test_lsh_sort_is_the_stable_permutation_at_c4(dev):
+    """64 (sequence, head) rows of 8192 keys in 256 buckets: the result is a permutation, sorted by bucket, ties in index order
+    (= argsort(S * bucket + index), HF's sort key), and sorted_pos is the position of each slot"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(0)
+    BH, S, NB = 64, RT, 256
+    bk = torch.randint(0, NB, (BH, S), device=dev, dtype=torch.int32)
+    bk[3] = 7                                                      # one bucket holds everything
+    bk[4] = torch.arange(S, device=dev, dtype=torch.int32) % NB    # perfectly interleaved
+    sidx = torch.empty(BH, S, device=dev, dtype=torch.int32)
+    spos = torch.empty_like(sidx)
+    ops.lsh_sort(bk, sidx, spos, BH, S, RT, NB)
+    si = sidx.long()
+    assert torch.equal(si.sort(-1).values, torch.arange(S, device=dev).expand(BH, S))        # a permutation
+    sb = bk.long().gather(1, si)
+    key = sb * S + si
+    assert (key[:, 1:] > key[:, :-1]).all()                        # bucket ascending, index ascending inside a bucket
+    assert torch.equal(spos.long(), si % RT)
+    assert torch.equal(si, torch.argsort(bk.long() * S + torch.arange(S, device=dev), dim=-1))
+
+
+def test_local_chunk_attention_properties_at_c4(dev):
+    """(8, 8192, 512) local attention: with V = 1 every output is the softmax mass 1; a perturbed key at position t changes only
+    the queries that can see it -- t .. end of the NEXT chunk -- and nothing else, bit for bit"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(1)
+    B, T, H, dh = 8, RT, RH, 64
+    d = H * dh
+    q = torch.randn(B, T, d, device=dev).bfloat16()
+    k = torch.randn(B, T, d, device=dev).bfloat16()
+    ones = torch.ones(B, T, d, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(B, 1, T, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, 1, H, T, device=dev)
+    ops.chunk_attn_fwd(q, k, ones, None, out, lse, B, T, H, dh, 1, 0, T * d, d)
+    assert (out.float() - 1.0).abs().max().item() < 1e-2
+    v = torch.randn(B, T, d, device=dev).bfloat16()
+    ops.chunk_attn_fwd(q, k, v, None, out, lse, B, T, H, dh, 1, 0, T * d, d)
+    base, base_lse = out.clone(), lse.clone()
+    t = 5000                                                       # chunk 78 = [4992, 5056); next chunk ends at 5120
+    k2 = k.clone(); k2[:, t] = k2[:, t] * -1.5
+    ops.chunk_attn_fwd(q, k2, v, None, out, lse, B, T, H, dh, 1, 0, T * d, d)
+    lo, hi = t, (t // 64 + 2) * 64
+    assert torch.equal(out[:, :, :lo], base[:, :, :lo]) and torch.equal(out[:, :, hi:], base[:, :, hi:])
+    assert torch.equal(lse[..., :lo], base_lse[..., :lo]) and torch.equal(lse[..., hi:], base_lse[..., hi:])
+    changed = (out[:, :, lo:hi] != base[:, :, lo:hi]).any(-1).float().mean().item()
+    assert changed > 0.9
+
+
+def test_reformer_model_properties_at_c4(dev):
+    """the C4 model (3 local + 3 LSH layers, T = 8192) with the hash rotations given explicitly: finite logits of the right
+    shape, an initial loss near ln V, batch equivariance bit for bit; and the all-local variant is bit-exactly causal"""
+    import math
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    cfg = MyReformerConfig('small', vocab_size=V, max_position_embeddings=RT, axial_pos_shape=(64, 128), num_hashes=1)
+    m = MyReformerModelWithLMHead(cfg, device=dev, seed=3).eval()
+    torch.manual_seed(2)
+    ids = torch.randint(4, V, (2, RT), device=dev)
+    rot = {l: torch.randn(RH, 64, 1, 16) for l, kind in enumerate(cfg.attn_layers) if kind == 'lsh'}     # buckets [16, 16]
+    o = m(input_ids=ids, labels=ids, rotations=rot)
+    lg = o.logits.float().clone()                   # the logits are a view of the engine's workspace: keep a copy
+    assert lg.shape == (2, RT, V) and torch.isfinite(lg).all()
+    assert abs(o.loss.item() - math.log(V)) < 0.5
+    o_sw = m(input_ids=ids.flip(0), rotations=rot)
+    assert torch.equal(o_sw.logits.float().flip(0), lg)
+    # every LSH layer really sorted 8192 keys into 256 buckets
+    for l in rot:
+        b = m.engine.last_buckets[l]
+        assert b.min().item() >= 0 and b.max().item() < 256 and b.unique().numel() > 200
+    del m, o, o_sw
+    cfg_l = MyReformerConfig('small', vocab_size=V, max_position_embeddings=RT, axial_pos_shape=(64, 128), num_hashes=1,
+                             attn_layers=['local'] * 6)
+    ml = MyReformerModelWithLMHead(cfg_l, device=dev, seed=3).eval()
+    a = ml(input_ids=ids).logits.float().clone()
+    t = 6000
+    ids2 = ids.clone(); ids2[:, t] = (ids2[:, t] + 11) % (V - 4) + 4
+    b2 = ml(input_ids=ids2).logits.float()
+    assert torch.equal(a[:, :t], b2[:, :t]) and not torch.equal(a[:, t:], b2[:, t:])
