@@ -107,9 +107,8 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
     }
 }
 
-// One 1x4 output quad (row m, columns n..n+3, n < N): alpha, bias, relu, dropout, relu-backward mask, aux add, store.
-__device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_) {
-            float v[4];
+// One 1x4 output quad (row m, columns n..n+3, n < N): alpha, bias, relu, dropout, relu-backward mask, aux add ...
+__device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_, float (&v)[4]) {
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = a4_[r] * p.alpha;
             const bool full = (n + 3 < p.N);
@@ -158,6 +157,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, c
                         if (n + r < p.N) v[r] += bf2f(p.aux[(size_t)m * p.ldaux + n + r]);
                 }
             }
+}
+// ... and its store
+__device__ __forceinline__ void epilogue_store(const GemmP& p, const int flags, const int m, const int n, const float (&v)[4]) {
+            const bool full = (n + 3 < p.N);
             if (flags & MXL_GEMM_OUT_F32_ATOMIC) {
                 float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
 #pragma unroll
@@ -174,12 +177,53 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, c
                 bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
                 if (full && ((p.ldc & 3) == 0)) {
                     u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(c) = o;
+                    if (flags & (1 << 30)) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(c));
+                    else *reinterpret_cast<u32x2*>(c) = o;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++) if (n + r < p.N) c[r] = f2bf(v[r]);
                 }
             }
+}
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_) {
+    float v[4];
+    epilogue_vals(p, flags, m, n, a4_, v);
+    epilogue_store(p, flags, m, n, v);
+}
+// Two quads of one row in neighbouring 16-column blocks (columns n and n + 16, both inside the matrix), bf16 output with 16-byte
+// aligned rows: lanes l and l ^ 16 trade one packed quad each (v_permlane16_swap) so that every lane holds 8 consecutive columns
+// and the pair leaves as ONE 16-byte store per lane -- a wave instruction then writes 16 rows x 64 contiguous bytes instead of
+// 16 x 32.  The store path of a CU handles ~30 ns per wave-instruction made of 32-byte row segments but ~11 ns per instruction
+// made of 64-byte segments, and half as many instructions (scripts/ubench/stores.hip: a 256 x 256 bf16 tile leaves a CU in 8.1 us
+// the first way, 1.4 us the second -- with no other CU active).
+__device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
+                                                   const f32x4 q0, const f32x4 q1) {
+    float v0[4], v1[4];
+    epilogue_vals(p, flags, m, n, q0, v0);
+    epilogue_vals(p, flags, m, n + 16, q1, v1);
+    unsigned a0 = pack2bf(v0[0], v0[1]), a1 = pack2bf(v0[2], v0[3]), b0 = pack2bf(v1[0], v1[1]), b1 = pack2bf(v1[2], v1[3]);
+    // even 16-lane rows keep block 0 and receive the neighbour's block-0 quad; odd rows keep block 1 and receive the neighbour's
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    const int col = ((l >> 4) & 1) ? n + 16 - 4 : n;
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + col;
+    *reinterpret_cast<u32x4*>(c) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+// The same for two quads of one 16-column block in neighbouring row blocks (rows m and m + 16): even 16-lane rows end up with 8
+// consecutive columns of row m, odd ones with 8 consecutive columns of row m + 16 (32-byte row segments, but 16 bytes per lane
+// and half the instructions).
+__device__ __forceinline__ void epilogue_rowpair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
+                                                      const f32x4 q0, const f32x4 q1) {
+    float v0[4], v1[4];
+    epilogue_vals(p, flags, m, n, q0, v0);
+    epilogue_vals(p, flags, m + 16, n, q1, v1);
+    unsigned a0 = pack2bf(v0[0], v0[1]), a1 = pack2bf(v0[2], v0[3]), b0 = pack2bf(v1[0], v1[1]), b1 = pack2bf(v1[2], v1[3]);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    const bool odd = (l >> 4) & 1;
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)(odd ? m + 16 : m) * p.ldc + (odd ? n - 4 : n);
+    *reinterpret_cast<u32x4*>(c) = u32x4{r0[0], r1[0], r0[1], r1[1]};
 }
 
 template <bool AT, bool BT, int BN_>
@@ -306,12 +350,22 @@ constexpr int G2_OP_BYTES = 256 * 32 * 2;      // one operand, one stage: [256 r
 constexpr int G2_STAGE = 2 * G2_OP_BYTES;
 constexpr int G2_SMEM = 4 * G2_STAGE;          // 128 KiB
 
+// Slot swizzle of the [rows][32 k] bf16 images (64-byte rows, four 16-byte slots): row r keeps k-chunk c in slot c ^ f(r/4 mod 4)
+// with f = {0, 2, 3, 1}.  ds_read_b128 is serviced in four 16-lane groups -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
+// same + 32 -- so with fragment lanes = (row l & 15, k-group l >> 4) one group holds rows 0-3 and 12-15 of one k-group and rows
+// 4-11 of its neighbour g ^ 1: the four rows that share r mod 4 (same 64-byte quarter of the 256-byte bank row) must land in four
+// different slots, i.e. {f0, f1 ^ 1, f2 ^ 1, f3} distinct.  The identity (c ^ (r/4 mod 4)) gives {0, 0, 3, 3}: a 2-way conflict on
+// every fragment read, 8 LDS cycles instead of 4 (measured: +2-3 % on the C3 shapes).
+__device__ __forceinline__ int g2_swz(int rb) { return ((((rb ^ (rb >> 1)) & 1) << 1) | (rb >> 1)) & 3; }
+
 typedef __attribute__((address_space(1))) const void* g2_gptr;
 typedef __attribute__((address_space(3))) void* g2_lptr;
 
 template <int NFN>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     constexpr int BN = 64 * NFN;
+    constexpr int WN = 4, WM = 2;                           // wave grid: 2 x 4 waves of 128 x BN/4
+    constexpr int FM = 16 / WM, FN = BN / 16 / WN;          // 16 x 16 fragments per wave: 8 rows x NFN columns
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int G = gridDim.x;
@@ -325,17 +379,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     const int S = my_tiles * nk;                              // flattened K-steps of this workgroup
 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int wr = wid >> 2, wc = wid & 3;
+    const int wr = wid / WN, wc = wid % WN;
 
     // ---- issue side.  DMA instruction i of wave w fills LDS rows (8i + w) * 16 .. +15 of an operand image (16 rows x 64 B,
-    // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ (l >> 4).
+    // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ g2_swz((row >> 2) & 3) = (l & 3) ^ g2_swz(l >> 4).
     // With BN = 192 the B image has 12 row groups: waves 4..7 issue three DMAs per step instead of four, and count their
     // waits accordingly (`per_step`, wave-uniform).
     unsigned ga[2], gb[2];          // element offsets of this lane's source rows (+ k-chunk): 32 bits (host check)
     int gi = 0, i_t = 0, i_tile = bid;
     auto set_ptrs = [&](int tile) {
         const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-        const int kc = ((l & 3) ^ (l >> 4)) * 8;
+        const int kc = ((l & 3) ^ g2_swz(l >> 4)) * 8;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int row = (8 * i + wid) * 16 + (l >> 2);
@@ -361,18 +415,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         }
     };
     // ---- fragment addresses: row = base + (l & 15), k-group g = l >> 4 sits in slot g ^ ((row >> 2) & 3)
-    const int fsw = ((l >> 4) ^ ((l >> 2) & 3)) << 4;
-    const int a_off = (wr * 128 + (l & 15)) * 64 + fsw;
-    const int b_off = G2_OP_BYTES + (wc * (BN / 4) + (l & 15)) * 64 + fsw;
-    auto frags = [&](int g, bf16x8 (&fa)[8], bf16x8 (&fb)[NFN]) {
+    const int fsw = ((l >> 4) ^ g2_swz((l >> 2) & 3)) << 4;
+    const int a_off = (wr * (FM * 16) + (l & 15)) * 64 + fsw;
+    const int b_off = G2_OP_BYTES + (wc * (FN * 16) + (l & 15)) * 64 + fsw;
+    auto frags = [&](int g, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN]) {
         const char* st = smem + (g & 3) * G2_STAGE;
 #pragma unroll
-        for (int j = 0; j < NFN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
+        for (int j = 0; j < FN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
+        for (int i = 0; i < FM; i++) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
     };
 
-    f32x4 acc[8][NFN];
+    f32x4 acc[FM][FN];
     // prologue: three steps in flight, steps 0 and 1 landed before the first barrier
     issue_next();
     if (S > 1) issue_next();
@@ -382,21 +436,21 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 fa0[8], fb0[NFN], fa1[8], fb1[NFN];
+    bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
     frags(0, fa0, fb0);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): nothing outstanding at loop entry, the loop body needs no wait before its MFMAs
 
     int g = 0;                              // flattened step being computed
-    auto step = [&](bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[8], bf16x8 (&fb)[NFN], bf16x8 (&na)[8],
-                    bf16x8 (&nb)[NFN]) {
+    auto step = [&](bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN], bf16x8 (&na)[FM],
+                    bf16x8 (&nb)[FN]) {
         const bool issued = gi < S;
         if (issued) issue_next();
         if (g + 1 < S) frags(g + 1, na, nb);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < FM; i++)
 #pragma unroll
-            for (int j = 0; j < NFN; j++)
+            for (int j = 0; j < FN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
                                                                     __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -414,25 +468,42 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll 1
     for (int tile = bid; tile < nwg; tile += G) {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < FM; i++)
 #pragma unroll
-            for (int j = 0; j < NFN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int t = 0; t < nk; t += 2) {
             step(t == 0 && tile != bid, false, fa0, fb0, fa1, fb1);
             step(false, t + 2 >= nk, fa1, fb1, fa0, fb0);
         }
-        // epilogue.  acc[i][j][r]: m = m0 + wr*128 + i*16 + (l&15), n = n0 + wc*(BN/4) + j*16 + (l>>4)*4 + r
+        // epilogue.  acc[i][j][r]: m = m0 + wr*FM*16 + i*16 + (l&15), n = n0 + wc*FN*16 + j*16 + (l>>4)*4 + r
         const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BN;
+        const bool pairs = !(flags & MXL_GEMM_OUT_F32) && n0 + BN <= p.N && m0 + 256 <= p.M && (p.ldc & 7) == 0 &&
+                           (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;                 // workgroup-uniform: interior tile
+        if (pairs) {
+            // 16-byte stores: column blocks (0,1), (2,3) of a row block pair up; with three column blocks the third one pairs up
+            // across row blocks (i, i+1)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int m = m0 + wr * 128 + i * 16 + (l & 15);
-            if (m >= p.M) continue;
+            for (int i = 0; i < FM; i++) {
+                const int m = m0 + wr * (FM * 16) + i * 16 + (l & 15);
 #pragma unroll
-            for (int j = 0; j < NFN; j++) {
-                const int n = n0 + wc * (BN / 4) + j * 16 + (l >> 4) * 4;
-                if (n >= p.N) continue;
-                epilogue_quad(p, flags, m, n, acc[i][j]);
+                for (int j = 0; j + 1 < FN; j += 2)
+                    epilogue_pair_bf16(p, flags, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1]);
+                if ((FN & 1) && !(i & 1))
+                    epilogue_rowpair_bf16(p, flags, m, n0 + wc * (FN * 16) + (FN - 1) * 16 + (l >> 4) * 4, l, acc[i][FN - 1],
+                                          acc[(i + 1) % FM][FN - 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; i++) {
+                const int m = m0 + wr * (FM * 16) + i * 16 + (l & 15);
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+                    const int n = n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4;
+                    if (n >= p.N) continue;
+                    epilogue_quad(p, flags, m, n, acc[i][j]);
+                }
             }
         }
     }
@@ -471,6 +542,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     p.ksplit = per * BK;
     p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.alpha = alpha; p.flags = flags;
     p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
+    { static const bool nt = getenv("MXL_GEMM_NT") != nullptr; if (nt) p.flags |= (1 << 30); }
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
     const int BN = (N <= 64) ? 64 : 128;
