@@ -226,7 +226,11 @@ __device__ __forceinline__ void epilogue_rowpair_bf16(const GemmP& p, const int 
     *reinterpret_cast<u32x4*>(c) = u32x4{r0[0], r1[0], r0[1], r1[1]};
 }
 
-template <bool AT, bool BT, int BN_>
+// SWAP (the split-K weight-gradient form: fp32 atomics, no other epilogue work): the MFMAs are issued (A, B) instead of (B, A), so a
+// lane owns one COLUMN and 4 consecutive rows of a fragment, and each of the 4 atomic instructions of a fragment covers 4 rows x
+// 64 contiguous bytes.  In the (B, A) layout an atomic instruction is 16 rows x 4 separate dwords: measured on 128 x 128 fp32
+// tiles from 512 colliding workgroups (scripts/ubench/atomic_tiles.hip) that form sustains 0.32 TB/s chip-wide, this one 1.35.
+template <bool AT, bool BT, int BN_, bool SWAP = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     constexpr int BN = BN_;              // 128, or 64 for skinny-N problems (the per-head dRd contraction: N = d_head)
     constexpr int NF = BN / 32;          // 16-wide n-fragments per wave
@@ -291,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < NF; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(mfma_bf16x8, fb[j]), __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
+                                                                               __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
+                                                                               __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         }
         if (more) {
             char* da = smem + (cur ^ 1) * STAGE;
@@ -303,6 +309,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
         cur ^= 1;
     }
 
+    if (SWAP) {   // acc[i][j][r]: m = m0 + wr*64 + i*16 + (l>>4)*4 + r, n = n0 + wc*(BN/2) + j*16 + (l&15)
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < NF; j++) {
+                const int n = n0 + wc * (BN / 2) + j * 16 + (l & 15);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = m0 + wr * 64 + i * 16 + (l >> 4) * 4 + r;
+                    if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                }
+            }
+        return;
+    }
     // epilogue.  acc[i][j][r]: m = m0 + wr*64 + i*16 + (l&15), n = n0 + wc*(BN/2) + j*16 + (l>>4)*4 + r
     const int flags = p.flags;
     const int mrow_l = l & 15, nq = (l >> 4) * 4;
@@ -590,6 +611,11 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         if (BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, 64>), grid, block, 2 * (TILE_BYTES + 64 * BK * 2), s, p); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, 128>), grid, block, 4 * TILE_BYTES, s, p);                      \
     } while (0)
+    const int epi = MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX | MXL_GEMM_OUT_F32;
+    if (transA && transB && (p.flags & MXL_GEMM_OUT_F32_ATOMIC) && !(p.flags & epi)) {     // weight gradients, dRd fallback
+        if (BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 64, true>), grid, block, 2 * (TILE_BYTES + 64 * BK * 2), s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 128, true>), grid, block, 4 * TILE_BYTES, s, p);
+    } else
     if (!transA && !transB) MXL_GEMM_LAUNCH(false, false);
     else if (!transA && transB) MXL_GEMM_LAUNCH(false, true);
     else if (transA && !transB) MXL_GEMM_LAUNCH(true, false);
