@@ -940,8 +940,8 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
-                                                                    __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
         // step g + 1 must have landed before the next iteration reads it: leave the two youngest steps in flight
         if (issued) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else if (g + 2 < S) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -949,18 +949,18 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    // acc[i][j][r]: distance d0 + 64 wid + 16i + (l & 15), e = 16j + 4*(l >> 4) + r   (MFMA issued (B, A))
+    // acc[i][j][r]: distance d0 + 64 wid + 16i + 4*(l >> 4) + r, e = 16j + (l & 15)   (MFMA issued (A, B): a lane owns one
+    // column, so an atomic instruction covers 4 rows x 64 contiguous bytes -- the (B, A) layout's 16 rows x 4 separate dwords
+    // run at a quarter of the atomic throughput, scripts/ubench/atomic_tiles.hip)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dd = d0 + 64 * wid + 16 * i + (l & 15);
-        if (dd >= p.M) continue;
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float* o = p.drd + (size_t)dd * p.drd_ld + h * 64 + 16 * j + 4 * (l >> 4);
+        for (int r = 0; r < 4; r++) {
+            const int dd = d0 + 64 * wid + 16 * i + 4 * (l >> 4) + r;
+            if (dd >= p.M) continue;
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(o + r, acc[i][j][r]);
+            for (int j = 0; j < 4; j++) atomicAdd(p.drd + (size_t)dd * p.drd_ld + h * 64 + 16 * j + (l & 15), acc[i][j][r]);
         }
-    }
 }
 
 template <int DH>
