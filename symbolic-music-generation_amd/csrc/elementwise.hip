@@ -238,7 +238,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
     if (col + 7 < N && (ld & 7) == 0) {
-        for (int r = r0 + rl; r < r1; r += 8) {
+        int r = r0 + rl;
+        for (; r + 24 < r1; r += 32) {            // four independent 16-byte loads in flight per thread
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 8) * ld + col);
+            const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 16) * ld + col);
+            const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 24) * ld + col);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                acc[j] += (bf2f((bf16_t)v0[j]) + bf2f((bf16_t)v1[j])) + (bf2f((bf16_t)v2[j]) + bf2f((bf16_t)v3[j]));
+        }
+        for (; r < r1; r += 8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)v[j]);
@@ -416,7 +426,7 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
 
 extern "C" int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream) {
     MXL_CHECK_ARG(X && out && M > 0 && N > 0 && ld >= N);
-    const int rpb = 512;
+    const int rpb = 128;      // 768 blocks for a 32768 x 768 matrix: three per CU, four loads in flight per thread
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)X, out, M, N, ld, rpb);
     MXL_LAUNCH_CHECK();

@@ -451,3 +451,17 @@ def test_relattn_fwd_matches_hf_xlnet_core(dev, idx):
                     Kc=Kc, q_bs=T * d, q_rs=d, kv_bs=Kc * d, kv_rs=d, rd_rs=d, o_bs=T * d, o_rs=d)
     ref = c['attn_vec'].permute(1, 0, 2, 3).reshape(B, T, d)
     assert rel_err(out.float().cpu(), ref) < 2.5e-2          # bf16 operands and output against an fp32 reference
+
+
+@pytest.mark.parametrize('M,N,ld', [(32768, 768, 768), (1000, 1190, 1216), (37, 72, 80), (4099, 3072, 3072), (129, 5, 8)])
+def test_colsum_accumulates_column_sums(dev, M, N, ld):
+    """bias-gradient reduction: out[n] += sum_m X[m][n] (bf16 in, fp32 out), ragged row counts / widths / padded rows"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(M + N)
+    buf = torch.randn(M, ld, device=dev).bfloat16()
+    x = buf[:, :N]
+    out = torch.full((N,), 2.5, device=dev)
+    ops.colsum(buf, out, M, N) if ld == N else ops.colsum(x, out, M, N)
+    want = x.double().sum(0) + 2.5
+    err = (out.double() - want).abs().max().item()
+    assert err < 2e-3 * max(1.0, M ** 0.5), err
