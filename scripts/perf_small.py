@@ -22,3 +22,21 @@ for d in (768, 3072, 2304):
         ops.colsum(X[i[0] % 3], out, N, d)
     t = timeit(f)
     print(f'colsum {N}x{d}: {t:.1f} us = {N*d*2/t/1e6:.2f} TB/s')
+for d in (768, 512):
+    x = [torch.randn(N, d, device=dev).bfloat16() for _ in range(3)]
+    res = torch.randn(N, d, device=dev).bfloat16()
+    gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    y = torch.empty(N, d, device=dev, dtype=torch.bfloat16); z = torch.empty_like(y)
+    mean, rstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    i = [0]
+    def ff():
+        i[0] += 1
+        ops.ln_residual_fwd(x[i[0] % 3], res, gam, bet, y, z, mean, rstd, drop_p=0.1, seed=1, site=2)
+    t = timeit(ff)
+    print(f'ln fwd {N}x{d} (dropout): {t:.1f} us = {N*d*2*4/t/1e6:.2f} TB/s (4 streams)')
+    dres = torch.empty_like(y); dx = torch.empty_like(y); dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    def fb():
+        i[0] += 1
+        ops.ln_residual_bwd(x[i[0] % 3], x[(i[0] + 1) % 3], z, mean, rstd, gam, dres, dx, dg, db, drop_p=0.1, seed=1, site=2)
+    t = timeit(fb)
+    print(f'ln bwd {N}x{d} (2 grads in, dres + dx out): {t:.1f} us = {N*d*2*5/t/1e6:.2f} TB/s (5 streams)')
