@@ -55,6 +55,12 @@ int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
  * flags: MXL_GEMM_OUT_F32 | MXL_GEMM_BIAS | MXL_GEMM_RELU.  Deterministic (fixed-order in-workgroup split-K). */
 int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc, int flags,
                          const float* bias, void* stream);
+/* The qkv projection of one decode step with the cache append in its epilogue (one launch instead of mxl_gemm_skinny_bf16 +
+ * mxl_kv_append): qkv (B, 3d) = x (B, d) . Wqkv (3d, d)^T; the k / v thirds also go into the head-major rings
+ * (B, H, Mring, dh) at slot *t_dev % Mring and q + r_r_bias into qr_out (B, d) -- HF's `cat([mems, h])` + qkv_net on the one
+ * new row.  B <= 64. */
+int mxl_decode_qkv(const void* x, const void* Wqkv, void* qkv, void* kcache, void* vcache, const int* t_dev,
+                   const float* r_r_bias, void* qr_out, int B, int d, int dh, int Mring, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Relative-position banded attention (K4).  Replaces RelPartialLearnableMultiHeadAttn.forward between qkv_net and

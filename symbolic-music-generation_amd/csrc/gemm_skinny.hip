@@ -14,6 +14,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 struct SkP {
     const bf16_t* A; const bf16_t* W; void* C; const float* bias;
     int M, N, K, lda, ldw, ldc, flags;
+    // decode qkv projection (mxl_decode_qkv): N = 3 d; besides C, column block [0,d) also leaves as q + r_r_bias into qr (M, d),
+    // [d,2d) / [2d,3d) are appended to the head-major K / V rings (B, H, Mring, dh) at slot *t_dev % Mring
+    bf16_t* kc; bf16_t* vc; bf16_t* qr; const float* rrb; const int* t_dev; int d, dh, Mring;
 };
 
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
@@ -53,6 +56,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
 #pragma unroll
         for (int r = 0; r < 4; r++) red[wid][(mf * 16 + li) * 16 + (l >> 4) * 4 + r] = acc[mf][r];
     __syncthreads();
+    int kv_part = 0, kv_col0 = 0;
+    size_t kv_off = 0, kv_bstride = 0;
+    if (p.kc) {
+        kv_part = n0 / p.d;
+        kv_col0 = n0 - kv_part * p.d;
+        const int hh = kv_col0 / p.dh, e0 = kv_col0 - hh * p.dh, slot = (*p.t_dev) % p.Mring;
+        kv_bstride = (size_t)(p.d / p.dh) * p.Mring * p.dh;
+        kv_off = ((size_t)hh * p.Mring + slot) * p.dh + e0;
+    }
     for (int i = tid; i < 64 * 16; i += 512) {
         const int m = i >> 4, nn = n0 + (i & 15);
         if (m < p.M && nn < p.N) {
@@ -61,6 +73,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
             if (p.flags & MXL_GEMM_RELU) v = fmaxf(v, 0.f);
             if (p.flags & MXL_GEMM_OUT_F32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nn] = v;
             else reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(v);
+            if (p.kc) {                                        // workgroup-uniform: its 16 columns sit in one third and one head
+                const bf16_t vb = f2bf(v);                     // the rings and qr see the value the qkv buffer holds
+                if (kv_part == 0) p.qr[(size_t)m * p.d + kv_col0 + (i & 15)] = f2bf(bf2f(vb) + p.rrb[kv_col0 + (i & 15)]);
+                else (kv_part == 1 ? p.kc : p.vc)[(size_t)m * kv_bstride + kv_off + (i & 15)] = vb;
+            }
         }
     }
 }
@@ -77,7 +94,23 @@ extern "C" int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M
     SkP p;
     p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.flags = flags;
+    p.kc = nullptr; p.vc = nullptr; p.qr = nullptr; p.rrb = nullptr; p.t_dev = nullptr; p.d = p.dh = p.Mring = 0;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(512), 0, (hipStream_t)stream, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_decode_qkv(const void* x, const void* Wqkv, void* qkv, void* kcache, void* vcache, const int* t_dev,
+                              const float* r_r_bias, void* qr_out, int B, int d, int dh, int Mring, void* stream) {
+    MXL_CHECK_ARG(x && Wqkv && qkv && kcache && vcache && t_dev && r_r_bias && qr_out);
+    MXL_CHECK_ARG(B > 0 && B <= 64 && d > 0 && (d % 16) == 0 && dh > 0 && (dh % 16) == 0 && (d % dh) == 0 && Mring > 0);
+    MXL_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)Wqkv % 16) == 0);
+    SkP p;
+    p.A = (const bf16_t*)x; p.W = (const bf16_t*)Wqkv; p.C = qkv; p.bias = nullptr;
+    p.M = B; p.N = 3 * d; p.K = d; p.lda = d; p.ldw = d; p.ldc = 3 * d; p.flags = 0;
+    p.kc = (bf16_t*)kcache; p.vc = (bf16_t*)vcache; p.qr = (bf16_t*)qr_out; p.rrb = r_r_bias; p.t_dev = t_dev;
+    p.d = d; p.dh = dh; p.Mring = Mring;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((3 * d + 15) / 16), dim3(512), 0, (hipStream_t)stream, p);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

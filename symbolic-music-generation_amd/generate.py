@@ -99,9 +99,13 @@ class XLDecoder:
         ops.decode_embed(self.ids, self.t_dev, E, self.h[0], math.sqrt(d))
         for l in range(L):
             h_in, h_out = self.h[l & 1], self.h[(l + 1) & 1]
-            G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
             rrb = e._lw(l, 'dec_attn.r_r_bias', e.P)
-            ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev, rrb=rrb.reshape(-1), qr_out=self.qr)
+            if B <= 64:      # projection, ring append and q + r_r_bias in one launch
+                ops.decode_qkv(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, self.kc[l], self.vc[l], self.t_dev,
+                               rrb.reshape(-1), self.qr, dh)
+            else:
+                G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
+                ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev, rrb=rrb.reshape(-1), qr_out=self.qr)
             ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
                                rrb, self.av, self.t_dev, H, dh, self.qr, self.bd, qr_ready=True)
             G(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)

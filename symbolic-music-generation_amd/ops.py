@@ -65,6 +65,13 @@ def gemm_skinny(a, w, c, M, N, K, *, flags=0, bias=None, lda=None, ldw=None, ldc
     return c
 
 
+def decode_qkv(x, wqkv, qkv, kc, vc, t_dev, rrb, qr_out, dh):
+    """one decode step's qkv projection + K/V ring append + (q + r_r_bias), fused (batch <= 64)"""
+    B, d = x.shape
+    check(lib().mxl_decode_qkv(_p(x), _p(wqkv), _p(qkv), _p(kc), _p(vc), _p(t_dev), _p(rrb), _p(qr_out), B, d, dh, kc.shape[-2],
+                               _stream()), 'mxl_decode_qkv')
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, relu=False, out=None,
            out_f32=False, drop_p=0.0, seed=0, site=0) -> torch.Tensor:
     """y = x @ w.T (+bias)(relu)(dropout); x (N, K) bf16, w (O, K) bf16."""
