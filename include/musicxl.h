@@ -55,6 +55,15 @@ int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
  * flags: MXL_GEMM_OUT_F32 | MXL_GEMM_BIAS | MXL_GEMM_RELU.  Deterministic (fixed-order in-workgroup split-K). */
 int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc, int flags,
                          const float* bias, void* stream);
+/* Narrow-N / long-K decode linears (the FFN output projection: N = d, K = 4d): K is sliced over workgroups as well; slice s
+ * writes its fp32 partial product to slabs[s] ((64, N) each, rows < M written) and mxl_ln_residual_fwd_partial finishes the
+ * linear: y = LayerNorm(res + bf16(sum_s slabs[s] + bias)) -- reduction, bias and the post-LN residual in one launch.
+ * (Two launches with a kernel boundary between them: a single-kernel reduction needs device-scope fences that cost more, on
+ * eight L2 domains, than the slicing saves.) */
+int mxl_gemm_skinny_partial(const void* A, const void* W, float* slabs, int M, int N, int K, int lda, int ldw, int KS,
+                            void* stream);
+int mxl_ln_residual_fwd_partial(const float* slabs, int KS, long long slab_stride, const float* bias, const void* res,
+                                const float* gamma, const float* beta, void* y, int N, int d, float eps, void* stream);
 /* The qkv projection of one decode step with the cache append in its epilogue (one launch instead of mxl_gemm_skinny_bf16 +
  * mxl_kv_append): qkv (B, 3d) = x (B, d) . Wqkv (3d, d)^T; the k / v thirds also go into the head-major rings
  * (B, H, Mring, dh) at slot *t_dev % Mring and q + r_r_bias into qr_out (B, d) -- HF's `cat([mems, h])` + qkv_net on the one

@@ -134,6 +134,68 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
     }
 }
 
+// y = LayerNorm(res + bf16(sum_s slab_s + bias)): the consumer of mxl_gemm_skinny_partial -- the K-slice reduction, the bias and
+// the post-LN residual of a decode-step linear in one launch (inference: no dropout, nothing saved for a backward)
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_res_partial_fwd_kernel(const float* slabs, int KS, long long slab_stride, const float* bias,
+                                                                 const bf16_t* res, const float* gamma, const float* beta, bf16_t* y,
+                                                                 int N, int d, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int chunks = d >> 3;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = 0.f;
+            for (int sl = 0; sl < KS; sl++) {
+                const float* pp = slabs + (size_t)sl * slab_stride + (size_t)row * d + c * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+            }
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (size_t)row * d + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float t = a[j] + (bias ? bias[c * 8 + j] : 0.f);
+                t = bf2f(f2bf(t)) + bf2f((bf16_t)rv[j]);          // the linear's output is a bf16 tensor in the unfused path
+                t = bf2f(f2bf(t));
+                v[i][j] = t;
+                s += t;
+            }
+        }
+    }
+    s = wave_sum(s);
+    const float mu = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float t = v[i][j] - mu; q += t * t; }
+        }
+    }
+    q = wave_sum(q);
+    const float rs = rsqrtf(q / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
+            u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(y + (size_t)row * d + c * 8) = ov;
+        }
+    }
+}
+
 // backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dres = dz (+ dres_in);  dx = keep*dscale*dz
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy : per-block partials through LDS, then one fp32 atomic per column.
 constexpr int LNB_ROWS = 64;  // rows per block (8 waves x 8 rows): 2d atomics per block, 4096 waves for the 32768-row C3 matrices
@@ -420,6 +482,17 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
     hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_ln_residual_fwd_partial(const float* slabs, int KS, long long slab_stride, const float* bias, const void* res,
+                                           const float* gamma, const float* beta, void* y, int N, int d, float eps, void* stream) {
+    MXL_CHECK_ARG(slabs && res && gamma && beta && y && KS >= 1 && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    MXL_CHECK_ARG(slab_stride >= (long long)N * d && ((uintptr_t)slabs % 16) == 0 && (slab_stride % 4) == 0);
+    const auto kfn = d <= 512 ? ln_res_partial_fwd_kernel<1> : d <= 1024 ? ln_res_partial_fwd_kernel<2> : ln_res_partial_fwd_kernel<LN_MAXCH>;
+    hipLaunchKernelGGL(kfn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, slabs, KS, slab_stride, bias, (const bf16_t*)res,
+                       gamma, beta, (bf16_t*)y, N, d, eps);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

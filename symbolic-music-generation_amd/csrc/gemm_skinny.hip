@@ -17,6 +17,8 @@ struct SkP {
     // decode qkv projection (mxl_decode_qkv): N = 3 d; besides C, column block [0,d) also leaves as q + r_r_bias into qr (M, d),
     // [d,2d) / [2d,3d) are appended to the head-major K / V rings (B, H, Mring, dh) at slot *t_dev % Mring
     bf16_t* kc; bf16_t* vc; bf16_t* qr; const float* rrb; const int* t_dev; int d, dh, Mring;
+    // K sliced over workgroups as well (grid.y = KS, mxl_gemm_skinny_partial): slice s writes its (64 x N) fp32 partial to slab s of ws
+    float* ws; int KS;
 };
 
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
@@ -25,9 +27,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
     const int n0 = blockIdx.x * 16;
     const int li = l & 15, kq = 8 * (l >> 4);
     // K slice of this wave (multiples of 32)
-    const int ksteps = (p.K + 31) / 32;
-    const int per = (ksteps + 7) / 8;
-    const int ks0 = wid * per, ks1 = min(ksteps, ks0 + per);
+    const int ksteps_all = (p.K + 31) / 32;
+    const int per_wg = (ksteps_all + p.KS - 1) / p.KS;                      // K-steps of this workgroup's slice (grid.y)
+    const int kw0 = blockIdx.y * per_wg, kw1 = min(ksteps_all, kw0 + per_wg);
+    const int per = (max(kw1 - kw0, 0) + 7) / 8;
+    const int ks0 = kw0 + wid * per, ks1 = min(kw1, ks0 + per);
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -65,6 +69,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
         kv_bstride = (size_t)(p.d / p.dh) * p.Mring * p.dh;
         kv_off = ((size_t)hh * p.Mring + slot) * p.dh + e0;
     }
+    if (p.ws) {      // partial product of this K slice; the consumer (mxl_ln_residual_fwd_partial) sums the slabs in slice order
+        float* slab = p.ws + (size_t)blockIdx.y * 64 * p.N;
+        for (int i = tid; i < 64 * 16; i += 512) {
+            const int m = i >> 4, nn = n0 + (i & 15);
+            if (m < p.M && nn < p.N)
+                slab[(size_t)m * p.N + nn] =
+                    ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
+        }
+        return;
+    }
     for (int i = tid; i < 64 * 16; i += 512) {
         const int m = i >> 4, nn = n0 + (i & 15);
         if (m < p.M && nn < p.N) {
@@ -95,6 +109,7 @@ extern "C" int mxl_gemm_skinny_bf16(const void* A, const void* W, void* C, int M
     p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.flags = flags;
     p.kc = nullptr; p.vc = nullptr; p.qr = nullptr; p.rrb = nullptr; p.t_dev = nullptr; p.d = p.dh = p.Mring = 0;
+    p.ws = nullptr; p.KS = 1;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(512), 0, (hipStream_t)stream, p);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
@@ -110,7 +125,23 @@ extern "C" int mxl_decode_qkv(const void* x, const void* Wqkv, void* qkv, void* 
     p.M = B; p.N = 3 * d; p.K = d; p.lda = d; p.ldw = d; p.ldc = 3 * d; p.flags = 0;
     p.kc = (bf16_t*)kcache; p.vc = (bf16_t*)vcache; p.qr = (bf16_t*)qr_out; p.rrb = r_r_bias; p.t_dev = t_dev;
     p.d = d; p.dh = dh; p.Mring = Mring;
+    p.ws = nullptr; p.KS = 1;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3((3 * d + 15) / 16), dim3(512), 0, (hipStream_t)stream, p);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_gemm_skinny_partial(const void* A, const void* W, float* slabs, int M, int N, int K, int lda, int ldw, int KS,
+                                       void* stream) {
+    MXL_CHECK_ARG(A && W && slabs && M > 0 && M <= 64 && N > 0 && K > 0 && KS >= 1 && KS <= 16);
+    MXL_CHECK_ARG((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0);
+    MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    SkP p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = nullptr; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.flags = 0;
+    p.kc = nullptr; p.vc = nullptr; p.qr = nullptr; p.rrb = nullptr; p.t_dev = nullptr; p.d = p.dh = p.Mring = 0;
+    p.ws = slabs; p.KS = KS;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16, KS), dim3(512), 0, (hipStream_t)stream, p);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

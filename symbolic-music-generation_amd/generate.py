@@ -38,6 +38,7 @@ class XLDecoder:
         self.qkv = torch.empty(batch, 3 * d, **bf)
         self.av = torch.empty(batch, d, **bf)
         self.qr = torch.empty(batch, d, **bf)
+        self.slabs = torch.zeros(4, 64, d, device=dev, dtype=torch.float32)   # K-slice partials of the FFN output projection
         self.bd = torch.empty(batch, H, M, device=dev, dtype=torch.float32)
         self.tmp = torch.empty(batch, d, **bf)
         self.h1 = torch.empty(batch, d, **bf)
@@ -113,10 +114,17 @@ class XLDecoder:
                                 e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)
             G(self.h1, e._lw(l, 'pos_ff.CoreNet.0.weight'), self.a, B, Fi, d, flags=ops.GEMM_BIAS | ops.GEMM_RELU,
               bias=e._lw(l, 'pos_ff.CoreNet.0.bias', e.P))
-            G(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.tmp, B, d, Fi, flags=ops.GEMM_BIAS,
-              bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
-            ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
-                                e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
+            if B <= 64:
+                # N = d columns are only d/16 workgroups: slice K four ways as well; the slabs are summed by the LayerNorm launch
+                ops.gemm_skinny_partial(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.slabs, B, d, Fi, 4)
+                ops.ln_residual_fwd_partial(self.slabs, 4, e._lw(l, 'pos_ff.CoreNet.3.bias', e.P), self.h1,
+                                            e._lw(l, 'pos_ff.layer_norm.weight', e.P), e._lw(l, 'pos_ff.layer_norm.bias', e.P),
+                                            h_out, eps=c.layer_norm_epsilon)
+            else:
+                G(self.a, e._lw(l, 'pos_ff.CoreNet.3.weight'), self.tmp, B, d, Fi, flags=ops.GEMM_BIAS,
+                  bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
+                ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
+                                    e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
         hid = self.h[L & 1]
         nrow, nrow_p = e.layout.n_head_rows, e.layout.head_rows_padded
         head_w = e.W[:nrow_p * d].view(nrow_p, d)

@@ -65,6 +65,20 @@ def gemm_skinny(a, w, c, M, N, K, *, flags=0, bias=None, lda=None, ldw=None, ldc
     return c
 
 
+def gemm_skinny_partial(a, w, slabs, M, N, K, KS):
+    """K-sliced skinny product: slabs (KS, 64, N) f32 receive the partial sums (finish with ln_residual_fwd_partial)"""
+    check(lib().mxl_gemm_skinny_partial(_p(a), _p(w), _p(slabs), M, N, K, a.stride(-2), w.stride(-2), KS, _stream()),
+          'mxl_gemm_skinny_partial')
+
+
+def ln_residual_fwd_partial(slabs, KS, bias, res, gamma, beta, y, eps=1e-5):
+    """y = LayerNorm(res + bf16(sum of the KS slabs + bias)); slabs (KS, 64, d) f32, res / y (N <= 64, d) bf16"""
+    N, d = res.shape
+    check(lib().mxl_ln_residual_fwd_partial(_p(slabs), KS, slabs.stride(0), _p(bias), _p(res), _p(gamma), _p(beta), _p(y), N, d,
+                                            float(eps), _stream()), 'mxl_ln_residual_fwd_partial')
+    return y
+
+
 def decode_qkv(x, wqkv, qkv, kc, vc, t_dev, rrb, qr_out, dh):
     """one decode step's qkv projection + K/V ring append + (q + r_r_bias), fused (batch <= 64)"""
     B, d = x.shape
