@@ -152,3 +152,28 @@ def test_generate_with_repetition_penalty_runs_in_graph(dev):
     # with a strong penalty greedy decoding repeats less
     rep = lambda x: sum(len(r.tolist()) - len(set(r.tolist())) for r in x[:, 12:])
     assert rep(g1) <= rep(g0)
+
+
+def test_decode_qkv_fused_equals_projection_plus_append(dev):
+    """mxl_decode_qkv == mxl_gemm_skinny_bf16 + mxl_kv_append, bit for bit: qkv buffer, both rings (only the slot of step t
+    touched), and q + r_r_bias"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(4)
+    B, d, H, dh, M = 7, 128, 8, 16, 40
+    x = (torch.randn(B, d)).bfloat16().to(dev)
+    w = (torch.randn(3 * d, d) * 0.1).bfloat16().to(dev)
+    rrb = torch.randn(d, device=dev) * 0.2
+    for t in (0, 13, 39, 40, 97):                      # 97 % 40: the ring wraps
+        t_dev = torch.full((1,), t, device=dev, dtype=torch.int32)
+        kc0 = torch.randn(B, H, M, dh, device=dev).bfloat16(); vc0 = torch.randn(B, H, M, dh, device=dev).bfloat16()
+        kc1, vc1, kc2, vc2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+        qkv1 = torch.empty(B, 3 * d, device=dev, dtype=torch.bfloat16); qkv2 = torch.empty_like(qkv1)
+        qr1 = torch.empty(B, d, device=dev, dtype=torch.bfloat16); qr2 = torch.empty_like(qr1)
+        ops.gemm_skinny(x, w, qkv1, B, 3 * d, d)
+        ops.kv_append(qkv1, kc1, vc1, t_dev, rrb=rrb, qr_out=qr1)
+        ops.decode_qkv(x, w, qkv2, kc2, vc2, t_dev, rrb, qr2, dh)
+        assert torch.equal(qkv1, qkv2) and torch.equal(qr1, qr2)
+        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+        slot = t % M
+        untouched = torch.ones(M, dtype=torch.bool); untouched[slot] = False
+        assert torch.equal(kc2[:, :, untouched], kc0[:, :, untouched]) and not torch.equal(kc2[:, :, slot], kc0[:, :, slot])
