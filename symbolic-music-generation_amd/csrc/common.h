@@ -60,6 +60,11 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint6
     const uint32_t h = mxl_hash32(((uint32_t)idx * 0x9E3779B1U) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77U) ^ mix);
     return h >= thresh;
 }
+// the same decision for an element index below 2^32 (the high-word term of dropout_keep is zero): one multiply less, no 64-bit math
+__device__ __forceinline__ bool dropout_keep32(uint64_t seed, uint32_t site, uint32_t idx, uint32_t thresh) {
+    const uint32_t mix = mxl_hash32((uint32_t)seed ^ (site * 0x9E3779B9U)) + (uint32_t)(seed >> 32);
+    return mxl_hash32((idx * 0x9E3779B1U) ^ mix) >= thresh;
+}
 static inline uint32_t dropout_thresh(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 4294967296.0;

@@ -126,11 +126,11 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
                 for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
             }
             if (flags & MXL_GEMM_DROPOUT) {
+                // 32-bit element index (host check: M * N <= 2^32): the same decisions as dropout_keep's 64-bit form, which the
+                // stand-alone dropout / LayerNorm kernels use when they regenerate a mask
+                const uint32_t i0 = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool keep = dropout_keep(p.seed, p.site, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), p.thresh);
-                    v[r] = keep ? v[r] * p.drop_scale : 0.f;
-                }
+                for (int r = 0; r < 4; r++) v[r] = dropout_keep32(p.seed, p.site, i0 + r, p.thresh) ? v[r] * p.drop_scale : 0.f;
             }
             if (flags & MXL_GEMM_RELU_BWD) {
                 if (full && ((p.ldaux & 3) == 0)) {
@@ -382,7 +382,10 @@ __device__ __forceinline__ int g2_swz(int rb) { return ((((rb ^ (rb >> 1)) & 1) 
 typedef __attribute__((address_space(1))) const void* g2_gptr;
 typedef __attribute__((address_space(3))) void* g2_lptr;
 
-template <int NFN>
+// EPI >= 0: the epilogue flags as a compile-time constant (the common combinations; EPI == 0 also means alpha == 1).  With the
+// flags only known at run time the general epilogue's pointers, dropout constants and 64-bit indices all stay live next to the 128
+// accumulators and spill (71 values at BN = 256).
+template <int NFN, int EPI = -1>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     constexpr int BN = 64 * NFN;
     constexpr int WN = 4, WM = 2;                           // wave grid: 2 x 4 waves of 128 x BN/4
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         g++;
     };
 
-    const int flags = p.flags;
+    const int flags = EPI >= 0 ? EPI : p.flags;
+    if (EPI == 0) p.alpha = 1.f;
 #pragma unroll 1
     for (int tile = bid; tile < nwg; tile += G) {
 #pragma unroll
@@ -566,6 +570,8 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     { static const bool nt = getenv("MXL_GEMM_NT") != nullptr; if (nt) p.flags |= (1 << 30); }
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
+    // the dropout mask is indexed by the 32-bit element index (kernels that regenerate it use the same index for < 2^32 elements)
+    if (p.flags & MXL_GEMM_DROPOUT) MXL_CHECK_ARG((unsigned long long)M * (unsigned long long)N <= 0xffffffffull);
     const int BN = (N <= 64) ? 64 : 128;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     MXL_CHECK_ARG(batch >= 1 && bdiv >= 1);
@@ -581,12 +587,6 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         static bool attr_set = false;
         static int n_cu = 256;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
-            if (e != hipSuccess) return (int)e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
-            if (e != hipSuccess) return (int)e;
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) == hipSuccess &&
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
@@ -600,8 +600,29 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         p.tiles_m = tm; p.tiles_n = use192 ? (N + 191) / 192 : (N + 255) / 256;
         const int ntile = p.tiles_m * p.tiles_n;
         dim3 grid(ntile < n_cu ? ntile : n_cu);
-        if (use192) hipLaunchKernelGGL(gemm_nt256_kernel<3>, grid, dim3(512), G2_SMEM, s, p);
-        else hipLaunchKernelGGL(gemm_nt256_kernel<4>, grid, dim3(512), G2_SMEM, s, p);
+        // compile-time epilogues for the combinations the engines use; everything else takes the run-time form
+#define MXL_NT256_LAUNCH(EPI_)                                                                                                   \
+    do {                                                                                                                         \
+        static bool attr_e = false;                                                                                              \
+        if (!attr_e) {                                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<4, EPI_>),                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);                             \
+            if (e != hipSuccess) return (int)e;                                                                                  \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<3, EPI_>),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);                                        \
+            if (e != hipSuccess) return (int)e;                                                                                  \
+            attr_e = true;                                                                                                       \
+        }                                                                                                                        \
+        if (use192) hipLaunchKernelGGL((gemm_nt256_kernel<3, EPI_>), grid, dim3(512), G2_SMEM, s, p);                              \
+        else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
+    } while (0)
+        if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
+        else if (p.flags == MXL_GEMM_BIAS) MXL_NT256_LAUNCH(MXL_GEMM_BIAS);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT);
+        else if (p.flags == MXL_GEMM_RELU_BWD) MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD);
+        else MXL_NT256_LAUNCH(-1);
+#undef MXL_NT256_LAUNCH
         MXL_LAUNCH_CHECK();
         return MXL_OK;
     }
