@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float a = bf2f((bf16_t)xv[j]);
-                if (thresh) a = dropout_keep(seed, site, (uint64_t)row * d + c * 8 + j, thresh) ? a * dscale : 0.f;
+                if (thresh) a = dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + j, thresh) ? a * dscale : 0.f;
                 a += bf2f((bf16_t)rv[j]);
                 // z is stored in bf16; normalise the *stored* value so forward and backward agree
                 a = bf2f(f2bf(a));
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256) void ln_res_partial_fwd_kernel(const float* sl
 
 // backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dres = dz (+ dres_in);  dx = keep*dscale*dz
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy : per-block partials through LDS, then one fp32 atomic per column.
-constexpr int LNB_ROWS = 64;  // rows per block (8 waves x 8 rows): 2d atomics per block, 4096 waves for the 32768-row C3 matrices
+#ifndef LNB_ROWS_
+#define LNB_ROWS_ 64
+#endif
+constexpr int LNB_ROWS = LNB_ROWS_;  // rows per block (8 waves x 8 rows): 2d atomics per block, 4096 waves for the 32768-row C3 matrices
 constexpr int LNB_THREADS = 512;
 
 template <int NCH>
@@ -208,10 +211,16 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
                                                          int d, unsigned thresh, float dscale, unsigned long long seed,
                                                          unsigned site, const bf16_t* dadd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sg = reinterpret_cast<float*>(smem_raw);  // [d] dgamma partial
+    // per-wave slabs [8 waves][2][d] of dgamma / dbeta partials (plain 16-byte writes, then a column-wise sum): LDS atomics from
+    // eight waves onto the same 2d addresses cost as much as several rows of work.  (NCH > 2: d up to 2048 would need 128 KB of
+    // slabs -- those keep the shared [2][d] accumulators and LDS atomics.)
+    constexpr bool SLABS = NCH <= 2;
+    float* sg = reinterpret_cast<float*>(smem_raw);  // [d] dgamma partial (slab 0 when SLABS)
     float* sb = sg + d;                              // [d] dbeta partial
-    for (int i = threadIdx.x; i < 2 * d; i += LNB_THREADS) sg[i] = 0.f;
-    __syncthreads();
+    if (!SLABS) {
+        for (int i = threadIdx.x; i < 2 * d; i += LNB_THREADS) sg[i] = 0.f;
+        __syncthreads();
+    }
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunks = d >> 3;
     float ag[NCH][8], ab[NCH][8];
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
                 for (int j = 0; j < 8; j++) {
                     o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
                     ox[j] = o[j];
-                    if (thresh) ox[j] = dropout_keep(seed, site, (uint64_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
+                    if (thresh) ox[j] = dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
                 }
                 if (dres) {
                     if (dadd) {
@@ -272,6 +281,27 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
                 }
             }
         }
+    }
+    if (SLABS) {
+        float* mg = sg + (size_t)wid * 2 * d;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = lane + i * 64;
+            if (c < chunks) {
+                *reinterpret_cast<f32x4*>(mg + c * 8) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
+                *reinterpret_cast<f32x4*>(mg + c * 8 + 4) = f32x4{ag[i][4], ag[i][5], ag[i][6], ag[i][7]};
+                *reinterpret_cast<f32x4*>(mg + d + c * 8) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+                *reinterpret_cast<f32x4*>(mg + d + c * 8 + 4) = f32x4{ab[i][4], ab[i][5], ab[i][6], ab[i][7]};
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * d; i += LNB_THREADS) {       // i < d: dgamma column i, else dbeta column i - d
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < LNB_THREADS / 64; w++) t += sg[(size_t)w * 2 * d + i];
+            atomicAdd((i < d ? dgamma : dbeta - d) + i, t);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
@@ -453,6 +483,7 @@ extern "C" int mxl_ln_residual_fwd(const void* x, const void* res, const float* 
                                    void* z, float* mean, float* rstd, int N, int d, float eps, float drop_p,
                                    unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(x && gamma && beta && y && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    MXL_CHECK_ARG(drop_p <= 0.f || (unsigned long long)N * d <= 0xffffffffull);      // the dropout mask is indexed in 32 bits
     const auto kfn = d <= 512 ? ln_res_fwd_kernel<1> : d <= 1024 ? ln_res_fwd_kernel<2> : ln_res_fwd_kernel<LN_MAXCH>;
     hipLaunchKernelGGL(kfn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (const bf16_t*)res, gamma, beta, (bf16_t*)y, (bf16_t*)z, mean, rstd, N, d, eps,
@@ -465,8 +496,9 @@ extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* 
                                    const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
                                    float drop_p, unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    MXL_CHECK_ARG(drop_p <= 0.f || (unsigned long long)N * d <= 0xffffffffull);
     const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
-    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), 2 * d * sizeof(float),
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (d <= 1024 ? LNB_THREADS / 64 : 1) * 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr);
@@ -479,7 +511,7 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
                                        int d, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dres && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
     const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
-    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), 2 * d * sizeof(float),
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (d <= 1024 ? LNB_THREADS / 64 : 1) * 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
     MXL_LAUNCH_CHECK();
