@@ -40,3 +40,9 @@ for d in (768, 512):
         ops.ln_residual_bwd(x[i[0] % 3], x[(i[0] + 1) % 3], z, mean, rstd, gam, dres, dx, dg, db, drop_p=0.1, seed=1, site=2)
     t = timeit(fb)
     print(f'ln bwd {N}x{d} (2 grads in, dres + dx out): {t:.1f} us = {N*d*2*5/t/1e6:.2f} TB/s (5 streams)')
+V = 1190
+logits = torch.randn(N, 1216, device=dev)
+labels = torch.randint(4, V, (16, 2048), device=dev)
+nll = torch.empty(16, 2047, device=dev); hl = torch.empty(N, 2, device=dev); acc = torch.zeros(2, device=dev)
+t = timeit(lambda: ops.adaptive_nll_fwd(logits, labels, nll, hl, acc, 16, 2048, V, ()))
+print(f'nll fwd {N}x{V}: {t:.1f} us = {N*V*4/t/1e6:.2f} TB/s')

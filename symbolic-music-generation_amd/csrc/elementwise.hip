@@ -401,8 +401,8 @@ __global__ void dropout_kernel(const bf16_t* x, bf16_t* y, long long n8, unsigne
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            o[j] = dropout_keep(seed, site, (uint64_t)i * 8 + j, thresh) ? bf2f((bf16_t)v[j]) * dscale : 0.f;
+        for (int j = 0; j < 8; j++)   // n <= 2^32 (host check): the 32-bit index form makes the same decisions as dropout_keep
+            o[j] = dropout_keep32(seed, site, (uint32_t)i * 8u + j, thresh) ? bf2f((bf16_t)v[j]) * dscale : 0.f;
         u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
         *reinterpret_cast<u32x4*>(y + i * 8) = w;
     }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* src, 
 
 extern "C" int mxl_dropout_bf16(const void* x, void* y, long long n, float drop_p, unsigned long long seed, unsigned site,
                                 void* stream) {
-    MXL_CHECK_ARG(x && y && n > 0 && (n % 8) == 0 && drop_p > 0.f && drop_p < 1.f);
+    MXL_CHECK_ARG(x && y && n > 0 && (n % 8) == 0 && drop_p > 0.f && drop_p < 1.f && n <= 0x100000000ll);
     long long blocks = (n / 8 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,

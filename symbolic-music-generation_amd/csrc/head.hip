@@ -18,8 +18,28 @@ struct HeadGeom {
 
 __device__ __forceinline__ float wave_lse_range(const float* row, int lo, int hi, int lane, float extra_max,
                                                 const float* extra, int n_extra) {
-    // logsumexp over row[lo:hi] (+ n_extra values at extra[]), wave-cooperative
+    // logsumexp over row[lo:hi] (+ n_extra values at extra[]), wave-cooperative.  Ranges of up to 64 * 32 columns (every
+    // vocabulary of the reference) are read ONCE into registers, all loads in flight together; longer ones take two passes.
+    constexpr int RMAX = 32;
     float m = -INFINITY;
+    if (hi - lo <= 64 * RMAX) {
+        float buf[RMAX];
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            const int j = lo + lane + 64 * k;
+            buf[k] = (j < hi) ? row[j] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) m = fmaxf(m, buf[k]);
+        if (lane < n_extra) m = fmaxf(m, extra[lane]);
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) s += __expf(buf[k] - m);          // exp(-inf) = 0 for the padding
+        if (lane < n_extra) s += __expf(extra[lane] - m);
+        s = wave_sum(s);
+        return m + __logf(s);
+    }
     for (int j = lo + lane; j < hi; j += 64) m = fmaxf(m, row[j]);
     if (lane < n_extra) m = fmaxf(m, extra[lane]);
     m = wave_max(m);
@@ -43,7 +63,7 @@ __global__ void label_guard_kernel(long long* labels, int T, long long eos) {
 
 // nll[b][t] for t in [0, T-1); acc[0] += sum(nll), acc[1] += count(nll != 0).  lse_out[row][0] = head lse,
 // lse_out[row][1] = tail lse of the label's cluster (if any).
-constexpr int NLL_ROWS_PER_WAVE = 16;   // 64 token rows per block: one atomic pair per block instead of per row
+constexpr int NLL_ROWS_PER_WAVE = 4;    // 16 token rows per block (one atomic pair per block); more rows per wave leave too few waves to hide the per-row latency chain
 __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logits, int ldl, const long long* labels, float* nll,
                                                       float* lse_out, float* acc, int B, int T, HeadGeom g) {
     __shared__ float part[8];
