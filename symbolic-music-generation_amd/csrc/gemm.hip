@@ -621,6 +621,11 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT);
         else if (p.flags == MXL_GEMM_RELU_BWD) MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD);
+        else if (p.flags == MXL_GEMM_ADD_AUX) MXL_NT256_LAUNCH(MXL_GEMM_ADD_AUX);                    // Reformer residual epilogues
+        else if (p.flags == (MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT))
+            MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT);
         else MXL_NT256_LAUNCH(-1);
 #undef MXL_NT256_LAUNCH
         MXL_LAUNCH_CHECK();
