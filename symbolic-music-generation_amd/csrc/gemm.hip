@@ -108,7 +108,9 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
 }
 
 // One 1x4 output quad (row m, columns n..n+3, n < N): alpha, bias, relu, dropout, relu-backward mask, aux add ...
-__device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_, float (&v)[4]) {
+// `auxq`: the aux values of columns n..n+3 (4 bf16 in two dwords) if the caller has loaded them already
+__device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_, float (&v)[4],
+                                              const uint32_t* auxq = nullptr) {
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = a4_[r] * p.alpha;
             const bool full = (n + 3 < p.N);
@@ -132,7 +134,12 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = dropout_keep32(p.seed, p.site, i0 + r, p.thresh) ? v[r] * p.drop_scale : 0.f;
             }
-            if (flags & MXL_GEMM_RELU_BWD) {
+            if ((flags & MXL_GEMM_RELU_BWD) && auxq) {
+                v[0] = bf2f((bf16_t)(auxq[0] & 0xffffu)) > 0.f ? v[0] : 0.f;
+                v[1] = bf2f((bf16_t)(auxq[0] >> 16)) > 0.f ? v[1] : 0.f;
+                v[2] = bf2f((bf16_t)(auxq[1] & 0xffffu)) > 0.f ? v[2] : 0.f;
+                v[3] = bf2f((bf16_t)(auxq[1] >> 16)) > 0.f ? v[3] : 0.f;
+            } else if (flags & MXL_GEMM_RELU_BWD) {
                 if (full && ((p.ldaux & 3) == 0)) {
                     const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
@@ -146,7 +153,10 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
                         }
                 }
             }
-            if (flags & MXL_GEMM_ADD_AUX) {
+            if ((flags & MXL_GEMM_ADD_AUX) && auxq) {
+                v[0] += bf2f((bf16_t)(auxq[0] & 0xffffu)); v[1] += bf2f((bf16_t)(auxq[0] >> 16));
+                v[2] += bf2f((bf16_t)(auxq[1] & 0xffffu)); v[3] += bf2f((bf16_t)(auxq[1] >> 16));
+            } else if (flags & MXL_GEMM_ADD_AUX) {
                 if (full && ((p.ldaux & 3) == 0)) {
                     const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
@@ -199,8 +209,20 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, c
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
                                                    const f32x4 q0, const f32x4 q1) {
     float v0[4], v1[4];
-    epilogue_vals(p, flags, m, n, q0, v0);
-    epilogue_vals(p, flags, m, n + 16, q1, v1);
+    if ((flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) {
+        // the aux operand the same way round: one 16-byte load per lane at the address the store below uses (8 consecutive
+        // columns of one block), then lanes l and l ^ 16 trade halves so that each holds the aux of its own two quads
+        const int acol = ((l >> 4) & 1) ? n + 16 - 4 : n;
+        const u32x4 ax = *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.ldaux + acol);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(ax[0], ax[2], false, false);    // (lo, hi): odd rows' lo <-> even rows' hi
+        const auto s1 = __builtin_amdgcn_permlane16_swap(ax[1], ax[3], false, false);
+        const uint32_t aq0[2] = {s0[0], s1[0]}, aq1[2] = {s0[1], s1[1]};                  // block 0 quad, block 1 quad of this lane
+        epilogue_vals(p, flags, m, n, q0, v0, aq0);
+        epilogue_vals(p, flags, m, n + 16, q1, v1, aq1);
+    } else {
+        epilogue_vals(p, flags, m, n, q0, v0);
+        epilogue_vals(p, flags, m, n + 16, q1, v1);
+    }
     unsigned a0 = pack2bf(v0[0], v0[1]), a1 = pack2bf(v0[2], v0[3]), b0 = pack2bf(v1[0], v1[1]), b1 = pack2bf(v1[2], v1[3]);
     // even 16-lane rows keep block 0 and receive the neighbour's block-0 quad; odd rows keep block 1 and receive the neighbour's
     const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
