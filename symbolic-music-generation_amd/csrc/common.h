@@ -34,6 +34,24 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// Attention grids are (blocks of one (head, sequence), heads, sequences).  Workgroups are handed to the 8 XCDs round-robin in
+// launch order, so by default the blocks of one (head, sequence) -- which share its K / V / Q tiles -- land on 8 different L2s.
+// This remap gives every XCD whole (head, sequence) groups: launch slot L = (xcd, idx) works on group (idx / gx) * 8 + xcd,
+// block idx % gx.  (Needs heads x sequences to be a multiple of 8; otherwise the identity.)
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, groups = gridDim.y * gridDim.z;
+#ifndef MXL_NO_XCD_REMAP
+    if ((groups & 7) == 0) {
+        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = L & 7, idx = L >> 3;
+        const int grp = (idx / gx) * 8 + xcd;
+        bx = idx % gx; by = grp % gy; bz = grp / gy;
+        return;
+    }
+#endif
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ float wave_sum(float v) {

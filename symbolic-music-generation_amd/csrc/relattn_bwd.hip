@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);
     // longest-first: late query blocks see the most real keys (early ones mostly phantom distances), and they are dispatched
     // first so the tail of the launch is made of short workgroups
-    const int i0 = (gridDim.x - 1 - blockIdx.x) * QB;
+    const int i0 = (gridDim.x - 1 - bx_) * QB;
     const int iw0 = i0 + 32 * wid;
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;
@@ -599,10 +600,11 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;
-    const int P0 = p0 + blockIdx.x * KB;   // first key position of the workgroup
+    const int P0 = p0 + bx_ * KB;   // first key position of the workgroup
     const int Pw = P0 + 32 * wid;
     const int pk = Pw + r;                 // this lane's key position
     const bool kok = pk < T;               // pk >= p0 always

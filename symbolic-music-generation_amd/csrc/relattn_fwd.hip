@@ -119,10 +119,11 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);
     // longest-first: late query blocks see the most real keys (early ones mostly phantom distances), and they are dispatched
     // first so the tail of the launch is made of short workgroups
-    const int i0 = (gridDim.x - 1 - blockIdx.x) * QB;
+    const int i0 = (gridDim.x - 1 - bx_) * QB;
     const int iw0 = i0 + 32 * wid;
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;  // lowest stored key position
