@@ -36,20 +36,31 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 
 // Attention grids are (blocks of one (head, sequence), heads, sequences).  Workgroups are handed to the 8 XCDs round-robin in
 // launch order, so by default the blocks of one (head, sequence) -- which share its K / V / Q tiles -- land on 8 different L2s.
-// This remap gives every XCD whole (head, sequence) groups: launch slot L = (xcd, idx) works on group (idx / gx) * 8 + xcd,
-// block idx % gx.  (Needs heads x sequences to be a multiple of 8; otherwise the identity.)
+// Launch slot L = (xcd = L % 8, idx = L / 8) is remapped so that an XCD works through whole groups:
+//   groups % 8 == 0: group (idx / gx) * 8 + xcd, block idx % gx.  The eight XCDs then work on eight NEIGHBOURING groups at any
+//     time (mostly the heads of one sequence): their K / V rows and dG rows are adjacent in HBM.  Measured at C3: forward
+//     0.548 -> 0.475 ms, backward 2.17 -> 1.77 ms per layer.
+//   otherwise: XCD x takes a contiguous run of the (group-major) logical order, bijective for any grid (whole groups apart from
+//     one straddling each boundary).  Same L2 sharing, but the XCDs are then far apart in HBM: backward 2.05 ms in the C3 test.
 __device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
     const int gx = gridDim.x, gy = gridDim.y, groups = gridDim.y * gridDim.z;
 #ifndef MXL_NO_XCD_REMAP
+    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = L & 7, idx = L >> 3;
+    int grp;
     if ((groups & 7) == 0) {
-        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const int xcd = L & 7, idx = L >> 3;
-        const int grp = (idx / gx) * 8 + xcd;
-        bx = idx % gx; by = grp % gy; bz = grp / gy;
-        return;
+        grp = (idx / gx) * 8 + xcd;
+        bx = idx % gx;
+    } else {
+        const int n = gx * groups, q = n >> 3, r = n & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        grp = id / gx;
+        bx = id - grp * gx;
     }
-#endif
+    by = grp % gy; bz = grp / gy;
+#else
     bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#endif
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
