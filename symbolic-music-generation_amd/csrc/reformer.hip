@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
     int* sPos = reinterpret_cast<int*>(sV + G::T_BYTES);
     float* sFac = reinterpret_cast<float*>(sPos + G::ROWS);
     const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);     // the chunk workgroups of one (head, sequence) share an XCD's L2 (neighbours share a K/V chunk)
     const int NC = p.S / 64;
-    const int c0 = blockIdx.x * 2;
+    const int c0 = bx_ * 2;
     stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
     __syncthreads();
     const int chunk = c0 + (wid >> 1);
@@ -364,9 +365,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
     int* sPos = reinterpret_cast<int*>(sV + G::T_BYTES);
     float* sFac = reinterpret_cast<float*>(sPos + G::ROWS);
     const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);     // the chunk workgroups of one (head, sequence) share an XCD's L2 (neighbours share a K/V chunk)
     const int NC = p.S / 64;
-    const int c0 = blockIdx.x * 2;
+    const int c0 = bx_ * 2;
     stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
     __syncthreads();
     const int chunk = c0 + (wid >> 1);
@@ -506,9 +508,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
     float* sDl = sLse + 128;
     float* sDlse = sDl + 128;
     const int tid = threadIdx.x, wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);     // the chunk workgroups of one (head, sequence) share an XCD's L2 (neighbours share a K/V chunk)
     const int NC = p.S / 64;
-    const int kc = blockIdx.x;
+    const int kc = bx_;
     const int d = p.H * DH;
     const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
     // stage the 128 queries: rows 0-63 = chunk kc, rows 64-127 = chunk kc+1 (mod NC)
