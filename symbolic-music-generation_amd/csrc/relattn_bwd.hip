@@ -325,7 +325,20 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
                             *reinterpret_cast<u32x2*>(myDG + 8 * grp + 4 * hh) = w;
                         }
                     } else {
-                        if (dgrow && qok) {
+                        if (dgrow && (M & 7) == 0) {
+                            // lanes l and l + 32 (same query, distance groups 4 apart) trade one packed quad each, so that every
+                            // lane stores 8 consecutive distances with one 16-byte store instead of two 8-byte ones (the store
+                            // path's cost is per instruction and per row segment: scripts/ubench/stores.hip)
+#pragma unroll
+                            for (int gp = 0; gp < 2; gp++) {
+                                const unsigned a0 = pack2bf(g[8 * gp], g[8 * gp + 1]), a1 = pack2bf(g[8 * gp + 2], g[8 * gp + 3]);
+                                const unsigned b0 = pack2bf(g[8 * gp + 4], g[8 * gp + 5]), b1 = pack2bf(g[8 * gp + 6], g[8 * gp + 7]);
+                                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                                const int d8 = dblk + 16 * gp + 8 * hh;
+                                if (qok && d8 + 7 <= M - 1) *reinterpret_cast<u32x4*>(dgrow + d8) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                            }
+                        } else if (dgrow && qok) {
 #pragma unroll
                             for (int grp = 0; grp < 4; grp++) {
                                 const int d4 = dblk + 8 * grp + 4 * hh;
