@@ -887,7 +887,9 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int d0 = blockIdx.x * 256, h = blockIdx.y, b0 = blockIdx.z * p.bgroup;
+    int bx_, h, bz_;
+    xcd_block(bx_, h, bz_);      // the distance blocks of one (head, batch group) read the same Qr tiles: keep them on one XCD
+    const int d0 = bx_ * 256, b0 = bz_ * p.bgroup;
     const int nb = min(p.bgroup, p.B - b0);
     const int spb = p.T >> 5;                       // 32-row steps per batch item
     const int S = nb * spb;
