@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     const int d = H * DH;
     const int t = *t_dev;
     const int tm = t % M;
+    // ring slots that have never been written (t < M - 1: the sequence is shorter than the memory) are HF's zero-initialised
+    // mems: k = v = 0, so their score is the positional term alone and they add nothing to the output -- no K / V bytes are
+    // read for them
+    const int nvalid = t + 1 < M ? t + 1 : M;
 
     float qw[8];
     {
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
         for (int u = 0; u < U; u++) {
             const int s = s0 + u * 4 * KPW + ksub;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            kvv[u] = (s < M) ? *reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH) : z;
+            kvv[u] = (s < nvalid) ? *reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH) : z;
             int dist = tm - s;
             if (dist < 0) dist += M;
             bdv[u] = (s < M && c8 == 0) ? bdrow[dist] : 0.f;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
         for (int u = 0; u < U; u++) {
             const int s = s0 + u * 4 * KPW + ksub;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            vvv[u] = (s < M) ? *reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH) : z;
+            vvv[u] = (s < nvalid) ? *reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH) : z;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
