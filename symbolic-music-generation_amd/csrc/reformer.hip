@@ -163,6 +163,69 @@ __global__ __launch_bounds__(64) void lsh_sort_kernel(const int* buckets, int* s
     }
 }
 
+// The same sort with W waves per (b,h): wave w owns the contiguous segment [w * seg, (w+1) * seg) of the slots (seg a multiple of
+// 64), histograms it into its own counters, and after one exclusive scan over (bucket-major, wave-minor) runs the in-order
+// multisplit on its segment -- the result is the same stable permutation, W times as many slots in flight.
+template <int W>
+__global__ __launch_bounds__(64 * W) void lsh_sort_mw_kernel(const int* buckets, int* sidx, int* spos, int S, int T, int NBT) {
+    extern __shared__ int cnt[];  // [W][NBT] per-wave counters, then per-wave write offsets
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int* bk = buckets + (size_t)blockIdx.x * S;
+    int* so = sidx + (size_t)blockIdx.x * S;
+    int* sp = spos + (size_t)blockIdx.x * S;
+    const int seg = ((S + W - 1) / W + 63) & ~63;
+    const int lo = w * seg, hi = min(S, lo + seg);
+    int* mine = cnt + w * NBT;
+    for (int i = threadIdx.x; i < W * NBT; i += 64 * W) cnt[i] = 0;
+    __syncthreads();
+    for (int i = lo + lane; i < hi; i += 64) atomicAdd(&mine[bk[i]], 1);
+    __syncthreads();
+    // exclusive scan in (bucket, wave) order by wave 0: offset[w][b] = sum over buckets < b of all waves + waves < w of bucket b
+    if (w == 0) {
+        int carry = 0;
+        for (int base = 0; base < NBT; base += 64) {
+            const int b = base + lane;
+            int tot = 0;
+            if (b < NBT)
+                for (int ww = 0; ww < W; ww++) tot += cnt[ww * NBT + b];
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+            if (b < NBT) {
+                int run = carry + incl - tot;
+                for (int ww = 0; ww < W; ww++) { const int c = cnt[ww * NBT + b]; cnt[ww * NBT + b] = run; run += c; }
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    int nbits = 1;
+    while ((1 << nbits) < NBT) nbits++;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = lo; base < lo + seg; base += 64) {          // same trip count for every wave (no block barrier inside)
+        const int i = base + lane;
+        const bool ok = i < hi;
+        const int b = ok ? bk[i] : -1;
+        unsigned long long peers = __ballot(ok);
+        for (int bit = 0; bit < nbits; bit++) {
+            const bool on = (b >> bit) & 1;
+            const unsigned long long bal = __ballot(on && ok);
+            peers &= on ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & lt);
+        int off = 0;
+        if (ok) off = mine[b];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // all lanes have read the wave's counters before any leader updates one (one wave)
+        if (ok) {
+            const int dst = off + rank;
+            so[dst] = i;
+            sp[dst] = i % T;
+            if (rank == 0) mine[b] = off + __popcll(peers);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // the update is in LDS before the next strip of this wave reads it
+    }
+}
+
 // =====================================================================================================================
 // chunked attention, forward.  Slots s = 0..S-1 (sorted order for LSH, identity for local), chunk = 64 slots; queries
 // of chunk c attend the 128 keys of chunks (c-1 mod NC, c) (HF515:362-383).  dots = f_k * (q . x_k) with
@@ -985,6 +1048,11 @@ extern "C" int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* r
 extern "C" int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, int S, int T, int n_buckets_total,
                             void* stream) {
     MXL_CHECK_ARG(buckets && sorted_idx && sorted_pos && BH > 0 && S > 0 && T > 0 && n_buckets_total > 0 && n_buckets_total <= 8192);
+    // long rows: 8 waves per row (the single-wave form leaves the chip to B*H waves); their counters: 8 * NBT ints of LDS
+    if (S >= 2048 && n_buckets_total <= 1024)
+        hipLaunchKernelGGL(lsh_sort_mw_kernel<8>, dim3(BH), dim3(512), (size_t)8 * n_buckets_total * 4, (hipStream_t)stream, buckets,
+                           sorted_idx, sorted_pos, S, T, n_buckets_total);
+    else
     hipLaunchKernelGGL(lsh_sort_kernel, dim3(BH), dim3(64), (size_t)n_buckets_total * 4, (hipStream_t)stream, buckets, sorted_idx,
                        sorted_pos, S, T, n_buckets_total);
     MXL_LAUNCH_CHECK();
