@@ -109,6 +109,86 @@ __global__ __launch_bounds__(256) void lsh_hash_kernel(const bf16_t* qk, long lo
     buckets[((size_t)b * H + h) * n_h * T + (size_t)r * T + t] = r * NB + bucket;
 }
 
+// MFMA form for dh = 32 / 64: a wave hashes 16 tokens with v_mfma_f32_16x16x32_bf16.  x is bf16 already; the fp32 rotations enter
+// as three bf16 terms (hi + mid + lo = 24 mantissa bits), so the products are exact to fp32 and only the summation order differs
+// from the scalar kernel (a flipped near-tie in ~1e-4 of the tokens, as between any two fp32 orders).  The token rows are read as
+// MFMA fragments -- 16 rows x 64 contiguous bytes per load instead of 64 rows x 16 -- and the 1024 FMAs + broadcast LDS reads per
+// token of the scalar form are six MFMAs per 16 tokens.
+typedef __attribute__((ext_vector_type(8))) __bf16 hash_bf16x8;
+template <int NBLK>   // 16-column blocks of rotations: R2 <= 16 * NBLK
+__global__ __launch_bounds__(256) void lsh_hash_mfma_kernel(const bf16_t* qk, long long bs, int rs, const float* rot, int* buckets,
+                                                            int B, int T, int H, int dh, int n_h, int R2, int NB, HashGeom g) {
+    constexpr int TG = 8;                                         // 16-token groups per wave: the rotation fragments are built once
+    __shared__ float sacc[4][16][16 * NBLK + 1];
+    const int h = blockIdx.y % H, r = blockIdx.y / H, b = blockIdx.z;
+    const int wid = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, kg = l >> 4;
+    const int KS = dh / 32;                                       // 1 or 2 K-steps
+    // rotation fragments: row n = nb*16 + li of R^T, k = 32 ks + 8 kg .. + 7, as three bf16 terms
+    bf16x8 rf[2][NBLK][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int nb = 0; nb < NBLK; nb++) {
+            const int n = nb * 16 + li;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int e = 32 * ks + 8 * kg + j;
+                const float v = (ks < KS && n < R2) ? rot[(((size_t)h * dh + e) * n_h + r) * R2 + n] : 0.f;
+                const bf16_t h0 = f2bf(v);
+                const float r1 = v - bf2f(h0);
+                const bf16_t h1 = f2bf(r1);
+                const bf16_t h2 = f2bf(r1 - bf2f(h1));
+                rf[ks][nb][0][j] = (short)h0; rf[ks][nb][1][j] = (short)h1; rf[ks][nb][2][j] = (short)h2;
+            }
+        }
+#pragma unroll 1
+    for (int grp = 0; grp < TG; grp++) {
+        const int t0 = ((blockIdx.x * 4 + wid) * TG + grp) * 16;
+        if (t0 >= T) break;                                       // wave-uniform
+        f32x4 acc[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tok = min(t0 + li, T - 1);
+        const bf16_t* x = qk + (size_t)b * bs + (size_t)tok * rs + h * dh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            if (ks < KS) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(x + 32 * ks + 8 * kg);
+#pragma unroll
+                for (int nb = 0; nb < NBLK; nb++)
+#pragma unroll
+                    for (int sp = 2; sp >= 0; sp--)               // smallest term first
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hash_bf16x8, rf[ks][nb][sp]),
+                                                                          __builtin_bit_cast(hash_bf16x8, xf), acc[nb], 0, 0, 0);
+            }
+        }
+        // D[n][token]: lane = token li (column), rows n = nb*16 + 4*kg + j -> one LDS row per token
+#pragma unroll
+        for (int nb = 0; nb < NBLK; nb++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) sacc[wid][li][nb * 16 + 4 * kg + j] = acc[nb][j];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (kg == 0 && t0 + li < T) {
+            const float* a = sacc[wid][li];
+            int bucket = 0, cur = 0, prod = 1;
+            for (int f = 0; f < g.nfac; f++) {
+                const int half = g.fac[f] / 2;
+                float best = -INFINITY;
+                int arg = 0;
+                for (int c = 0; c < half; c++) { const float v = a[cur + c]; if (v > best) { best = v; arg = c; } }
+                for (int c = 0; c < half; c++) { const float v = -a[cur + c]; if (v > best) { best = v; arg = half + c; } }
+                bucket += prod * arg;
+                prod *= g.fac[f];
+                cur += half;
+            }
+            buckets[((size_t)b * H + h) * n_h * T + (size_t)r * T + t0 + li] = r * NB + bucket;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();                          // the row is consumed before the next group overwrites it
+    }
+}
+
 // =====================================================================================================================
 // stable counting sort of S = n_h*T slots by bucket per (b,h) (HF515:151-157, 772-789: argsort of S*bucket + index).
 // one wave per (b,h): histogram -> scan -> in-order multisplit with ballot ranking.  Outputs sidx (slot -> element index
@@ -1038,6 +1118,13 @@ extern "C" int mxl_lsh_hash(const void* qk, long long bs, int rs, const float* r
         g.fac[i] = factors_host[i]; R2 += factors_host[i] / 2; NB *= factors_host[i];
     }
     MXL_CHECK_ARG(R2 <= MAX_R2 && (size_t)dh * R2 * 4 <= 48 * 1024);
+    if ((dh == 32 || dh == 64) && (rs % 8) == 0 && (bs % 8) == 0 && ((uintptr_t)qk % 16) == 0) {
+        const auto kfm = R2 <= 16 ? lsh_hash_mfma_kernel<1> : R2 <= 32 ? lsh_hash_mfma_kernel<2> : lsh_hash_mfma_kernel<4>;
+        hipLaunchKernelGGL(kfm, dim3((T + 511) / 512, H * n_h, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qk, bs, rs,
+                           rotations, buckets, B, T, H, dh, n_h, R2, NB, g);
+        MXL_LAUNCH_CHECK();
+        return MXL_OK;
+    }
     const auto kfn = R2 <= 16 ? lsh_hash_kernel<16> : R2 <= 32 ? lsh_hash_kernel<32> : lsh_hash_kernel<64>;
     hipLaunchKernelGGL(kfn, dim3((T + 255) / 256, H * n_h, B), dim3(256), (size_t)dh * R2 * 4, (hipStream_t)stream,
                        (const bf16_t*)qk, bs, rs, rotations, buckets, B, T, H, dh, n_h, R2, NB, g);
