@@ -101,15 +101,11 @@ def main():
     def timed_relattn_bwd(*a, **k):
         if timed['on']:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d_rd = k.pop('d_rd', None)
-            qr = k.pop('qr_buf', None)
             s.record()
-            orig_bwd(*a, **k)          # the three attention-backward launches only
+            finish = orig_bwd(*a, defer_drd=True, **k)          # the three attention-backward launches only
             e.record()
             timed['ev'].append((s, e))
-            if d_rd is not None:       # the dRd contraction, outside the bracket
-                ops.relattn_drd(a[0], a[5], a[13], d_rd, qr, B=k['B'], T=k['T'], H=k['H'], dh=k['dh'], M=k['M'],
-                                q_bs=k['q_bs'], q_rs=k['q_rs'])
+            finish()                   # the dRd contraction (+ the r_r_bias gradient), outside the bracket
         else:
             orig_bwd(*a, **k)
 

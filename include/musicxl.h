@@ -94,16 +94,21 @@ int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd,
  *   d_r_w_bias, d_r_r_bias : (H,dh) f32, accumulated (+=).   M % 8 == 0. */
 int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                     const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
-                    void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
+                    void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias /* may be NULL: see mxl_relattn_drd */, int B, int T,
                     int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                     long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                     float scale, void* stream);
 
 /* The contraction the caller owes after mxl_relattn_bwd, as one HBM-streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0;
  * MXL_EUNSUPPORTED otherwise -- use mxl_gemm_bf16_batched):
- *   d_rd[delta, h*dh + e] += sum_{b,i} dg[b,h,i,delta] * qr[b,i,h,e]      qr = (q + r_r_bias) in bf16, strides (qr_bs, qr_rs) */
+ *   d_rd[delta, h*dh + e] += sum_{b,i} dg[b,h,i,delta] * qr[b,i,h,e]      qr = (q + r_r_bias) in bf16, strides (qr_bs, qr_rs)
+ * Optionally also the r_r_bias gradient (rd / d_r_r_bias non-NULL):
+ *   d_r_r_bias[h*dh + e] += sum_delta colsum_{b,i}(dg)[h, delta] * rd[delta, h*dh + e]
+ * and, when d_r_w_bias_fix is given, the same amount is subtracted there.  This pairs with mxl_relattn_bwd called with
+ * d_r_r_bias == NULL: its query-owner kernel then runs in the faster 8-wave form, which has room for one dq accumulator only and
+ * therefore leaves the SUM d(r_w_bias) + d(r_r_bias) in d_r_w_bias; after mxl_relattn_drd both hold their own gradient. */
 int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs,
-                    int qr_rs, int drd_ld, void* stream);
+                    int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, float* d_r_w_bias_fix, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.

@@ -542,6 +542,11 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
             }
         }
     }
+    // per-wave column sums -> LDS, summed over the waves, ONE atomic instruction per workgroup and bias (lane = e).  Issued per
+    // wave they are 64 two-lane atomic instructions each, 786 k instructions onto 1536 addresses per layer: measured 0.3 ms of
+    // this kernel.
+    __syncthreads();                                       // the K / V images are dead: reuse them
+    float* sred = reinterpret_cast<float*>(smem);          // [4 waves][2][64]
 #pragma unroll
     for (int e = 0; e < EB; e++) {
 #pragma unroll
@@ -550,9 +555,461 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); c += __shfl_xor(c, off, 64); }
             const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (r == 0 && ee < DH) {
-                atomicAdd(p.d_rwb + h * DH + ee, a);
-                atomicAdd(p.d_rrb + h * DH + ee, c);
+            if (r == 0 && ee < DH) { sred[(wid * 2 + 0) * 64 + ee] = a; sred[(wid * 2 + 1) * 64 + ee] = c; }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * DH) {
+        const int which = tid / DH, ee = tid % DH;
+        const float t = (sred[(0 * 2 + which) * 64 + ee] + sred[(1 * 2 + which) * 64 + ee]) +
+                        (sred[(2 * 2 + which) * 64 + ee] + sred[(3 * 2 + which) * 64 + ee]);
+        atomicAdd((which ? p.d_rrb : p.d_rwb) + h * DH + ee, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// query-owner kernel, 8-wave form (used when the caller takes d(r_r_bias) from the dRd kernel: d_r_r_bias == NULL).
+// Two waves per 32-query group, split by key half, so every SIMD holds two waves instead of one -- the 4-wave kernel above is
+// latency-bound at one.  At 256 registers per wave there is room for ONE dq accumulator: dQw and dQr are summed in it, its
+// column sums (= d r_w_bias + d r_r_bias) go to d_rwb, and mxl_relattn_drd, which streams dG anyway, computes
+// d r_r_bias = colsum(dG) . Rd and moves it from d_rwb to d_rrb.  Three barriers per tile (G blocks visible / dS visible /
+// buffers swapped).  Measured at C3: backward 1.74 -> 1.51 ms per layer.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
+    using G = GeoQ<DH>;
+    constexpr int KS = G::KS, EB = G::EB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                       // [2][64][DH]   double-buffered: one barrier per tile, loads hidden behind compute
+    char* sV = sK + 2 * G::K_BYTES;        // [2][64][DH]
+    char* sR = sV + 2 * G::K_BYTES;        // ring [256][DH]
+    _Float16* sG = reinterpret_cast<_Float16*>(sR + G::R_BYTES);                  // [4][32][GS] fp16
+    bf16_t* sDG = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sG) + G::G_BYTES);  // [4][32][DGS] bf16
+
+    const int tid = threadIdx.x;
+    // 8 waves: waves w and w + 4 share query group w (32 queries, one LDS skew row per query between them); kbw = 0 takes the
+    // first 32 keys of every 64-key tile, kbw = 1 the last 32 -- two waves per SIMD instead of one.
+    const int wid = (tid >> 6) & 3, kbw = tid >> 8, l = tid & 63, r = l & 31, hh = l >> 5;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);
+    // longest-first: late query blocks see the most real keys (early ones mostly phantom distances), and they are dispatched
+    // first so the tail of the launch is made of short workgroups
+    const int i0 = (gridDim.x - 1 - bx_) * QB;
+    const int iw0 = i0 + 32 * wid;
+    const int T = p.T, M = p.M;
+    const int p0 = T - p.Kc;
+    // both per-wave buffers use FIXED columns c = distance - dlo in [0, 96): every address is a per-lane constant plus an
+    // immediate.  Carry between tiles (block 0 -> block 2): G in registers, dG by an LDS move of the lane's own row.
+    _Float16* gW = sG + wid * 32 * GS + r * GS + 4 * hh;
+    const _Float16* gR = sG + wid * 32 * GS + r * GS + r + 64 - 4 * hh;
+    const uint32_t gRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(gR - 27);
+    bf16_t* myDG = sDG + wid * 32 * DGS + r * DGS;                 // row of this lane's query
+    const uint32_t dgWb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(myDG + r + 64 - 4 * hh - 27);
+    f16x4 carry[4];
+    // Rd ring fragments: slot = (16-aligned window base + r) & 255, so the XOR-swizzle term of its row depends on the lane only
+    int rswz[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) rswz[ks] = (DH == 64) ? (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4) : ((2 * ks + hh) << 4);
+
+    const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
+    const bf16_t* rbase = p.rd + (size_t)h * DH;
+    const int qi = iw0 + r;
+    const bool qok = qi < T;
+
+    bf16x8 qw[KS], qr[KS], dof[KS];
+    {
+        const size_t qrow = (size_t)(qok ? qi : 0);
+        const bf16_t* qp = p.q + (size_t)b * p.q_bs + qrow * p.q_rs + (size_t)h * DH;
+        const bf16_t* dop = p.dout + (size_t)b * p.o_bs + qrow * p.o_rs + (size_t)h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int e0 = 16 * ks + 8 * hh;
+            const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + e0);
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dop + e0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float qf = qok ? bf2f((bf16_t)qv[j]) : 0.f;
+                qw[ks][j] = (short)f2bf((qf + p.rwb[h * DH + e0 + j]) * p.scale_log2e);
+                qr[ks][j] = (short)f2bf((qf + p.rrb[h * DH + e0 + j]) * p.scale_log2e);
+                dof[ks][j] = qok ? (short)f2bf(bf2f((bf16_t)dv[j]) * p.scale) : (short)0;
+            }
+        }
+    }
+    const size_t sidx = ((size_t)b * p.H + h) * T + (qok ? qi : 0);
+    const float lse2 = qok ? p.lse[sidx] * LOG2E : 0.f;
+    const float ndlt = qok ? -p.scale * p.delta[sidx] : 0.f;
+    f32x16 c_lse, c_dlt;          // MFMA C operands: -lse (log2 units) and -scale*delta of this lane's query
+#pragma unroll
+    for (int j = 0; j < 16; j++) { c_lse[j] = -lse2; c_dlt[j] = ndlt; }
+
+    // zero this wave's un-skew ring: never-written cells must read as 0
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(sDG + wid * 32 * DGS);
+        if (kbw == 0)
+            for (int i = l; i < 32 * DGS / 2; i += 64) z[i] = 0u;
+    }
+
+    const int p_lo = i0 - M + 1;
+    const int p_hi = min(i0 + QB - 1, T - 1);
+    const int kt_lo = floordiv(p_lo, KT), kt_hi = floordiv(p_hi, KT);
+
+    constexpr int NLD8 = (KT * G::CH + 511) / 512;
+    u32x4 rk[NLD8], rv[NLD8], rr[NLD8];
+    auto load_kv = [&](int kt) {
+        const int P = kt * KT;
+#pragma unroll
+        for (int n = 0; n < NLD8; n++) {
+            const int c = tid + n * 512;
+            const int row = c / G::CH, ch = c % G::CH;
+            const int srow = P + row - p0;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            const bool ok = (c < KT * G::CH) && (srow >= 0) && (srow < p.Kc);
+            rk[n] = ok ? *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+            rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NLD8; n++) {
+            const int c = tid + n * 512;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = rk[n];
+                *reinterpret_cast<u32x4*>(sV + buf * G::K_BYTES + G::koff(row, ch)) = rv[n];
+            }
+        }
+    };
+    auto load_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < NLD8; n++) {
+            const int c = tid + n * 512;
+            const int row = c / G::CH, ch = c % G::CH;
+            int d = dbase + row;
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rr[n] = (c < KT * G::CH) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8) : z;
+        }
+    };
+    auto store_r = [&](int dbase) {
+#pragma unroll
+        for (int n = 0; n < NLD8; n++) {
+            const int c = tid + n * 512;
+            if (c < KT * G::CH) {
+                const int row = c / G::CH, ch = c % G::CH;
+                *reinterpret_cast<u32x4*>(sR + G::koff((dbase + row) & 255, ch)) = rr[n];
+            }
+        }
+    };
+
+    f32x16 aw[EB];          // (dQw + dQr)^T : [e][query] -- ONE accumulator: see the note above the kernel
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) aw[e][j] = 0.f;
+    bool have_ring = false;
+    int cur = 0;
+    bf16_t* dgrow = p.dg ? p.dg + (((size_t)b * p.H + h) * T + (qok ? qi : 0)) * (size_t)M : nullptr;
+    __syncthreads();   // dG buffer zeroed
+
+    // ---- phantom keys (see relattn_fwd.hip): for key positions below the first stored tile pz, k = v = 0, hence S = 0 and
+    // dP = 0: dSr = -scale * P * delta depends only on the distance.  Walk those DISTANCES d in [i - pz + 1, M - 1] block-wise:
+    // G^T (no skew) -> P -> dG^T straight from the accumulators -> dQr MFMA + dG store.  No K/V, no S/dP/dQw, no LDS rings.
+    // The one block that straddles real and phantom distances (d in [iw0-pz, iw0-pz+31]) is deposited into the un-skew buffer
+    // (block-0 columns) so that the first real tile completes and emits it.
+    const int pz = floordiv(p0, KT) * KT;
+    int kt_start = kt_lo;
+    if (kt_lo * KT < pz) {
+        kt_start = pz / KT;
+        const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+        load_r(i0 - pz);
+#pragma unroll 1
+        for (int db = i0 - pz; db <= M - 1; db += 64) {
+            store_r(db);
+            __syncthreads();
+            if (db + 64 <= M - 1) load_r(db + 64);
+            if (iw0 < T) {
+                for (int gb = kbw; gb == kbw; gb += 2) {                  // each wave of the pair takes one 32-distance block
+                    const int dblk = db + 32 * gb;
+                    if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform
+                    f32x16 g = c_lse;
+                    const int slot = (dblk + r) & 255;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                    }
+                    // dSr = -scale * P * delta.  Only boundary blocks need the per-cell validity test (scalar branch).
+                    const bool fullblk = __builtin_amdgcn_readfirstlane(
+                        (int)((dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T))) != 0;
+                    if (fullblk) {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) g[j] = __builtin_amdgcn_exp2f(g[j]) * ndlt;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                            const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && qok;
+                            g[j] = valid ? __builtin_amdgcn_exp2f(g[j]) * ndlt : 0.f;
+                        }
+                    }
+                    if (dblk == iw0 - pz) {
+                        // straddling block: into block-0 columns of the un-skew buffer (4 consecutive distances per store)
+#pragma unroll
+                        for (int grp = 0; grp < 4; grp++) {
+                            const u32x2 w = {pack2bf(g[4 * grp], g[4 * grp + 1]), pack2bf(g[4 * grp + 2], g[4 * grp + 3])};
+                            *reinterpret_cast<u32x2*>(myDG + 8 * grp + 4 * hh) = w;
+                        }
+                    } else {
+                        if (dgrow && (M & 7) == 0) {
+                            // lanes l and l + 32 (same query, distance groups 4 apart) trade one packed quad each, so that every
+                            // lane stores 8 consecutive distances with one 16-byte store instead of two 8-byte ones (the store
+                            // path's cost is per instruction and per row segment: scripts/ubench/stores.hip)
+#pragma unroll
+                            for (int gp = 0; gp < 2; gp++) {
+                                const unsigned a0 = pack2bf(g[8 * gp], g[8 * gp + 1]), a1 = pack2bf(g[8 * gp + 2], g[8 * gp + 3]);
+                                const unsigned b0 = pack2bf(g[8 * gp + 4], g[8 * gp + 5]), b1 = pack2bf(g[8 * gp + 6], g[8 * gp + 7]);
+                                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                                const int d8 = dblk + 16 * gp + 8 * hh;
+                                if (qok && d8 + 7 <= M - 1) *reinterpret_cast<u32x4*>(dgrow + d8) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                            }
+                        } else if (dgrow && qok) {
+#pragma unroll
+                            for (int grp = 0; grp < 4; grp++) {
+                                const int d4 = dblk + 8 * grp + 4 * hh;
+                                if (d4 + 3 <= M - 1) {
+                                    const u32x2 w = {pack2bf(g[4 * grp], g[4 * grp + 1]), pack2bf(g[4 * grp + 2], g[4 * grp + 3])};
+                                    *reinterpret_cast<u32x2*>(dgrow + d4) = w;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int st = 0; st < 2; st++) {
+                            const u32x4 pw = {pack2bf(g[8 * st], g[8 * st + 1]), pack2bf(g[8 * st + 2], g[8 * st + 3]),
+                                              pack2bf(g[8 * st + 4], g[8 * st + 5]), pack2bf(g[8 * st + 6], g[8 * st + 7])};
+                            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                            for (int e = 0; e < EB; e++) {
+                                const int dist = dblk + 16 * st + 4 * hh + q4;      // accumulator-permuted k order
+                                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                                bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                                if (ecol < DH) {
+                                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff(dist & 255, ecol)));
+                                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff((dist + 8) & 255, ecol)));
+                                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                }
+                                aw[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                                __builtin_bit_cast(mfma_bf16x8, pf), aw[e], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    {
+        const int P0 = kt_start * KT;
+        load_kv(kt_start);
+        store_kv(0);
+#pragma unroll 1
+        for (int q4 = 0; q4 < 3; q4++) {
+            const int dbase = i0 - P0 - 64 + 64 * q4;
+            load_r(dbase);
+            store_r(dbase);
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int kt = kt_start; kt <= kt_hi; kt++) {
+        const int P = kt * KT;
+        const bool more = kt < kt_hi;
+        if (more) {
+            load_kv(kt + 1);
+            load_r(i0 - (P + KT) - 64);
+        }
+        const int dmin_w = iw0 - P - (KT - 1), dmax_w = iw0 + 31 - P;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);       // same for both waves of a pair
+        const int dlo = iw0 - P - 64;
+        const char* cK = sK + cur * G::K_BYTES;
+        const char* cV = sV + cur * G::K_BYTES;
+        const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+        // ---- phase 1: the G blocks of this tile's 96-column window.  Wave 1 (keys 32..63: columns 0..63) computes block 0 and
+        // carries it as the next tile's block 2; wave 0 (keys 0..31: columns 32..95) computes block 1 and moves the un-skew
+        // buffer's carried block (columns [0,32) of the previous tile are columns [64,96) of this one).
+        if (active) {
+            auto gblock = [&](int gb, f16x4 (&dst)[4]) {
+                f32x16 g;
+#pragma unroll
+                for (int j = 0; j < 16; j++) g[j] = 0.f;
+                const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    dst[grp] = __builtin_convertvector(v4, f16x4);
+                }
+            };
+            if (kbw == 1) {
+                f16x4 b0[4];
+                if (!have_ring) gblock(2, carry);
+                gblock(0, b0);
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
+                    *reinterpret_cast<f16x4*>(gW + 64 + 8 * grp) = carry[grp];
+                    carry[grp] = b0[grp];
+                }
+            } else {
+                f16x4 b1[4];
+                gblock(1, b1);
+                const u32x4 m0 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh);
+                const u32x4 m1 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh + 8);
+                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh) = m0;
+                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh + 8) = m1;
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) *reinterpret_cast<f16x4*>(gW + 32 + 8 * grp) = b1[grp];
+            }
+            have_ring = true;
+        }
+        __syncthreads();
+        // ---- phase 2: this wave's 32 keys: S / dP chains, skew read, P and dSr, skew write, dQw products
+        if (active) {
+            const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
+            const int kb = kbw;
+            f32x16 s = c_lse, dp = c_dlt;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                            __builtin_bit_cast(mfma_bf16x8, qw[ks]), s, 0, 0, 0);
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(cV + G::koff(32 * kb + r, 2 * ks + hh));
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
+                                                             __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp, 0, 0, 0);
+            }
+            uint32_t bdu[16];
+            skew_read16(gRb - 64 * kb, bdu);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) s[j] = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j])) * dp[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
+                    const bool valid = (d >= 0) && (d <= M - 1) && qok;
+                    const float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
+                    s[j] = valid ? pv * dp[j] : 0.f;
+                }
+            }
+            uint32_t dsw[8];          // dSr as bf16 pairs (2m, 2m+1): MFMA operand and skew-write source
+#pragma unroll
+            for (int m = 0; m < 8; m++) dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]);
+            skew_write16p(dgWb - 64 * kb, dsw);
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const u32x4 pw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                for (int e = 0; e < EB; e++) {
+                    const int key = 32 * kb + 16 * st + 4 * hh + q4;
+                    const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                    bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ecol < DH) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(cK + G::eoff(key, ecol)));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(cK + G::eoff(key + 8, ecol)));
+                        a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                    aw[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, pf), aw[e], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: completed distance blocks of the window: wave 0 emits block 2 (d in [dlo+64, dlo+95]), wave 1 block 1
+        if (active) {
+            const int blk = 2 - kbw;
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ks2++) {
+                const int d8 = dlo + 32 * blk + 16 * ks2 + 8 * hh;  // 8 consecutive distances (natural k order)
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(myDG + 32 * blk + 16 * ks2 + 8 * hh);
+                if (dgrow && qok && d8 >= 0 && d8 + 7 <= M - 1)
+                    *reinterpret_cast<bf16x8*>(dgrow + d8) = bfrag;
+#pragma unroll
+                for (int e = 0; e < EB; e++) {
+                    const int dist = dlo + 32 * blk + 16 * ks2 + 8 * (gq >> 1) + q4;
+                    const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                    bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ecol < DH) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff(dist & 255, ecol)));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff((dist + 4) & 255, ecol)));
+                        a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                    aw[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                    __builtin_bit_cast(mfma_bf16x8, bfrag), aw[e], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            store_kv(cur ^ 1);
+            store_r(i0 - (P + KT) - 64);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  The column sums of the wave's accumulator over its queries are its part of d(r_w_bias) + d(r_r_bias): they
+    // go to d_rwb; the dRd kernel moves the r_r_bias part over (colsum(dG) . Rd).  dq = the two waves' accumulators, summed
+    // through LDS (the K / V images are dead now).
+    __syncthreads();                                       // the K / V images are dead: reuse them
+    float* sred = reinterpret_cast<float*>(smem) + 4 * EB * 16 * 64;     // [8 waves][64], behind the dq exchange area below
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float a = qok ? aw[e][j] : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (r == 0 && ee < DH) sred[(kbw * 4 + wid) * 64 + ee] = a;
+        }
+    }
+    float* red = reinterpret_cast<float*>(smem);          // [4 groups][EB * 16][64 lanes] f32 <= 32 KB
+    if (kbw == 1) {
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) red[(wid * EB * 16 + e * 16 + j) * 64 + l] = aw[e][j];
+    }
+    __syncthreads();
+    if (tid < DH) {          // one atomic instruction per workgroup (lane = e): see the 4-wave kernel's epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) t += sred[w * 64 + tid];
+        atomicAdd(p.d_rwb + h * DH + tid, t);
+    }
+    if (kbw == 0 && qok) {
+        bf16_t* dqp = p.dq + (size_t)b * p.dq_bs + (size_t)qi * p.dq_rs + (size_t)h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o[t] = aw[e][4 * grp + t] + red[(wid * EB * 16 + e * 16 + 4 * grp + t) * 64 + l];
+                    u32x2 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *reinterpret_cast<u32x2*>(dqp + e0) = w;
+                }
             }
         }
     }
@@ -875,6 +1332,9 @@ struct DrdP {
     const bf16_t* dg; const bf16_t* qr; float* drd;
     int B, T, H, M, bgroup;            // bgroup = batches per workgroup
     long long qr_bs; int qr_rs, drd_ld;
+    // optional: d r_r_bias[h, :] += colsum_i(dG)[delta] . Rd[delta, h, :], and the same amount is taken OUT of d_rwb (the 8-wave
+    // query-owner kernel leaves d r_w_bias + d r_r_bias there)
+    const bf16_t* rd; int rd_rs; float* d_rrb; float* d_rwb;
 };
 constexpr int DRD_A = 32 * 512;        // dG tile  [32 i][256 delta] bf16
 constexpr int DRD_B = 32 * 128;        // Qr tile  [32 i][64 e] bf16
@@ -931,11 +1391,16 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], accs[4];          // accs: dG^T . 1 = column sums of dG over i (every output column the same)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
+        accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_rrb = p.d_rrb != nullptr;
+    const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     issue(0);
     if (S > 1) issue(1);
@@ -959,6 +1424,12 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
             for (int j = 0; j < 4; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
                                                                     __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        if (want_rrb) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
+                                                                  __builtin_bit_cast(mfma_bf16x8, ones), accs[i], 0, 0, 0);
+        }
         // step g + 1 must have landed before the next iteration reads it: leave the two youngest steps in flight
         if (issued) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else if (g + 2 < S) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -978,6 +1449,26 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) atomicAdd(p.drd + (size_t)dd * p.drd_ld + h * 64 + 16 * j + (l & 15), acc[i][j][r]);
         }
+    if (want_rrb) {
+        // this wave's 64 column sums (lanes with l & 15 == 0 hold them: rows 16i + 4*(l >> 4) + r) -> LDS (the ring is drained),
+        // then lane = e: sum over the wave's distances of cs[delta] * Rd[delta, h, e]
+        float* scs = reinterpret_cast<float*>(smem) + wid * 64;
+        if ((l & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) scs[16 * i + 4 * (l >> 4) + r] = accs[i][r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float sum = 0.f;
+        for (int dl = 0; dl < 64; dl++) {
+            const int dd = d0 + 64 * wid + dl;
+            if (dd < p.M) sum += scs[dl] * bf2f(p.rd[(size_t)dd * p.rd_rs + h * 64 + l]);
+        }
+        atomicAdd(p.d_rrb + h * 64 + l, sum);
+        if (p.d_rwb) atomicAdd(p.d_rwb + h * 64 + l, -sum);
+    }
 }
 
 template <int DH>
@@ -993,6 +1484,16 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL(relattn_bwd_delta_kernel, dim3((p.B * p.T + 3) / 4), dim3(256), 0, s, p, DH);
+    if (p.d_rrb == nullptr) {
+        static bool attr8 = false;
+        if (!attr8) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dq8_kernel<DH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, GeoQ<DH>::SMEM);
+            if (e != hipSuccess) return (int)e;
+            attr8 = true;
+        }
+        hipLaunchKernelGGL((relattn_bwd_dq8_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(512), GeoQ<DH>::SMEM, s, p);
+    } else
     hipLaunchKernelGGL((relattn_bwd_dq_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(256), GeoQ<DH>::SMEM, s, p);
     hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
     MXL_LAUNCH_CHECK();
@@ -1008,7 +1509,7 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
                                long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                                float scale, void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv);
-    MXL_CHECK_ARG(d_r_w_bias && d_r_r_bias);
+    MXL_CHECK_ARG(d_r_w_bias);      // d_r_r_bias == NULL: it is left to mxl_relattn_drd (see there)
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && (M % 8) == 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 8) == 0 && (dq_rs % 4) == 0 && (dkv_rs % 4) == 0);
     MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 8) == 0 && (dq_bs % 4) == 0 && (dkv_bs % 4) == 0);
@@ -1032,7 +1533,8 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
 }
 
 extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
-                               long long qr_bs, int qr_rs, int drd_ld, void* stream) {
+                               long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
+                               float* d_r_w_bias_fix, void* stream) {
     MXL_CHECK_ARG(dg && qr && d_rd && B > 0 && T > 0 && H > 0 && M > 0);
     if (dh != 64 || (T % 32) != 0 || (M % 8) != 0 || M < 8) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG((qr_rs % 8) == 0 && (qr_bs % 8) == 0 && drd_ld >= H * dh && ((uintptr_t)dg % 16) == 0 && ((uintptr_t)qr % 16) == 0);
@@ -1046,6 +1548,8 @@ extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int 
     DrdP p;
     p.dg = (const bf16_t*)dg; p.qr = (const bf16_t*)qr; p.drd = d_rd;
     p.B = B; p.T = T; p.H = H; p.M = M; p.qr_bs = qr_bs; p.qr_rs = qr_rs; p.drd_ld = drd_ld;
+    MXL_CHECK_ARG(!d_r_r_bias || rd);
+    p.rd = (const bf16_t*)rd; p.rd_rs = rd_rs; p.d_rrb = d_r_r_bias; p.d_rwb = d_r_w_bias_fix;
     // batch groups: fill the 512 resident workgroup slots about once (each workgroup ends with 64 KB of fp32 atomics)
     const int tiles = ((M + 255) / 256) * H;
     int groups = 512 / tiles;

@@ -5,6 +5,7 @@ from libmusicxl.so and raises if the library is missing or a launch fails.  No C
 """
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -244,24 +245,37 @@ def add_rowbias(x, x_bs, x_rs, bias, out, B, T, n):
 
 def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_rwb, d_rrb, *, B, T, H, dh, M,
                 Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale=None,
-                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None):
+                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None, defer_drd: bool = False):
     """Backward of relattn_fwd.  If `d_rd` (M, H*dh) f32 is given, also contracts dG with (q + r_r_bias):
-    d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf)."""
+    d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf).
+    When that contraction runs as the streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0) it also produces d_rrb, and the
+    backward proper is launched without it -- its query-owner kernel then takes the faster 8-wave form."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    fused_rrb = (d_rd is not None and dg is not None and dh == 64 and T % 32 == 0 and M % 8 == 0 and M >= 8
+                 and os.environ.get('MXL_NO_DQ8') != '1')
     check(lib().mxl_relattn_bwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse),
-                                _p(delta), _p(dq), _p(dk), _p(dv), _p(dg), _p(d_rwb), _p(d_rrb), B, T, H, dh, M, Kc,
-                                q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale),
-                                _stream()), 'mxl_relattn_bwd')
-    if d_rd is not None:
-        relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, B=B, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs)
+                                _p(delta), _p(dq), _p(dk), _p(dv), _p(dg), _p(d_rwb), None if fused_rrb else _p(d_rrb), B, T, H,
+                                dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
+                                float(scale), _stream()), 'mxl_relattn_bwd')
+    def finish():
+        if d_rd is not None:
+            relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, B=B, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs,
+                        rd=rd if fused_rrb else None, rd_rs=rd_rs, d_rrb=d_rrb if fused_rrb else None,
+                        d_rwb=d_rwb if fused_rrb else None)
+    if defer_drd:          # (bench.py brackets the attention-backward launches alone)
+        return finish
+    finish()
 
 
-def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs):
-    """d_rd[delta, h*dh:(h+1)*dh] (M x dh, fp32, +=) = sum_b dG[b,h]^T (M x T) @ (q + r_r_bias)[b,:,h,:] (T x dh)"""
+def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs, rd=None, rd_rs=0, d_rrb=None, d_rwb=None):
+    """d_rd[delta, h*dh:(h+1)*dh] (M x dh, fp32, +=) = sum_b dG[b,h]^T (M x T) @ (q + r_r_bias)[b,:,h,:] (T x dh); with rd /
+    d_rrb (/ d_rwb) also d_rrb += colsum(dG) . Rd (and d_rwb -= the same): see mxl_relattn_drd"""
     d = H * dh
     add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
-    rc = lib().mxl_relattn_drd(_p(dg), _p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d, _stream())
+    rc = lib().mxl_relattn_drd(_p(dg), _p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d, _p(rd), int(rd_rs), _p(d_rrb),
+                               _p(d_rwb), _stream())
     if rc == -2:      # MXL_EUNSUPPORTED shape: the batched GEMM form
+        assert d_rrb is None
         gemm_batched(dg, qr_buf, d_rd, M, dh, T, lda=M, ldb=d, ldc=d, trans_a=True, trans_b=True,
                      flags=GEMM_OUT_F32_ATOMIC, batch=B * H, bdiv=H, sA=(H * T * M, T * M), sB=(T * d, dh), sC=(0, dh))
     else:

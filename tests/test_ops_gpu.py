@@ -419,11 +419,22 @@ def test_relattn_drd_streaming(dev, B, T, H, M):
     dg = bf(torch.randn(B, H, T, M) * 0.3).to(dev)
     qr = bf(torch.randn(B, T, d)).to(dev)
     out = torch.ones(M, d, device=dev, dtype=torch.float32)
-    rc = lib().mxl_relattn_drd(dg.data_ptr(), qr.data_ptr(), out.data_ptr(), B, T, H, dh, M, T * d, d, d,
+    rc = lib().mxl_relattn_drd(dg.data_ptr(), qr.data_ptr(), out.data_ptr(), B, T, H, dh, M, T * d, d, d, None, 0, None, None,
                                torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     ref = 1 + torch.einsum('bhim,bihe->mhe', dg.float().cpu(), qr.float().cpu().view(B, T, H, dh)).reshape(M, d)
     assert rel_err(out.cpu(), ref) < 2e-5
+    # with the Rd table: also d_rrb += colsum(dG) . Rd, the same amount taken out of d_rwb, d_rd unchanged
+    rd = bf(torch.randn(M, d) * 0.5).to(dev)
+    out2 = torch.ones(M, d, device=dev, dtype=torch.float32)
+    d_rrb = torch.full((d,), 2.0, device=dev); d_rwb = torch.full((d,), -3.0, device=dev)
+    rc = lib().mxl_relattn_drd(dg.data_ptr(), qr.data_ptr(), out2.data_ptr(), B, T, H, dh, M, T * d, d, d, rd.data_ptr(), d,
+                               d_rrb.data_ptr(), d_rwb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert rel_err(out2.cpu(), ref) < 2e-5
+    cs = dg.float().cpu().sum((0, 2))                                            # (H, M)
+    want = torch.einsum('hm,mhe->he', cs, rd.float().cpu().view(M, H, dh)).reshape(d)
+    assert rel_err(d_rrb.cpu() - 2.0, want) < 1e-4 and rel_err(-(d_rwb.cpu() + 3.0), want) < 1e-4
 
 
 @pytest.mark.gpu
