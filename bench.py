@@ -282,7 +282,8 @@ def pmc_traffic(workload, B):
     if workload != 'c3' or B != WORKLOADS['c3']['B'] or not os.path.exists(path):
         return None
     k = json.load(open(path))['kernels']
-    names = ('relattn_bwd_delta_kernel', 'relattn_bwd_dq_kernel<64>', 'relattn_bwd_dkv_kernel<64>')
+    dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
+    names = ('relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>')
     if not all(n in k for n in names):
         return None
     return sum(k[n]['hbm_bytes_per_launch'] for n in names)
