@@ -572,8 +572,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dq_kernel(BwdP p) {
 // Two waves per 32-query group, split by key half, so every SIMD holds two waves instead of one -- the 4-wave kernel above is
 // latency-bound at one.  At 256 registers per wave there is room for ONE dq accumulator: dQw and dQr are summed in it, its
 // column sums (= d r_w_bias + d r_r_bias) go to d_rwb, and mxl_relattn_drd, which streams dG anyway, computes
-// d r_r_bias = colsum(dG) . Rd and moves it from d_rwb to d_rrb.  Three barriers per tile (G blocks visible / dS visible /
-// buffers swapped).  Measured at C3: backward 1.74 -> 1.51 ms per layer.
+// d r_r_bias = colsum(dG) . Rd and moves it from d_rwb to d_rrb.  Two barriers per tile (dS visible / next tile's G blocks and
+// buffers ready).  Measured at C3: backward 1.74 -> 1.51 ms per layer.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
@@ -824,6 +824,59 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
     }
     __syncthreads();
 
+    // activity of this query group for the tile at key position P (the same for both waves of a pair)
+    auto is_active = [&](int P) { return (iw0 + 31 - P >= 0) && (iw0 - P - (KT - 1) <= M - 1) && (iw0 < T); };
+    // "pre-phase" of the tile at P: the G blocks of its 96-column window.  Wave 1 (keys 32..63: columns 0..63) computes block 0 and
+    // carries it as the next tile's block 2; wave 0 (keys 0..31: columns 32..95) computes block 1 and moves the un-skew buffer's
+    // carried block (columns [0,32) of the previous tile are columns [64,96) of this one).  It runs in the same barrier interval
+    // as the previous tile's completed-block phase (two barriers per tile instead of three).
+    auto pre_phase = [&](int P) {
+        const int dlo = iw0 - P - 64;
+        const bool active = is_active(P);
+        if (active) {
+        auto gblock = [&](int gb, f16x4 (&dst)[4]) {
+            f32x16 g;
+#pragma unroll
+            for (int j = 0; j < 16; j++) g[j] = 0.f;
+            const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                            __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+            }
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                dst[grp] = __builtin_convertvector(v4, f16x4);
+            }
+        };
+        if (kbw == 1) {
+            f16x4 b0[4];
+            if (!have_ring) gblock(2, carry);
+            gblock(0, b0);
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
+                *reinterpret_cast<f16x4*>(gW + 64 + 8 * grp) = carry[grp];
+                carry[grp] = b0[grp];
+            }
+        } else {
+            f16x4 b1[4];
+            gblock(1, b1);
+            const u32x4 m0 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh);
+            const u32x4 m1 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh + 8);
+            *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh) = m0;
+            *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh + 8) = m1;
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) *reinterpret_cast<f16x4*>(gW + 32 + 8 * grp) = b1[grp];
+        }
+        have_ring = true;
+    }
+    };
+    pre_phase(kt_start * KT);
+    __syncthreads();
+
 #pragma unroll 1
     for (int kt = kt_start; kt <= kt_hi; kt++) {
         const int P = kt * KT;
@@ -838,50 +891,6 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
         const char* cK = sK + cur * G::K_BYTES;
         const char* cV = sV + cur * G::K_BYTES;
         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
-        // ---- phase 1: the G blocks of this tile's 96-column window.  Wave 1 (keys 32..63: columns 0..63) computes block 0 and
-        // carries it as the next tile's block 2; wave 0 (keys 0..31: columns 32..95) computes block 1 and moves the un-skew
-        // buffer's carried block (columns [0,32) of the previous tile are columns [64,96) of this one).
-        if (active) {
-            auto gblock = [&](int gb, f16x4 (&dst)[4]) {
-                f32x16 g;
-#pragma unroll
-                for (int j = 0; j < 16; j++) g[j] = 0.f;
-                const int slot = (dlo + 32 * gb + r) & 255;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                                __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
-                }
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++) {
-                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
-                    dst[grp] = __builtin_convertvector(v4, f16x4);
-                }
-            };
-            if (kbw == 1) {
-                f16x4 b0[4];
-                if (!have_ring) gblock(2, carry);
-                gblock(0, b0);
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++) {
-                    *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
-                    *reinterpret_cast<f16x4*>(gW + 64 + 8 * grp) = carry[grp];
-                    carry[grp] = b0[grp];
-                }
-            } else {
-                f16x4 b1[4];
-                gblock(1, b1);
-                const u32x4 m0 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh);
-                const u32x4 m1 = *reinterpret_cast<const u32x4*>(myDG + 16 * hh + 8);
-                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh) = m0;
-                *reinterpret_cast<u32x4*>(myDG + 64 + 16 * hh + 8) = m1;
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++) *reinterpret_cast<f16x4*>(gW + 32 + 8 * grp) = b1[grp];
-            }
-            have_ring = true;
-        }
-        __syncthreads();
         // ---- phase 2: this wave's 32 keys: S / dP chains, skew read, P and dSr, skew write, dQw products
         if (active) {
             const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
@@ -933,6 +942,12 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                 }
             }
         }
+        // the next tile's K/V image and ring rows go to LDS before the barrier: the ring slots they overwrite lie above this tile's
+        // window, and the next tile's G blocks (below) need the new rows
+        if (more) {
+            store_kv(cur ^ 1);
+            store_r(i0 - (P + KT) - 64);
+        }
         __syncthreads();
         // ---- phase 3: completed distance blocks of the window: wave 0 emits block 2 (d in [dlo+64, dlo+95]), wave 1 block 1
         if (active) {
@@ -958,10 +973,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                 }
             }
         }
-        if (more) {
-            store_kv(cur ^ 1);
-            store_r(i0 - (P + KT) - 64);
-        }
+        if (more) pre_phase(P + KT);
         __syncthreads();
         cur ^= 1;
     }
