@@ -1041,7 +1041,8 @@ template <int DH> struct GeoK {
     static constexpr int Q_BYTES = QT * ROWB;          // one 32-row tile image
     static constexpr int R_BYTES = 256 * ROWB;
     static constexpr int S_BYTES = 4 * 32 * SKS * 2;
-    static constexpr int SMEM = 3 * Q_BYTES + 2 * QT * 4 + R_BYTES + S_BYTES;
+    static constexpr int QSET = 3 * Q_BYTES + 2 * QT * 4;       // one query tile: Qw, Qr, dO images + lse, delta
+    static constexpr int SMEM = 2 * QSET + R_BYTES + S_BYTES;   // two query tiles (double-buffered)
     __device__ static __forceinline__ int koff(int row, int ch) {
         if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
         return row * ROWB + (ch << 4);
@@ -1072,12 +1073,10 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     using G = GeoK<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQw = smem;
-    char* sQr = sQw + G::Q_BYTES;
-    char* sDO = sQr + G::Q_BYTES;
-    float* sLse = reinterpret_cast<float*>(sDO + G::Q_BYTES);  // [32] -lse (log2 units)
-    float* sDl = sLse + QT;                                     // [32] -scale * delta
-    char* sR = reinterpret_cast<char*>(sDl + QT);               // ring [256][DH]
+    // query tile set c (0 / 1, double-buffered: the next tile is stored while this one is read, one barrier per tile):
+    //   Qw, Qr, dO images, then -lse (log2 units) [32] and -scale * delta [32]
+    char* sQ0 = smem;
+    char* sR = smem + 2 * G::QSET;                              // ring [256][DH]
     _Float16* sS = reinterpret_cast<_Float16*>(sR + G::R_BYTES);   // [4][32 queries][SKS] fp16: G rows, lane-private per wave
 
     const int tid = threadIdx.x;
@@ -1136,7 +1135,12 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
             tdl = ok2 ? -p.scale * p.delta[sidx] : 0.f;
         }
     };
-    auto store_q = [&]() {
+    auto store_q = [&](int buf) {
+        char* sQw = sQ0 + buf * G::QSET;
+        char* sQr = sQw + G::Q_BYTES;
+        char* sDO = sQr + G::Q_BYTES;
+        float* sLse = reinterpret_cast<float*>(sDO + G::Q_BYTES);
+        float* sDl = sLse + QT;
         if (tid < QT * G::CH) {
             const int row = tid / G::CH, ch = tid % G::CH;
             u32x4 w, rq, wd;
@@ -1177,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     {
         const int I = it_lo * QT;
         load_q(it_lo);
-        store_q();
+        store_q(0);
 #pragma unroll 1
         for (int c5 = 0; c5 < 5; c5++) {
             const int dbase = I - P0 - 128 + 32 * c5;
@@ -1193,10 +1197,16 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
 #pragma unroll
         for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; }
 
+    int cur = 0;
 #pragma unroll 1
     for (int it = it_lo; it <= it_hi; it++) {
         const int I = it * QT;
         const bool more = it < it_hi;
+        const char* sQw = sQ0 + cur * G::QSET;
+        const char* sQr = sQw + G::Q_BYTES;
+        const char* sDO = sQr + G::Q_BYTES;
+        const float* sLse = reinterpret_cast<const float*>(sDO + G::Q_BYTES);
+        const float* sDl = sLse + QT;
         if (more) {
             load_q(it + 1);
             load_r(I + QT - P0);  // next window's 32 new (highest) distances: [I+32-P0, I+63-P0]
@@ -1295,12 +1305,13 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
                 }
             }
         }
-        __syncthreads();
+        // the next tile goes into the other tile set, its 32 new ring rows into slots below this tile's window: one barrier
         if (more) {
-            store_q();
+            store_q(cur ^ 1);
             store_r(I + QT - P0);
         }
         __syncthreads();
+        cur ^= 1;
     }
 
     // undo the operand scaling: dK was accumulated against scale*log2(e)*Qw, dV against scale*dO
