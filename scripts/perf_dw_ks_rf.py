@@ -1,0 +1,24 @@
+"""dW GEMM split-K sweep at the Reformer C4 shapes (65536 tokens, d = 512)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from symbolic_music_generation_amd import ops
+dev = torch.device('cuda:0')
+NT = 65536
+def timeit(fn, n=10, warm=2):
+    for i in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for name, O, K in (('o', 512, 512), ('qk+v', 1024, 512), ('qkv', 1536, 512), ('ff1', 2048, 512), ('ff2', 512, 2048)):
+    X = torch.randn(NT, K, device=dev).bfloat16(); Y = torch.randn(NT, O, device=dev).bfloat16()
+    dW = torch.zeros(O, K, device=dev)
+    res = []
+    for ks in (4, 6, 8, 12, 16, 24, 32):
+        t = timeit(lambda: ops.gemm(Y, X, dW, O, K, NT, trans_a=True, trans_b=True, flags=ops.GEMM_OUT_F32_ATOMIC, ksplits=ks))
+        res.append(f'ks={ks}: {t*1e3:.0f}us')
+    tiles = ((O + 127) // 128) * ((K + 127) // 128)
+    print(f'{name:5s} [{O}x{K}] tiles {tiles}: ' + '  '.join(res), flush=True)

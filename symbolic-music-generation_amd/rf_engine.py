@@ -367,8 +367,8 @@ class RFEngine:
     @staticmethod
     def _ks(m, n):
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        # fill the 512 resident workgroup slots (256 CUs x 2) in one round; measured (scripts/perf_dw_ks.py): up to 12 K-slices pay for the small gradients, 16 do not
-        return max(1, min(12, 512 // max(tiles, 1)))
+        # fill the 512 resident workgroup slots (256 CUs x 2) in one round; measured (scripts/perf_dw_ks.py): small gradients take as many K-slices as fill the slots (up to 24); beyond 512 workgroups a second round starts
+        return max(1, min(24, 512 // max(tiles, 1)))
 
     def backward(self, grad_scale=1.0, layer_done=None):
         ws, c = self._last, self.cfg
