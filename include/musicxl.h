@@ -196,6 +196,11 @@ int mxl_kv_append(const void* qkv, void* kcache, void* vcache, const int* t_dev,
                   const float* r_r_bias, void* qr_out, void* stream);   /* qr_out (B, d) bf16 = q + r_r_bias, or NULL */
 /* after the prompt forward: cache slots <- K/V rows of the last min(T, M) positions of a (B, T, 3d) qkv buffer */
 int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int T, int M, int d, int dh, void* stream);
+/* positional term of a decode step for the whole batch: bd[b][h][r] = sum_e qr[b][h*dh + e] * rd[r][h*dh + e], r < M.
+ * qr (B <= 64, ld_qr) bf16 = q + r_r_bias (mxl_decode_qkv / mxl_kv_append), rd (M, ld_rd) bf16 = r_net(pos_emb) of the layer
+ * (rows = distances), bd (B, H, M) f32.  dh = 64.  Replaces the `BD = einsum("ibnd,jnd->ijbn", rr_head_q, r_head_k)` of
+ * RelPartialLearnableMultiHeadAttn.forward (transformers 4.25.1 modeling_transfo_xl.py) for a single query position. */
+int mxl_decode_bd(const void* qr, const void* rd, float* bd, int B, int H, int dh, int M, int ld_qr, int ld_rd, void* stream);
 /* single-query relative attention over the ring, distances 0..M-1.  bd (B, H, M) f32 = (q + r_r_bias) . rd[dist], the
  * positional term for the whole batch (one mxl_gemm_bf16_batched per layer over heads); out (B, H*dh) bf16 */
 int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,

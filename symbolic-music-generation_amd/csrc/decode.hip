@@ -193,6 +193,49 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     }
 }
 
+// BD of one decode step (mxl_decode_bd): workgroup = (256 distances, head), wave = 64 distances x all (<= 64) batch rows x dh = 64:
+// 16 fragment loads straight from global memory (qr and the head's Rd columns are L2-resident), 32 MFMAs, 16-byte fp32 stores
+// along the distance axis.  The batched 128 x 128-tile GEMM this replaces took 9.7 us per layer for 0.2 GFLOP.
+typedef __attribute__((ext_vector_type(8))) __bf16 dec_mfma_bf16x8;
+__global__ __launch_bounds__(256) void decode_bd_kernel(const bf16_t* qr, const bf16_t* rd, float* bd, int B, int H, int M,
+                                                        int ld_qr, int ld_rd) {
+    const int h = blockIdx.y, wid = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 256 + wid * 64;
+    if (r0 >= M) return;
+    const int li = l & 15, kq = 8 * (l >> 4);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 fr[4][2], fq[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int r = r0 + f * 16 + li, b = f * 16 + li;
+            fr[f][ks] = r < M ? *reinterpret_cast<const bf16x8*>(rd + (size_t)r * ld_rd + h * 64 + ks * 32 + kq) : z;
+            fq[f][ks] = b < B ? *reinterpret_cast<const bf16x8*>(qr + (size_t)b * ld_qr + h * 64 + ks * 32 + kq) : z;
+        }
+    // acc[mf][nf][j]: b = mf*16 + (l & 15), r = r0 + nf*16 + 4*(l >> 4) + j
+#pragma unroll
+    for (int mf = 0; mf < 4; mf++) {
+        const int b = mf * 16 + li;
+#pragma unroll
+        for (int nf = 0; nf < 4; nf++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dec_mfma_bf16x8, fr[nf][ks]),
+                                                              __builtin_bit_cast(dec_mfma_bf16x8, fq[mf][ks]), acc, 0, 0, 0);
+            const int r = r0 + nf * 16 + 4 * (l >> 4);
+            if (b < B && r < M) {
+                float* o = bd + ((size_t)b * H + h) * M + r;
+                if (r + 3 < M && (M & 3) == 0) *reinterpret_cast<f32x4*>(o) = acc;
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (r + j < M) o[j] = acc[j];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sampler: HF GenerationMixin.sample / greedy_search on log-probs (B, V): repetition penalty (logits processor, over every
 // token already in the row) -> temperature -> top-k -> top-p -> typical-p -> renormalise -> multinomial
@@ -428,6 +471,18 @@ extern "C" int mxl_kv_fill(const void* qkv, void* kcache, void* vcache, int B, i
     const long long n = (long long)B * (T < M ? T : M) * (d / 8);
     hipLaunchKernelGGL(kv_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, T, M, d, dh);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_decode_bd(const void* qr, const void* rd, float* bd, int B, int H, int dh, int M, int ld_qr, int ld_rd,
+                             void* stream) {
+    MXL_CHECK_ARG(qr && rd && bd && B > 0 && B <= 64 && H > 0 && M > 0);
+    if (dh != 64) return MXL_EUNSUPPORTED;
+    MXL_CHECK_ARG(ld_qr >= H * 64 && ld_rd >= H * 64 && (ld_qr % 8) == 0 && (ld_rd % 8) == 0);
+    MXL_CHECK_ARG(((uintptr_t)qr % 16) == 0 && ((uintptr_t)rd % 16) == 0 && ((uintptr_t)bd % 16) == 0);
+    hipLaunchKernelGGL(decode_bd_kernel, dim3((M + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qr,
+                       (const bf16_t*)rd, bd, B, H, M, ld_qr, ld_rd);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -310,8 +310,11 @@ def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf,
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     if not qr_ready:
         add_rowbias(qkv, 3 * d, 3 * d, rrb.reshape(-1), qr_buf, B, 1, d)
-    gemm_batched(qr_buf, rd, bd_buf, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=GEMM_OUT_F32, batch=H, bdiv=1,
-                 sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
+    if dh == 64 and B <= 64:
+        check(lib().mxl_decode_bd(_p(qr_buf), _p(rd), _p(bd_buf), B, H, dh, M, d, rd.stride(0), _stream()), 'mxl_decode_bd')
+    else:
+        gemm_batched(qr_buf, rd, bd_buf, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=GEMM_OUT_F32, batch=H, bdiv=1,
+                     sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
     check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(bd_buf), _p(rwb), _p(out), _p(t_dev), B, H, dh, M,
                                    float(scale), _stream()), 'mxl_relattn_decode')
 

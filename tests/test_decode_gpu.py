@@ -177,3 +177,26 @@ def test_decode_qkv_fused_equals_projection_plus_append(dev):
         slot = t % M
         untouched = torch.ones(M, dtype=torch.bool); untouched[slot] = False
         assert torch.equal(kc2[:, :, untouched], kc0[:, :, untouched]) and not torch.equal(kc2[:, :, slot], kc0[:, :, slot])
+
+
+@pytest.mark.parametrize('B,H,M', [(64, 12, 2048), (5, 2, 300), (17, 3, 301), (1, 1, 64)])
+def test_decode_bd_vs_einsum(dev, B, H, M):
+    """mxl_decode_bd == einsum('bhe,rhe->bhr') of the bf16 operands in fp32 (HF: BD = einsum("ibnd,jnd->ijbn", rr_head_q,
+    r_head_k) for one query), and == the batched GEMM it replaces on the decode path; rows / distances beyond B / M untouched"""
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd._lib import lib
+    torch.manual_seed(B + M)
+    dh, d = 64, H * 64
+    qr = torch.randn(B, d, device=dev).bfloat16()
+    rd = torch.randn(M, d, device=dev).bfloat16()
+    bd = torch.full((B + 1, H, M), 7.0, device=dev, dtype=torch.float32)
+    ops.check(lib().mxl_decode_bd(qr.data_ptr(), rd.data_ptr(), bd.data_ptr(), B, H, dh, M, d, d, None), 'mxl_decode_bd')
+    torch.cuda.synchronize()
+    ref = torch.einsum('bhe,rhe->bhr', qr.float().view(B, H, dh), rd.float().view(M, H, dh))
+    assert torch.allclose(bd[:B], ref, rtol=1e-5, atol=1e-4)
+    assert torch.all(bd[B] == 7.0)
+    bd2 = torch.empty(B, H, M, device=dev, dtype=torch.float32)
+    ops.gemm_batched(qr, rd, bd2, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=ops.GEMM_OUT_F32, batch=H, bdiv=1,
+                     sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
+    assert torch.allclose(bd[:B], bd2, rtol=1e-6, atol=1e-5)
+    assert lib().mxl_decode_bd(qr.data_ptr(), rd.data_ptr(), bd.data_ptr(), 65, H, dh, M, d, d, None) < 0     # B > 64: argument error
