@@ -17,9 +17,9 @@ dout = torch.randn(B, T, d, device=dev).bfloat16()
 dqkv = torch.zeros_like(qkv); delta = torch.zeros(B, H, T, device=dev)
 dg = torch.empty(B, H, T, M, device=dev, dtype=torch.bfloat16)
 a, c = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
-for name, g in (('with dG', dg), ('no dG', None), ('with dG', dg), ('no dG', None)):
+for name, g, c_ in (('4-wave, with dG', dg, c), ('4-wave, no dG', None, c), ('8-wave, with dG', dg, None), ('8-wave, no dG', None, None)):
     f = lambda: ops.relattn_bwd(q, k, v, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc-T:, :d], dqkv[:, :, d:2*d], dqkv[:, :, 2*d:],
-                                g, a, c, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, **st)
+                                g, a, c_, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, **st)
     for _ in range(3): f()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
