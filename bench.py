@@ -25,7 +25,7 @@ import torch  # noqa: E402
 WORKLOADS = {
     # BASELINE.json configs[2] / SURVEY C3: the config the metric is quoted on (seq 2048); fits one GPU
     'c3': dict(name='TransfoXL 12L/768d H12 dh64 F3072 T=2048 M=2048 V=1190 cutoffs=[] (SURVEY C3, mode R: fresh zero mems)',
-               size='base', n_layer=12, T=2048, M=2048, B=16),
+               size='base', n_layer=12, T=2048, M=2048, B=32),
     # BASELINE.json configs[1] / SURVEY C2
     'c2': dict(name='TransfoXL 6L/512d H8 dh64 F2048 T=1024 M=1024 V=1190 cutoffs=[] (SURVEY C2, mode R)',
                size='small', n_layer=6, T=1024, M=1024, B=32),
@@ -279,9 +279,12 @@ def pmc_traffic(workload, B):
     gfx950 correction).  Counters cannot be collected from inside the timed run, so this is the recorded measurement for the
     default workload and None for any other."""
     path = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_traffic.json')
-    if workload != 'c3' or B != WORKLOADS['c3']['B'] or not os.path.exists(path):
+    if workload != 'c3' or not os.path.exists(path):
         return None
-    k = json.load(open(path))['kernels']
+    rec = json.load(open(path))
+    if rec.get('per_gpu_batch', 16) != B:          # the passes were collected at one batch size; no figure for another
+        return None
+    k = rec['kernels']
     dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
     names = ('relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>')
     if not all(n in k for n in names):

@@ -4,7 +4,7 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py ...
     python scripts/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv \
-        profiles/r01_c3_pmc_traffic.json
+        profiles/r01_c3_pmc_traffic.json [per-GPU batch of that run, default 32]
 
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KB; on gfx950 FETCH_SIZE
 tallies the 128-byte requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for
@@ -23,7 +23,7 @@ def per_kernel(path, counter):
     return df.groupby('k').Counter_Value.agg(['count', 'mean'])
 
 
-def main(fetch_csv, write_csv, out_json):
+def main(fetch_csv, write_csv, out_json, batch=32):
     f = per_kernel(fetch_csv, 'FETCH_SIZE')
     w = per_kernel(write_csv, 'WRITE_SIZE')
     out = {}
@@ -33,8 +33,9 @@ def main(fetch_csv, write_csv, out_json):
         out[k] = {'launches': int(f['count'].get(k, w['count'].get(k, 0))), 'fetch_size_bytes_raw': fk,
                   'fetch_bytes_corrected_x2': 2.0 * fk, 'write_bytes': wk, 'hbm_bytes_per_launch': 2.0 * fk + wk}
     json.dump({'command': 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (SURVEY C3, 1x MI355X)',
+               'per_gpu_batch': int(batch),
                'units': 'bytes per launch (counter mean over launches x 1000)', 'kernels': out}, open(out_json, 'w'), indent=1)
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

@@ -85,6 +85,50 @@ def test_attention_normalisation_and_causality_at_c3(dev):
     assert same2[100:].all() and (~same2[:100]).any()
 
 
+def test_attention_backward_batch_replication_at_bench_batch(dev):
+    """bench.py's per-GPU batch (32 sequences: dG holds 1.6 G elements, the fused qkv gradient 302 M): with the same
+    sequence in every batch slot the per-sequence outputs (dq, dk, dv, dG, delta) of the last slot equal those of the first
+    bit for bit (owner-computes kernels, no cross-sequence accumulation), and the batch-summed ones (d_rd, bias gradients)
+    are 32 x a B = 1 call up to fp32 atomic ordering -- an index that wrapped at these offsets would break either."""
+    from symbolic_music_generation_amd import ops
+    Kc = T
+    d = H * DH
+
+    def run(B):
+        qkv1, rd, rwb, rrb, _, _ = _attn_inputs(dev, 1, Kc, seed=3)
+        qkv = (qkv1 * 0.5).expand(B, Kc, 3 * d).contiguous()
+        torch.manual_seed(5)
+        dout = torch.randn(1, T, d, device=dev).to(torch.bfloat16).expand(B, T, d).contiguous()
+        st = dict(B=B, T=T, H=H, dh=DH, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+                  o_bs=T * d, o_rs=d)
+        out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16); lse = torch.zeros(B, H, T, device=dev)
+        qv, kv, vv = qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        ops.relattn_fwd(qv, kv, vv, rd, rwb, rrb, out, lse, **st)
+        dqkv = torch.zeros(B, Kc, 3 * d, device=dev, dtype=torch.bfloat16)
+        delta = torch.zeros(B, H, T, device=dev)
+        dg = torch.full((B, H, T, M), float('nan'), device=dev, dtype=torch.bfloat16)
+        d_rwb, d_rrb = torch.zeros(H, DH, device=dev), torch.zeros(H, DH, device=dev)
+        d_rd = torch.zeros(M, d, device=dev)
+        qr_buf = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
+        ops.relattn_bwd(qv, kv, vv, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d],
+                        dqkv[:, :, 2 * d:], dg, d_rwb, d_rrb, dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
+                        d_rd=d_rd, qr_buf=qr_buf, **st)
+        torch.cuda.synchronize()
+        return out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb
+
+    B = 32
+    out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb = run(B)
+    assert not torch.isnan(dg[-1].float()).any() and not torch.isnan(dg[0].float()).any()
+    for nm, t in [('out', out), ('lse', lse), ('dqkv', dqkv), ('delta', delta), ('dg', dg)]:
+        for b in (1, B // 2, B - 1):
+            assert torch.equal(t[b], t[0]), f'{nm}: batch slot {b} differs from slot 0'
+    assert dqkv[0].float().abs().sum().item() > 0
+    out1, lse1, dqkv1, delta1, dg1, d_rd1, d_rwb1, d_rrb1 = run(1)
+    assert torch.equal(dqkv[B - 1], dqkv1[0]) and torch.equal(dg[B - 1], dg1[0]) and torch.equal(out[B - 1], out1[0])
+    for nm, a, b in [('d_rd', d_rd, d_rd1), ('d_rwb', d_rwb, d_rwb1), ('d_rrb', d_rrb, d_rrb1)]:
+        assert _rel(a, B * b) < 1e-4, f'{nm}: {_rel(a, B * b)}'
+
+
 def test_model_properties_at_c3(dev):
     """the 12L / 768d model at T = M = 2048: log-prob normalisation, causality, segmentation invariance, batch equivariance"""
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
