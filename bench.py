@@ -28,7 +28,7 @@ WORKLOADS = {
                size='base', n_layer=12, T=2048, M=2048, B=32),
     # BASELINE.json configs[1] / SURVEY C2
     'c2': dict(name='TransfoXL 6L/512d H8 dh64 F2048 T=1024 M=1024 V=1190 cutoffs=[] (SURVEY C2, mode R)',
-               size='small', n_layer=6, T=1024, M=1024, B=32),
+               size='small', n_layer=6, T=1024, M=1024, B=64),
     'tiny': dict(name='debug 2L/128d T=256 M=256 (SURVEY C1 shape)', size='debug', n_layer=2, T=256, M=256, B=8),
 }
 V = 1190
