@@ -61,3 +61,26 @@ def pitch_shift(toks: List[str]) -> List[str]:
             midi -= 12
         out.append(f'p_{(midi % 12) + 1}/{midi // 12 - 1}_{deg}')
     return out
+
+
+def tempo_group(toks: List[str], tempo_bin: int = 5, low: int = 40, high: int = 240) -> List[str]:
+    """TempoGroup.__call__ (transform.py:123-136): the tempo token at position 1 becomes the token of its bin.  Bins
+    (music_vocab.py:402-417): [low, low+bin), ... from 40; the last bin also takes the high edge (one tempo longer); token
+    `Tempo_{start}/{end inclusive}`; the rare-tempo tokens keep their (edge) meta and hence their string (:420-421)."""
+    out = list(toks)
+    tp = out[1]
+    assert tp.startswith('Tempo_')
+    if tp in ('Tempo_low', 'Tempo_high'):
+        return out
+    n = int(tp[len('Tempo_'):])
+    assert (high - low) % tempo_bin == 0 and low <= n <= high
+    s = low
+    while s + tempo_bin <= high:
+        e = s + tempo_bin                       # exclusive
+        if s + tempo_bin * 2 > high:
+            e += 1
+        if s <= n < e:
+            out[1] = f'Tempo_{s}/{e - 1}'
+            return out
+        s = e
+    raise AssertionError(n)

@@ -115,12 +115,41 @@ class MixedTokenFiles:
 _T0 = dict(C=0, D=1, E=2, F=3, G=4, A=5, B=6)            # musicnlp/preprocess/key_finder.py:199-207
 
 
-def pitch_shift_tables(vocab_step, vocab_degree) -> np.ndarray:
+def tempo_group_map(vocab_group) -> dict:
+    """{'Tempo_N': 'Tempo_s/e'} for every common tempo N: the bin of the grouped vocabulary that holds N (TempoGroup,
+    transform.py:117-136, over `tempo_meta_map`, music_vocab.py:395-420; bins of `tempo_bin` tempi from 40, the last one a
+    tempo longer).  The two rare tokens (Tempo_low / Tempo_high) exist in both vocabularies and keep their strings."""
+    import re
+    if not vocab_group.tempo_bin:
+        raise ValueError('TempoGroup needs a vocabulary built with tempo_bin')
+    out = {}
+    for tok in vocab_group._tempos():
+        s, e = map(int, re.match(r'^Tempo_(\d+)/(\d+)$', tok).groups())
+        for n in range(s, e + 1):
+            out[f'Tempo_{n}'] = tok
+    return out
+
+
+def vocab_translation_table(vocab_src, vocab_dst, tok_map: Optional[dict] = None) -> np.ndarray:
+    """(V_src,) int32: id in `vocab_src` -> id of the same token string (or of tok_map[string]) in `vocab_dst`"""
+    tok_map = tok_map or {}
+    return np.asarray([vocab_dst.t2i(tok_map.get(vocab_src.i2t(i), vocab_src.i2t(i))) for i in range(len(vocab_src))], dtype=np.int32)
+
+
+def tempo_group_table(vocab_none, vocab_group) -> np.ndarray:
+    """(1, V_none) int32: TempoGroup as an id -> id table from the ungrouped-tempo vocabulary into the grouped one (the tempo
+    token moves to its bin's token, every other token keeps its string; ids shift because the grouped vocabulary holds 40
+    tempo tokens where the ungrouped one holds 201)."""
+    return vocab_translation_table(vocab_none, vocab_group, tempo_group_map(vocab_group))[None]
+
+
+def pitch_shift_tables(vocab_step, vocab_degree, tok_map: Optional[dict] = None) -> np.ndarray:
     """(24, V_step) int32: table[key ordinal][step-vocabulary id] = degree-vocabulary id.  Pitch tokens `p_i/o_S` become
     `p_i'/o'_deg` with deg = (t0[S] - t0[tonic letter]) % 7 + 1 (ScaleDegreeFinder.map_single, key_finder.py:245-262) and the
-    two out-of-range step tokens folded back by an octave (transform.py:184-191); every other token keeps its string and
-    changes id space only."""
+    two out-of-range step tokens folded back by an octave (transform.py:184-191); every other token keeps its string (or
+    becomes tok_map[string]: the tempo grouping folded into the same table) and changes id space only."""
     import re
+    tok_map = tok_map or {}
     pat = re.compile(r'^p_(-?\d+)/(-?\d+)_([A-G])$')
     V = len(vocab_step)
     tab = np.zeros((len(KEY_NAMES), V), dtype=np.int32)
@@ -130,7 +159,7 @@ def pitch_shift_tables(vocab_step, vocab_degree) -> np.ndarray:
             tok = vocab_step.i2t(i)
             m = pat.match(tok)
             if m is None:
-                tab[o, i] = vocab_degree.t2i(tok)
+                tab[o, i] = vocab_degree.t2i(tok_map.get(tok, tok))
                 continue
             midi = int(m.group(1)) - 1 + (int(m.group(2)) + 1) * 12
             midi = midi + 12 if midi == -12 else (midi - 12 if midi == 131 else midi)
@@ -144,7 +173,11 @@ class Augment:
     from (KeyInsert with `pt_sample`); needed for key insertion and pitch shift."""
 
     def __init__(self, tokenizer, random_crop: bool = False, min_seg_length: int = 16, crop_mult: int = 1,
-                 insert_key: bool = False, keys=None, pitch_shift: bool = False, tokenizer_degree=None, seed: int = 0):
+                 insert_key: bool = False, keys=None, pitch_shift: bool = False, tokenizer_degree=None, seed: int = 0,
+                 group_tempo: bool = False, tokenizer_group=None):
+        """`group_tempo`: the stored ids are in the ungrouped-tempo vocabulary of `tokenizer`; the batch comes out in the ids
+        of the grouped one (`tokenizer_group`, or `tokenizer_degree` built with tempo_bin when pitch shift is on too --
+        dataset.py:254-257,338-339 applies TempoGroup before KeyInsert / PitchShift; as tables they compose into one)."""
         v = tokenizer.vocab
         self.bar_id, self.omit_id = v.t2i(v.start_of_bar), v.t2i(v.omitted_segment)
         self.random_crop, self.min_seg_length, self.crop_mult = random_crop, min_seg_length, crop_mult
@@ -154,7 +187,15 @@ class Augment:
         if pitch_shift and not insert_key:
             raise ValueError('PitchShift reads the key token at position 2: enable insert_key (transform.py:219-221)')
         self.key_id = {k: v.t2i(f'Key_{k}') for k in KEY_NAMES}
-        self.tables = pitch_shift_tables(v, tokenizer_degree.vocab) if pitch_shift else None
+        self.group_tempo = group_tempo
+        if group_tempo:
+            dst = (tokenizer_degree if pitch_shift else tokenizer_group)
+            if dst is None or not dst.vocab.tempo_bin or v.tempo_bin:
+                raise ValueError('group_tempo: `tokenizer` must be ungrouped and the target tokenizer built with tempo_bin')
+            tmap = tempo_group_map(dst.vocab)
+            self.tables = pitch_shift_tables(v, dst.vocab, tmap) if pitch_shift else tempo_group_table(v, dst.vocab)
+        else:
+            self.tables = pitch_shift_tables(v, tokenizer_degree.vocab) if pitch_shift else None
         self.rng = np.random.default_rng(seed)
 
     def crop_high(self, n_bar: int) -> int:
@@ -188,7 +229,7 @@ class Augment:
             ordinal = KEY_NAMES.index(key)
             head = parts[0]
             parts = [head[:2], np.asarray([self.key_id[key]], dtype=seq.dtype), head[2:]] + parts[1:]
-        return parts, (ordinal if self.pitch_shift else -1)
+        return parts, (ordinal if self.pitch_shift else (0 if self.group_tempo else -1))
 
 class DeviceBatcher:
     """Double-buffered: while the model works on batch k, batch k+1 is being gathered into the other pinned buffer and copied."""

@@ -65,3 +65,39 @@ def test_random_draws_stay_in_range(env):
         seen_keys.add(ts.vocab.i2t(int(out[2]))); seen_lens.add(len(out))
         assert ordinal == -1 and (out == aug.bar_id).sum() >= 16
     assert seen_keys == {'Key_CMajor', 'Key_AMinor'} and len(seen_lens) > 5
+
+
+def test_tempo_group_oracle_hand_cases():
+    f = lambda n, b=5: R.tempo_group(['TimeSig_4/4', f'Tempo_{n}', '<bar>'], b)[1]
+    assert f(40) == 'Tempo_40/44' and f(44) == 'Tempo_40/44' and f(45) == 'Tempo_45/49' and f(120) == 'Tempo_120/124'
+    assert f(234) == 'Tempo_230/234' and f(235) == 'Tempo_235/240' and f(240) == 'Tempo_235/240'      # last bin: one longer
+    assert f(59, 20) == 'Tempo_40/59' and f(240, 20) == 'Tempo_220/240'
+    assert R.tempo_group(['TimeSig_4/4', 'Tempo_low', '<bar>'])[1] == 'Tempo_low'
+
+
+@pytest.mark.parametrize('pitch_shift', [False, True])
+def test_tempo_group_table_matches_string_transform(env, pitch_shift):
+    """TempoGroup as a table (alone, and folded into the pitch-shift tables) == the string transforms in dataset.py's order
+    (crop -> tempo group -> key insert -> pitch shift), tokenised by the grouped-tempo vocabulary; every tempo is covered."""
+    from symbolic_music_generation_amd.data import Augment, tempo_group_table
+    from symbolic_music_generation_amd.vocab import MusicTokenizer
+    ts, td, ids, toks = env
+    tg = MusicTokenizer(pitch_kind='degree' if pitch_shift else 'step', tempo_bin=5)
+    assert len(tg.vocab) == len((td if pitch_shift else ts).vocab) - 201 + 40
+    aug = Augment(ts, random_crop=True, insert_key=pitch_shift, keys=['AMajor'], pitch_shift=pitch_shift, seed=2,
+                  group_tempo=True, **(dict(tokenizer_degree=tg) if pitch_shift else dict(tokenizer_group=tg)))
+    parts, ordinal = aug.pieces(0, ids, crop_idx=7, key='AMajor' if pitch_shift else None)
+    got = aug.tables[ordinal][np.concatenate(parts)]
+    want = R.tempo_group(R.random_crop(toks, 7))
+    if pitch_shift:
+        want = R.pitch_shift(R.key_insert(want, 'AMajor'))
+    assert want[1] != toks[1] and '/' in want[1]
+    assert [tg.vocab.i2t(int(i)) for i in got] == want
+    if not pitch_shift:
+        tab = tempo_group_table(ts.vocab, tg.vocab)[0]
+        for n in range(40, 241):
+            assert tg.vocab.i2t(int(tab[ts.vocab.t2i(f'Tempo_{n}')])) == R.tempo_group(['x', f'Tempo_{n}'])[1]
+        for t in ('Tempo_low', 'Tempo_high', '<bar>', 'd_1', 'p_r', '[OMIT]', 'TimeSig_4/4'):
+            assert tg.vocab.i2t(int(tab[ts.vocab.t2i(t)])) == t
+    with pytest.raises(ValueError):
+        Augment(ts, group_tempo=True, tokenizer_group=ts)

@@ -96,6 +96,39 @@ def test_device_batcher_with_augmentation(tmp_path):
     assert np.array_equal(got_ids.cpu().numpy(), ref_ids) and np.array_equal(got_lab.cpu().numpy(), ref_lab)
 
 
+@pytest.mark.parametrize('pitch_shift', [False, True])
+def test_device_batcher_with_tempo_grouping(tmp_path, pitch_shift):
+    """TempoGroup (transform.py:117-136) as the device id -> id table, alone and folded into the pitch-shift tables: the batch
+    equals crop -> tempo group (-> key insert -> pitch shift) on strings, tokenised by the grouped-tempo vocabulary"""
+    from oracle import augment_ref as A
+    from symbolic_music_generation_amd.data import Augment, DeviceBatcher, TokenFile, write_token_file
+    from symbolic_music_generation_amd.vocab import MusicTokenizer
+    ts = MusicTokenizer(pitch_kind='step')
+    tg = MusicTokenizer(pitch_kind='degree' if pitch_shift else 'step', tempo_bin=5)
+    ids = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample_score_ids.npz'))['sample_full_step'].astype(np.int64)
+    songs = [ids, ids[:900]]
+    keys = ['DMajor', 'BMinor']
+    write_token_file(str(tmp_path / 'st'), songs, vocab_size=len(ts.vocab))
+    aug = Augment(ts, random_crop=True, insert_key=pitch_shift, keys=keys, pitch_shift=pitch_shift, seed=11, group_tempo=True,
+                  **(dict(tokenizer_degree=tg) if pitch_shift else dict(tokenizer_group=tg)))
+    L, pad = 1024, tg.vocab.t2i('[PAD]')
+    db = DeviceBatcher(TokenFile(str(tmp_path / 'st')), batch_size=2, max_length=L, pad_id=pad, device='cuda:0', augment=aug)
+    rng = np.random.default_rng(11)
+    want = []
+    for s, key in zip(songs, keys):
+        toks = [ts.vocab.i2t(int(i)) for i in s]
+        high = A.crop_high(toks)
+        idx = int(rng.integers(0, high + 1)) if high > 0 else 0
+        out = A.tempo_group(A.random_crop(toks, idx))
+        if pitch_shift:
+            out = A.pitch_shift(A.key_insert(out, key))
+        want.append([tg.vocab.t2i(t) for t in out])
+    ref_ids, ref_lab = pad_and_label(want, L, pad)
+    (got_ids, got_lab), = list(db)
+    assert np.array_equal(got_ids.cpu().numpy(), ref_ids) and np.array_equal(got_lab.cpu().numpy(), ref_lab)
+    assert '/' in tg.vocab.i2t(int(got_ids[0, 1]))
+
+
 def test_find_token_and_bar_cuts_vs_oracle(dev):
     """mxl_find_token + the bar-aligned cuts of eval.py:178-198 on the reference's real degree-pitch stream and on edge rows"""
     from oracle.data_ref import truncate_first_n_bar_ref, truncate_last_bar_ref
