@@ -176,7 +176,7 @@ def reformer_bench(args, dev, rank, world, dist):
     dropout on (0.05), auto num_buckets = [16,16].  Step = fwd + bwd + all-reduce + clip + AdamW."""
     from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
     from symbolic_music_generation_amd.dist import GradSync
-    B, T = args.batch or 8, 8192
+    B, T = args.batch or 16, 8192          # per-GPU batch sweep (DESIGN 4): 8 -> 3.61 M, 16 -> 3.87 M, 32 -> 3.97 M tok/s
     cfg = MyReformerConfig('small', vocab_size=V, max_position_embeddings=T, axial_pos_shape=(64, 128), num_hashes=1)
     model = MyReformerModelWithLMHead(cfg, device=dev, seed=77).train()
     eng = model.engine
