@@ -339,8 +339,14 @@ class XLEngine:
             self.G.zero_()
 
     @staticmethod
-    def _ks(m, n):
+    def _ks(m, n, k=0):
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        if k >= 49152:
+            # long contractions (per-GPU batch 32: 65536 tokens) amortise a slice's atomics over more K-steps, and shorter
+            # slices in ~3 rounds balance better than one round of long ones (scripts/perf_dw_ks.py 65536: ffn1 459 -> 429 us,
+            # ffn2 456 -> 436, qkv 351 -> 343 at 10-13 slices; the 768 x 768 gradient is best at 12: 122 us, 146 at 24).  Inside the
+            # C3 step the gain is within noise (weight-gradient GEMM 271 -> 269 us on average over a step's 61 launches)
+            return 12 if tiles <= 48 else max(1, min(24, 1440 // tiles))
         # fill the 512 resident workgroup slots (256 CUs x 2) in one round; measured (scripts/perf_dw_ks.py): small gradients take as many K-slices as fill the slots (up to 24: a 512 x 512 gradient 86 -> 68 us); beyond 512 workgroups a second round starts
         return max(1, min(24, 512 // max(tiles, 1)))
 
@@ -370,7 +376,7 @@ class XLEngine:
         boff = self.layout.entries['crit.out_layers.0.bias'][0]
         ops.colsum(ws.dlogits, G[boff:boff + nrow], N, nrow)
         ops.gemm(ws.dlogits, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
-                 ksplits=self._ks(nrow_p, d))
+                 ksplits=self._ks(nrow_p, d, N))
         dy, dy2 = ws.dA, None
         ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True)
         if p > 0:
@@ -386,13 +392,13 @@ class XLEngine:
             # FFN2
             ops.colsum(ws.dD, gw(l, 'pos_ff.CoreNet.3.bias'), N, d)
             ops.gemm(ws.dD, ws.a[l], gw(l, 'pos_ff.CoreNet.3.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
-                     ksplits=self._ks(d, Fi))
+                     ksplits=self._ks(d, Fi, N))
             ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
                      aux=ws.a[l], alpha=dscale)
             # FFN1
             ops.colsum(ws.dF, gw(l, 'pos_ff.CoreNet.0.bias'), N, Fi)
             ops.gemm(ws.dF, ws.h1[l], gw(l, 'pos_ff.CoreNet.0.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
-                     ksplits=self._ks(Fi, d))
+                     ksplits=self._ks(Fi, d, N))
             ops.gemm(ws.dF, self._lwt(l, 'pos_ff.CoreNet.0.weight'), ws.dD, N, d, Fi)
             # LN1 backward with both streams into h1: dC (residual) + dD (FFN1 dX)
             ops.ln_residual_bwd(ws.dC, ws.dD, ws.z1[l], ws.st1[l][0], ws.st1[l][1],
@@ -401,7 +407,7 @@ class XLEngine:
                                 seed=seed, site=self._site(l, 0))
             # now dA = grad into h_in via residual, dB = grad into o_net output
             ops.gemm(ws.dB, ws.av[l], gw(l, 'dec_attn.o_net.weight'), d, d, N, trans_a=True, trans_b=True, flags=AT,
-                     ksplits=self._ks(d, d))
+                     ksplits=self._ks(d, d, N))
             ops.gemm(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d)   # d attn_vec
             qkv, dqkv = ws.qkv[l], ws.dqkv
             ws.d_rd.zero_()
@@ -421,7 +427,7 @@ class XLEngine:
             else:
                 x_qkv = h_in
             ops.gemm(dqkv.view(B * Kc, 3 * d), x_qkv, gw(l, 'dec_attn.qkv_net.weight'), 3 * d, d, B * Kc, trans_a=True,
-                     trans_b=True, flags=AT, ksplits=self._ks(3 * d, d))
+                     trans_b=True, flags=AT, ksplits=self._ks(3 * d, d, B * Kc))
             if ws.has_mem:
                 # only the current rows receive gradient (mems are detached): per-batch GEMM on the last T rows
                 ops.gemm_batched(dqkv[:, M:], self._lw(l, 'dec_attn.qkv_net.weight'), ws.dB, T, d, 3 * d, lda=3 * d,
