@@ -3,7 +3,7 @@ ORACLE (test infrastructure, NOT product code) -- CPU fp32 restatement of the Tr
 of StefanHeng/Symbolic-Music-Generation.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
-The product path (`symbolic-music-generation_amd/`) never does.
+The product path (`symbolic_music_generation_amd/`) never does.
 
 PARITY STATUS: **decoder layer and adaptive softmax pinned on external implementations, the glue around them unpinned**.
 Pinned (tests/test_xlnet_pin_cpu.py; goldens from tests/golden/make_xlnet_relattn_goldens.py, inputs + outputs only):

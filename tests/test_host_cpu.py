@@ -46,7 +46,7 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_no_oracle_import_in_product_package():
-    pkg = os.path.join(ROOT, 'symbolic-music-generation_amd')
+    pkg = os.path.join(ROOT, 'symbolic_music_generation_amd')
     for fn in os.listdir(pkg):
         if fn.endswith('.py') and fn != 'smoke.py':
             src = open(os.path.join(pkg, fn)).read()
