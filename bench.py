@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Transformer-XL training throughput on synthetic token streams (BASELINE.json metric
-"train tokens/sec/GPU (TransfoXL seq2048 bf16)"), one process per GPU, data-parallel over RCCL.
+"""Headline benchmark (BASELINE.json metric "train tokens/sec/GPU (TransfoXL seq2048 bf16) at 1/2/4/8 GPUs; AR decode tok/s").
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-A step = forward + backward + gradient all-reduce + clip + AdamW on one batch of (B, T) synthetic ids per GPU
-(weak scaling).  Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline     -- the dominant kernel, timed live with HIP events on the launch stream
-  cpu_baseline -- the CPU oracle (oracle/transfoxl_ref.py, the reference-style dense fp32 path) on the host cores,
-                  rank 0 at N=1 only, on a bounded sample of the same workload
+* N > 1 and no launcher environment: this process touches no GPU; it starts N ranks with
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one process per GPU, RCCL),
+  relays rank 0's JSON line and exits with the children's code.  Started under a launcher (WORLD_SIZE set) it is one rank.
+* The headline leg (`value`) is the SURVEY C3 training step: forward + backward + gradient all-reduce + clip + AdamW on one
+  batch of (B, T) synthetic ids per GPU (weak scaling).  At N = 1 the same process then runs the other two legs of the
+  metric and attaches them to the same JSON line: `"decode"` (cached-mem AR decode, batch 64, top-k 8, one
+  hipGraph replay per token) and `"reformer"` (Reformer 6L/512d, T = 8192).  Decode and eval are replicas only
+  (DESIGN 6), so at N > 1 only the training leg runs.
+* Every leg carries `roofline` (dominant kernel, HIP events on the launch stream inside the timed region) and, at N = 1,
+  `cpu_baseline`: the CPU oracle (oracle/*.py, the reference-style fp32 path; `kind: "port"`) on the host cores on a
+  bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not initialise the GPU)
 
 WORKLOADS = {
     # BASELINE.json configs[2] / SURVEY C3: the config the metric is quoted on (seq 2048); fits one GPU
@@ -34,6 +39,7 @@ WORKLOADS = {
 V = 1190
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+CPU_BUDGET_S = 30.0              # bounded CPU-oracle sample per leg
 
 
 def flops_per_token_fwd(L, d, T, M, Vv):
@@ -43,44 +49,125 @@ def flops_per_token_fwd(L, d, T, M, Vv):
     return L * (24 * d * d + 4 * d * nbar + 2 * d * M) + 2 * d * Vv
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c3', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (sequences)')
-    ap.add_argument('--mode', default='train', choices=['train', 'decode', 'reformer'],
-                    help='train = headline metric; decode = AR decode tok/s (SURVEY C5), single GPU replicas')
+    ap.add_argument('--mode', default='all', choices=['all', 'train', 'decode', 'reformer'],
+                    help='all = train leg + (at one GPU) the decode and Reformer legs on the same JSON line')
+    ap.add_argument('--eager', action='store_true', help='decode leg without hipGraph replay (PMC passes: rocprofv3 cannot '
+                                                         'collect counters over graph replays)')
+    ap.add_argument('--decode-steps', type=int, default=0, help='decode steps to time (0 = the whole C5 generation)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--master-port', type=int, default=29533)
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1 or os.environ.get('MXL_DIST_FORCE') == '1':
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend='nccl', device_id=dev)
-    else:
-        dist = None
 
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_argv(args, argv):
+    """The child command for `--gpus N` (N > 1): the launch line the driver itself uses."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(args.master_port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn(args, argv) -> int:
+    """Parent of an N-rank run: no GPU call happens in this process (a process that has initialised the GPU must not
+    start or replace programs on this pool).  Children inherit stdout; only rank 0 prints the JSON line."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL on this pool
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.Popen(spawn_argv(args, argv), env=env)
+    return proc.wait()
+
+
+# ------------------------------------------------------------------------------------------------ shared timing skeleton
+class Ranks:
+    """process-group plumbing shared by the legs (and by the CPU stub used in tests)"""
+
+    def __init__(self, backend, dev):
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.dev = dev
+        self.dist = None
+        if self.world > 1 or os.environ.get('MXL_DIST_FORCE') == '1':
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+            kw = dict(device_id=dev) if backend == 'nccl' else {}
+            dist.init_process_group(backend=backend, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.dev.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.dist is None:
+            return dt
+        t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def rccl_ranks(self) -> int:
+        return self.dist.get_world_size() if self.dist is not None else 1
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ranks: Ranks, step, steps: int, warmup: int, on_timed=None) -> float:
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    ranks.barrier()
+    if on_timed is not None:
+        on_timed(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ranks.barrier()
+    dt = time.perf_counter() - t0
+    if on_timed is not None:
+        on_timed(False)
+    return ranks.max_over_ranks(dt)
+
+
+class EventBracket:
+    """HIP events on torch's current stream -- the stream every libmusicxl launch of this process goes to (ops._stream)."""
+
+    def __init__(self):
+        self.on, self.ev, self.work = False, [], 0.0
+
+    def run(self, fn, work=0.0):
+        if not self.on:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self.ev.append((s, e))
+        self.work += work
+        return r
+
+    def total_ms(self):
+        return sum(s.elapsed_time(e) for s, e in self.ev)
+
+
+# ------------------------------------------------------------------------------------------------ legs
+def train_leg(args, ranks: Ranks):
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
     from symbolic_music_generation_amd.dist import GradSync
     from symbolic_music_generation_amd import ops
-
-    if args.mode == 'decode':
-        return decode_bench(args, dev, rank, world)
-    if args.mode == 'reformer':
-        return reformer_bench(args, dev, rank, world, dist)
+    dev, rank, world = ranks.dev, ranks.rank, ranks.world
     wl = WORKLOADS[args.workload]
     B = args.batch or wl['B']
     T, M = wl['T'], wl['M']
@@ -91,55 +178,34 @@ def main():
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)          # musicnlp/util/config.json "random-seed": 77
     ids = torch.randint(4, V, (B, T), generator=gen).to(dev)            # skip the special ids
     labels = ids.clone()
-    # cosine schedule with warm-up, as TrainArgs defaults (train.py:165-190) -- lr value is irrelevant to throughput
-    lr, wd = 3e-4, 0.1
+    lr, wd = 3e-4, 0.1            # train_xl's weight decay (train.py:570); the lr value is irrelevant to throughput
 
-    # ---- live roofline timing of the dominant kernel (relattn_bwd dkv+dq launches)
-    timed = {'on': False, 'ev': []}
+    # live roofline timing of the dominant kernel group (attention backward)
+    br = EventBracket()
     orig_bwd = ops.relattn_bwd
 
     def timed_relattn_bwd(*a, **k):
-        if timed['on']:
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            finish = orig_bwd(*a, defer_drd=True, **k)          # the three attention-backward launches only
-            e.record()
-            timed['ev'].append((s, e))
-            finish()                   # the dRd contraction (+ the r_r_bias gradient), outside the bracket
-        else:
-            orig_bwd(*a, **k)
+        if not br.on:
+            return orig_bwd(*a, **k)
+        finish = br.run(lambda: orig_bwd(*a, defer_drd=True, **k))     # the attention-backward launches only
+        finish()                                                       # whatever the wrapper runs after them
 
     if not args.no_roofline:
         ops.relattn_bwd = timed_relattn_bwd
 
     def step():
-        eng.zero_grad()
-        model(input_ids=ids, labels=labels)
-        eng.backward(layer_done=sync.layer_done)
-        sync.finish()
-        eng.optimizer_step(lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_scale=1.0 / world)
+        with torch.no_grad():          # the fused path: explicit engine backward, no autograd node needed
+            eng.zero_grad()
+            model(input_ids=ids, labels=labels)
+            eng.backward(layer_done=sync.layer_done)
+            sync.finish()
+            eng.optimizer_step(lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_scale=1.0 / world)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    timed['on'] = not args.no_roofline
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timed['on'] = False
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    loss = model(input_ids=ids, labels=labels).loss.item()
-
+    dt = timed_steps(ranks, step, args.steps, args.warmup, on_timed=lambda on: setattr(br, 'on', on and not args.no_roofline))
+    ops.relattn_bwd = orig_bwd
+    with torch.no_grad():
+        loss = model(input_ids=ids, labels=labels).loss.item()
+    out = None
     if rank == 0:
         tokens = B * T * world * args.steps
         d, L = cfg.d_model, cfg.n_layer
@@ -148,35 +214,41 @@ def main():
             'metric': 'train tokens/sec (TransfoXL seq2048 bf16), whole job', 'value': tokens / dt, 'unit': 'tokens/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'rccl_ranks': ranks.rccl_ranks(),
             'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T, 'mem_len': M,
                        'parallelism': f'dp{world}', 'dropout': cfg.dropout, 'final_loss': loss,
                        'train_flops_per_token': 3 * f_fwd,
                        'whole_step_mfma_frac': 3 * f_fwd * tokens / dt / world / (MFMA_BF16_PEAK_TFLOPS * 1e12)},
         }
-        if not args.no_roofline and timed['ev']:
-            ms = sum(s.elapsed_time(e) for s, e in timed['ev']) / len(timed['ev'])
+        if br.ev:
+            ms = br.total_ms() / len(br.ev)
             # algorithmic flops of ONE attention-backward call (one layer, this rank's batch): backward = 2 x forward of the
             # banded attention core, forward = B*T*(4*d*n_bar + 2*d*M)
             nbar = (T + 1) / 2 if T <= M else M
             alg = 2 * B * T * (4 * d * nbar + 2 * d * M)
             ach = alg / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'relattn_bwd (delta + dq + dkv launches, one layer)', 'bound': 'mfma', 'achieved': ach,
-                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS,
-                               'traffic': pmc_traffic(args.workload, B), 'traffic_unit': 'HBM bytes per launch group (PMC)',
-                               'avg_launch_ms': ms, 'launches_timed': len(timed['ev'])}
+            traffic, src = pmc_traffic(args.workload, B)
+            out['roofline'] = {'kernel': 'relattn_bwd (all attention-backward launches of one layer)', 'bound': 'mfma',
+                               'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'HBM bytes per launch group (PMC)', 'traffic_source': src,
+                               'avg_launch_ms': ms, 'launches_timed': len(br.ev)}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(wl, T, M)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+            out['cpu_baseline'] = cpu_baseline_train(wl, T, M)
+    del model, eng, sync
+    torch.cuda.empty_cache()
+    return out
 
 
-def reformer_bench(args, dev, rank, world, dist):
-    """Reformer 6L (3 local + 3 LSH) d=512 H=8 dh=64 F=2048, T=8192 (axial 64x128), num_hashes=1, per-GPU B=8,
-    dropout on (0.05), auto num_buckets = [16,16].  Step = fwd + bwd + all-reduce + clip + AdamW."""
+def reformer_leg(args, ranks: Ranks, steps: int, warmup: int):
+    """Reformer 6L (3 local + 3 LSH) d=512 H=8 dh=64 F=2048, T=8192 (axial 64x128), num_hashes=1, dropout on
+    (0.05), auto num_buckets = [16,16].  Step = fwd + bwd + all-reduce + clip + AdamW."""
     from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
     from symbolic_music_generation_amd.dist import GradSync
-    B, T = args.batch or 16, 8192          # per-GPU batch sweep (DESIGN 4): 8 -> 3.61 M, 16 -> 3.87 M, 32 -> 3.97 M tok/s
+    from symbolic_music_generation_amd import ops
+    dev, rank, world = ranks.dev, ranks.rank, ranks.world
+    B = (args.batch if args.mode == 'reformer' and args.batch else 16)
+    T = 8192
     cfg = MyReformerConfig('small', vocab_size=V, max_position_embeddings=T, axial_pos_shape=(64, 128), num_hashes=1)
     model = MyReformerModelWithLMHead(cfg, device=dev, seed=77).train()
     eng = model.engine
@@ -184,140 +256,309 @@ def reformer_bench(args, dev, rank, world, dist):
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)
     ids = torch.randint(4, V, (B, T), generator=gen).to(dev)
 
-    def step():
-        eng.zero_grad()
-        model(input_ids=ids, labels=ids)
-        eng.backward(layer_done=sync.layer_done)
-        sync.finish()
-        eng.optimizer_step(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / world)
+    # dominant kernel of the step: the weight-gradient GEMM dW = dY^T X (split-K, fp32 atomics), 20 % of the kernel time
+    br = EventBracket()
+    orig_gemm = ops.gemm
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed_gemm(a, b, c, M_, N_, K_, **k):
+        if br.on and k.get('trans_a') and (k.get('flags', 0) & ops.GEMM_OUT_F32_ATOMIC):
+            return br.run(lambda: orig_gemm(a, b, c, M_, N_, K_, **k), work=2.0 * M_ * N_ * K_)
+        return orig_gemm(a, b, c, M_, N_, K_, **k)
+
+    if not args.no_roofline:
+        ops.gemm = timed_gemm
+
+    def step():
+        with torch.no_grad():
+            eng.zero_grad()
+            model(input_ids=ids, labels=ids)
+            eng.backward(layer_done=sync.layer_done)
+            sync.finish()
+            eng.optimizer_step(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / world)
+
+    dt = timed_steps(ranks, step, steps, warmup, on_timed=lambda on: setattr(br, 'on', on and not args.no_roofline))
+    ops.gemm = orig_gemm
+    out = None
     if rank == 0:
         d = cfg.hidden_size
         # local layer 24d^2 + 2*2*(2*64)*d, LSH layer 22d^2 + n_h*(d*rot + 512 d), head 2*2d*V; train = 3x
         rot = 32
         f_fwd = 3 * (24 * d * d + 512 * d) + 3 * (22 * d * d + (d * rot + 512 * d)) + 2 * 2 * d * V
-        tokens = B * T * world * args.steps
-        print(json.dumps({'metric': 'train tokens/sec (Reformer 6L/512d seq8192 bf16), whole job', 'value': tokens / dt,
-                          'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                          'dtype': 'bf16', 'data': 'synthetic',
-                          'config': {'workload': 'SURVEY C4: Reformer small (3 local + 3 LSH) d=512 T=8192 axial 64x128 n_h=1',
-                                     'per_gpu_batch': B, 'train_flops_per_token': 3 * f_fwd,
-                                     'whole_step_mfma_frac': 3 * f_fwd * tokens / dt / world / (MFMA_BF16_PEAK_TFLOPS * 1e12)}}),
-              flush=True)
+        tokens = B * T * world * steps
+        out = {'metric': 'train tokens/sec (Reformer 6L/512d seq8192 bf16), whole job', 'value': tokens / dt, 'unit': 'tokens/s',
+               'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16',
+               'data': 'synthetic',
+               'config': {'workload': 'SURVEY C4: Reformer small (3 local + 3 LSH) d=512 H8 dh64 F2048 T=8192 axial 64x128 n_h=1 '
+                                      'V=1190, dropout 0.05', 'per_gpu_batch': B, 'train_flops_per_token': 3 * f_fwd,
+                          'whole_step_mfma_frac': 3 * f_fwd * tokens / dt / world / (MFMA_BF16_PEAK_TFLOPS * 1e12)}}
+        if br.ev:
+            ms_total = br.total_ms()
+            ach = br.work / (ms_total * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'weight-gradient GEMM dW = dY^T X (gemm_bf16_kernel<AT,BT>, split-K fp32 atomics): every '
+                                         'such launch of the timed steps', 'bound': 'mfma', 'achieved': ach,
+                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS,
+                               'traffic': None, 'avg_launch_ms': ms_total / len(br.ev), 'launches_timed': len(br.ev),
+                               'share_of_step': ms_total * 1e-3 / dt}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_reformer(T)
+    del model, eng, sync
+    torch.cuda.empty_cache()
+    return out
 
 
-def decode_bench(args, dev, rank, world):
+def decode_leg(args, ranks: Ranks, warmup: int):
     """TransfoXL 12L/768d cached-mem decode, batch 64 prompts x 256 tokens, top-k 8, generate to 2048,
     one hipGraph replay per token.  A 'step' here = one generated token for the whole batch."""
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
     from symbolic_music_generation_amd.generate import XLDecoder
-    B, Tp, M = args.batch or 64, 256, 2048
+    dev, rank = ranks.dev, ranks.rank
+    B, Tp, M = (args.batch if args.mode == 'decode' and args.batch else 64), 256, 2048
     cfg = MyTransfoXLConfig('base', max_length=2048, vocab_size=V, mem_len=M, cutoffs=[])
     model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).eval()
-    dec = XLDecoder(model.engine, B, 2048, seed=77 + rank)
+    # room past T = 2048 so that a full-ring window can be timed after the C5 generation proper
+    FULL = 128
+    dec = XLDecoder(model.engine, B, 2048 + FULL + 8, seed=77 + rank)
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)
     prompt = torch.randint(4, V, (B, Tp), generator=gen).to(dev)
     samp = dict(do_sample=True, top_k=8, top_p=1.0, temperature=1.0)
-    dec.prefill(prompt, samp)
-    for _ in range(max(args.warmup, 1)):
-        dec.step(samp)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        dec.step(samp)
-    torch.cuda.synchronize()
-    # default: the whole C5 generation, prompt 256 -> T = 2048 (the first steps are cheaper than the last: ring slots that were
-    # never written are HF's zero mems and cost no K/V bytes, so a short window after the prompt would flatter the number)
-    done = Tp + 1 + max(args.warmup, 1) + 1                 # positions filled so far: prompt, its sample, warm-up and capture steps
-    steps = args.steps if args.steps != 10 else 2048 - done
-    steps = min(steps, 2048 - done)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        g.replay()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    warm = max(warmup, 1)
+    with torch.no_grad():
+        dec.prefill(prompt, samp)
+        for _ in range(warm):
+            dec.step(samp)
+        if args.eager:
+            replay = lambda: dec.step(samp)
+            done = Tp + 1 + warm
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                dec.step(samp)
+            replay = g.replay
+            done = Tp + 1 + warm + 1      # positions filled so far: prompt, its sample, warm-up and capture steps
+        torch.cuda.synchronize()
+        # the whole C5 generation, prompt 256 -> T = 2048 (the first steps are cheaper than the last: ring slots that were never
+        # written are HF's zero mems and cost no K/V bytes, so a short window after the prompt would flatter the number)
+        steps = 2048 - done if args.decode_steps <= 0 else min(args.decode_steps, 2048 - done)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # steady state with every ring slot written: positions 2048 .. 2048 + FULL
+        full_steps = FULL if args.decode_steps <= 0 else 0
+        dt_full = None
+        if full_steps:
+            t0 = time.perf_counter()
+            for _ in range(full_steps):
+                replay()
+            torch.cuda.synchronize()
+            dt_full = time.perf_counter() - t0
     d, L = cfg.d_model, cfg.n_layer
     # algorithmic bytes per step (SURVEY 8d): weights once + the WRITTEN part of the projected K/V ring per sequence, averaged
-    # over the timed steps (+ Rd tables, L2-resident); `full_ring` is the figure for a full memory (2 M d 2 B per layer)
+    # over the timed steps; `full_ring` is the figure for a full memory (2 M d 2 B per layer)
     valid = sum(min(done + i, M) for i in range(steps)) / max(steps, 1)
-    bytes_step = L * 12 * d * d * 2 + V * d * 2 + B * L * 2 * valid * d * 2
-    bytes_full = L * 12 * d * d * 2 + V * d * 2 + B * L * 2 * M * d * 2
+    wbytes = L * 12 * d * d * 2 + V * d * 2
+    bytes_step = wbytes + B * L * 2 * valid * d * 2
+    bytes_full = wbytes + B * L * 2 * M * d * 2
+    out = None
     if rank == 0:
+        ach = bytes_step / (dt / steps) / 1e9
         out = {'metric': 'AR decode tokens/sec (TransfoXL 12L/768d, batch 64, cached mems, top-k 8, hipGraph step)',
-               'value': B * steps / dt, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup,
-               'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'bf16', 'data': 'synthetic',
+               'value': B * steps / dt, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': steps, 'warmup': warm,
+               'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16', 'data': 'synthetic',
                'config': {'workload': 'SURVEY C5 decode: 12L/768d, M=2048, B=64 prompts x 256 tokens generated to T=2048, top_k=8',
-                          'batch': B, 'positions_timed': [done, done + steps]},
-               'roofline': {'kernel': 'whole decode step (hipGraph replay)', 'bound': 'hbm',
-                            'achieved': bytes_step / (dt / steps) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': bytes_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                            'algorithmic_bytes_per_step': bytes_step, 'algorithmic_bytes_per_step_full_ring': bytes_full,
-                            'mean_valid_ring_slots': valid}}
-        print(json.dumps(out), flush=True)
+                          'batch': B, 'positions_timed': [done, done + steps], 'hipgraph': not args.eager},
+               'roofline': {'kernel': 'whole decode step (one hipGraph replay: 12 x [qkv+append, bd, ring attention, o, LN, ffn1, '
+                                      'ffn2 slabs, LN] + head + sampler)', 'bound': 'hbm', 'achieved': ach,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                            'basis': 'written ring slots, averaged over the timed generation',
+                            'algorithmic_bytes_per_step': bytes_step, 'mean_valid_ring_slots': valid}}
+        if dt_full:
+            ach_f = bytes_full / (dt_full / full_steps) / 1e9
+            out['full_ring'] = {'value': B * full_steps / dt_full, 'unit': 'tokens/s', 'steps': full_steps,
+                                'ms_per_step': 1e3 * dt_full / full_steps, 'positions_timed': [2048, 2048 + full_steps],
+                                'roofline': {'bound': 'hbm', 'achieved': ach_f, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                             'frac': ach_f / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': bytes_full}}
+        if ranks.world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_decode(Tp, M)
+    del dec, model
+    torch.cuda.empty_cache()
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ PMC traffic (recorded)
 def pmc_traffic(workload, B):
-    """HBM bytes per attention-backward call from the committed PMC passes (profiles/r01_c3_pmc_traffic.json, produced by
-    scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same command; FETCH doubled per the
-    gfx950 correction).  Counters cannot be collected from inside the timed run, so this is the recorded measurement for the
-    default workload and None for any other."""
-    path = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_traffic.json')
-    if workload != 'c3' or not os.path.exists(path):
-        return None
+    """HBM bytes per attention-backward group from the newest committed PMC passes (profiles/r*_c3_pmc_traffic.json, produced
+    by scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same command; FETCH doubled per
+    the gfx950 correction).  Counters cannot be collected from inside the timed run, so this is the recorded measurement for
+    the default workload and None for any other batch / workload / kernel set."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_c3_pmc_traffic.json')))
+    if workload != 'c3' or not files:
+        return None, None
+    path = files[-1]
     rec = json.load(open(path))
-    if rec.get('per_gpu_batch', 16) != B:          # the passes were collected at one batch size; no figure for another
-        return None
+    if rec.get('per_gpu_batch', 16) != B:
+        return None, None
     k = rec['kernels']
-    dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
-    names = ('relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>')
+    names = rec.get('attention_backward_group')
+    if names is None:
+        dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
+        names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>']
     if not all(n in k for n in names):
-        return None
-    return sum(k[n]['hbm_bytes_per_launch'] for n in names)
+        return None, None
+    return sum(k[n]['hbm_bytes_per_launch'] * k[n].get('launches_per_group', 1) for n in names), os.path.basename(path)
 
 
-def cpu_baseline(wl, T, M):
-    """The oracle (reference-style dense fp32 TransfoXL, oracle/transfoxl_ref.py) on the host cores: train steps
-    (fwd + bwd + clip + AdamW) on a bounded sample: B=1 sequence of the same T/M and, to stay within ~30 s of CPU work,
-    at most 3 of the workload's layers (per-layer cost is identical; embedding + head are included once), scaled to the
-    full depth in `value`."""
+# ------------------------------------------------------------------------------------------------ CPU oracle baselines
+def _timed_cpu_steps(fn, max_steps=3, budget=CPU_BUDGET_S):
+    """1 warm-up + up to `max_steps` timed calls, stopping early once `budget` seconds of CPU work are spent"""
+    t_all = time.perf_counter()
+    fn()
+    times = []
+    while len(times) < max_steps and (not times or time.perf_counter() - t_all + times[-1] < budget):
+        t = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t)
+    return times
+
+
+def cpu_baseline_train(wl, T, M):
+    """The oracle (reference-style dense fp32 TransfoXL, oracle/transfoxl_ref.py) on the host cores: train steps (fwd + bwd +
+    clip + AdamW), B = 1 sequence of the same T / M.  A full 12-layer step takes ~80 s on the box's host, so the sample is
+    ONE decoder layer (1 warm-up + up to 3 timed steps) plus the embedding / head part timed on a 0-layer model; per-layer cost
+    is identical across layers, so a full step is t(0 layers) + L x (t(1 layer) - t(0 layers))."""
     from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
     torch.manual_seed(77)
     L_full = wl['n_layer']
-    L_s = min(L_full, 3)
-    c = RefXLConfig.from_preset(wl['size'], vocab_size=V, max_length=T, mem_len=M, cutoffs=[], n_layer=L_s)
-    m = RefTransfoXLLMHeadModel(c).train()
     ids = torch.randint(4, V, (1, T))
-    opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.1)
-    times = []
-    for i in range(2):
+
+    def make(L):
+        c = RefXLConfig.from_preset(wl['size'], vocab_size=V, max_length=T, mem_len=M, cutoffs=[], n_layer=L)
+        m = RefTransfoXLLMHeadModel(c).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.1)
+
+        def one():
+            o = m(ids, labels=ids)
+            o.loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+        return one
+
+    t0 = _timed_cpu_steps(make(0), 3, 5.0)
+    t1 = _timed_cpu_steps(make(1), 3, CPU_BUDGET_S)
+    a, b = sum(t0) / len(t0), sum(t1) / len(t1)
+    t_full = a + L_full * max(b - a, 1e-9)
+    return {'value': T / t_full, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'B=1 x T={T} (M={M}) fp32 train steps (fwd+bwd+clip+AdamW) after 1 warm-up: {len(t1)} steps of a 1-layer '
+                      f'model ({b:.2f} s each) and {len(t0)} of the 0-layer embedding+head part ({a:.2f} s); full step = '
+                      f't0 + {L_full} x (t1 - t0) = {t_full:.1f} s'}
+
+
+def cpu_baseline_decode(Tp, M):
+    """oracle greedy decode (HF-style loop: one forward per token over cat(mems, token), mems carried) at the C5 model,
+    B = 1, 256-token prompt, 32 generated tokens"""
+    from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
+    torch.manual_seed(77)
+    c = RefXLConfig.from_preset('base', vocab_size=V, max_length=2048, mem_len=M, cutoffs=[])
+    m = RefTransfoXLLMHeadModel(c).eval()
+    ids = torch.randint(4, V, (1, Tp))
+    n_new = 32
+    with torch.no_grad():
         t = time.perf_counter()
-        o = m(ids, labels=ids)
-        o.loss.backward()
-        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        out = m(ids)                                   # prompt pass (not counted in tokens/s: the GPU number excludes it too)
+        t_prompt = time.perf_counter() - t
+        past, cur = out.mems, out.prediction_scores[:, -1].argmax(-1, keepdim=True)
+        t = time.perf_counter()
+        for _ in range(n_new):
+            o = m(cur, mems=past)
+            past, cur = o.mems, o.prediction_scores[:, -1].argmax(-1, keepdim=True)
+        dt = time.perf_counter() - t
+    return {'value': n_new / dt, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'B=1, {Tp}-token prompt ({t_prompt:.2f} s, not counted), {n_new} greedy tokens with carried mems '
+                      f'(M={M}), fp32, {dt:.2f} s'}
+
+
+def cpu_baseline_reformer(T):
+    """oracle/reformer_ref.py (pinned on HF Reformer goldens) at C4, B = 1: forward + loss + autograd backward (stored
+    activations; HF's reversible stack would recompute every layer on top of this) + clip + AdamW"""
+    from oracle.reformer_ref import RefReformerConfig, RefReformer, init_params
+    torch.manual_seed(77)
+    c = RefReformerConfig.from_preset('small', vocab_size=V, max_position_embeddings=T, axial_pos_shape=(64, 128), num_hashes=1,
+                                      hidden_dropout_prob=0.0, local_attention_probs_dropout_prob=0.0)
+    params = {k: v.requires_grad_(True) for k, v in init_params(c, seed=77).items()}
+    m = RefReformer(c, params)
+    opt = torch.optim.AdamW(list(params.values()), lr=3e-4, weight_decay=0.01)
+    ids = torch.randint(4, V, (1, T))
+    g = torch.Generator().manual_seed(77)
+    rots = {l: torch.randn(*m.rotations_shape(T), generator=g) for l, kind in enumerate(c.attn_layers) if kind == 'lsh'}
+
+    def one():
+        _, loss = m.forward(ids, rotations=rots, labels=ids)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
         opt.step()
         opt.zero_grad()
-        times.append(time.perf_counter() - t)
-    t_full = times[-1] * L_full / L_s
-    return {'value': T / t_full, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 train step after 1 warm-up, B=1 x T={T} (M={M}), fp32, {L_s} of {L_full} layers timed '
-                      f'({times[-1]:.1f} s) and scaled x{L_full}/{L_s}'}
+
+    times = _timed_cpu_steps(one, 3, CPU_BUDGET_S)
+    t = sum(times) / len(times)
+    return {'value': T / t, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'B=1 x T={T} fp32 train steps (fwd+bwd+clip+AdamW, no reversible recompute) after 1 warm-up: {len(times)} '
+                      f'steps, {t:.2f} s each'}
+
+
+# ------------------------------------------------------------------------------------------------ CPU stub (tests only)
+def stub_leg(args, ranks: Ranks):
+    """`MXL_BENCH_STUB=1`: no GPU, gloo ranks, a step = one all-reduce of a small buffer.  Exists so that a CPU test can run
+    `bench.py --gpus 2` through the real launcher / barrier / max-over-ranks / relay code path."""
+    buf = torch.ones(1024)
+
+    def step():
+        ranks.dist.all_reduce(buf) if ranks.dist is not None else None
+        buf.fill_(1.0)
+
+    dt = timed_steps(ranks, step, args.steps, args.warmup)
+    if ranks.rank == 0:
+        return {'metric': 'stub', 'value': args.steps / dt, 'unit': 'steps/s', 'n_gpus': ranks.world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'rccl_ranks': ranks.rccl_ranks(), 'stub': True}
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    launched = 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn(args, argv))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if launched and world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if os.environ.get('MXL_BENCH_STUB') == '1':
+        ranks = Ranks('gloo', torch.device('cpu'))
+        out = stub_leg(args, ranks)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local_rank)
+        ranks = Ranks('nccl', torch.device('cuda', local_rank))
+        if args.mode == 'decode':
+            out = decode_leg(args, ranks, args.warmup)
+        elif args.mode == 'reformer':
+            out = reformer_leg(args, ranks, args.steps, args.warmup)
+            if out is not None:
+                out.update(higher_is_better=True, scaling='weak', vs_baseline=None, rccl_ranks=ranks.rccl_ranks())
+        else:
+            out = train_leg(args, ranks)
+            if args.mode == 'all' and world == 1 and args.workload == 'c3':
+                dec = decode_leg(args, ranks, 3)
+                ref = reformer_leg(args, ranks, min(args.steps, 10), min(args.warmup, 3))
+                out['decode'], out['reformer'] = dec, ref
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    ranks.close()
 
 
 if __name__ == '__main__':

@@ -175,6 +175,9 @@ int mxl_adamw_step(float* p, const float* g, float* m, float* v, void* w16, long
                    float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
                    float max_norm, float grad_scale, void* stream);
 int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
+/* x = hi + lo, hi = bf16(x), lo = bf16(x - hi): operand pair that keeps 16 mantissa bits through a bf16 MFMA contraction
+ * (used for dW_r = dRd^T phi, the gradient of upstream's r_net: its fp32 partial sums dRd must not be rounded to 8 bits). */
+int mxl_split_f32_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream);
 /* dst[b][c][r] = src[b][r][c] (bf16; element strides between batch items).  Keeps [in][out] copies of the Linear weights so
  * that the input gradient dX = dY W (autograd of F.linear) runs in the K-contiguous GEMM form. */
 int mxl_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, int batch,

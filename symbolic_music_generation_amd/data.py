@@ -258,9 +258,14 @@ class DeviceBatcher:
         self._first = [True, True]
 
     def order(self) -> np.ndarray:
+        """This rank's rows.  Like `DistributedSampler` the (shuffled) index is padded by wrapping around to a multiple of the
+        world size before striding: every rank then yields the same number of equally sized batches, so the ranks' gradient
+        all-reduces always pair up (a shard one row short would run one step fewer and hang the job)."""
         idx = np.arange(len(self.tf))
         if self.shuffle:
             np.random.default_rng(self.seed + self.epoch).shuffle(idx)
+        if self.world > 1 and len(idx) % self.world:
+            idx = np.concatenate([idx, idx[:self.world - len(idx) % self.world]])
         return idx[self.rank::self.world]
 
     def __len__(self):

@@ -47,6 +47,9 @@ class XLDecoder:
         self.logp = torch.empty(batch, c.vocab_size, device=dev, dtype=torch.float32)
         self.graph = None
         self._graph_key = None
+        # optional (B, Tmax, V) f32 buffer: row t receives the log-probs computed FROM position t (parity tests compare them
+        # with a one-shot forward); written on the device by position, so it also works under hipGraph replay
+        self.trace = None
 
     def _tables(self):
         if self.rd is None:
@@ -87,6 +90,7 @@ class XLDecoder:
         last = ws.logits.view(B, Tp, -1)[:, Tp - 1]
         ops.adaptive_logprob(last, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         self.t_dev.fill_(Tp - 1)
+        self._trace()
         ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
         ops.decode_advance(self.t_dev, self.rng)       # t = Tp: position of the token just sampled
         return out
@@ -131,8 +135,13 @@ class XLDecoder:
         boff = e.layout.entries['crit.out_layers.0.bias'][0]
         G(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
         ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
+        self._trace()
         ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
         ops.decode_advance(self.t_dev, self.rng)
+
+    def _trace(self):
+        if self.trace is not None:
+            self.trace.index_copy_(1, self.t_dev.to(torch.int64), self.logp.unsqueeze(1))
 
     # ---------------------------------------------------------------- loop
     def generate(self, prompt: torch.Tensor, max_length: int, do_sample: bool = False, top_k: Optional[int] = None,

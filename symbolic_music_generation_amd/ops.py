@@ -21,6 +21,19 @@ GEMM_RELU_BWD = 0x20
 GEMM_ADD_AUX = 0x40
 
 
+def mix_seed(base_seed: int, step: int) -> int:
+    """Dropout / LSH-rotation seed of one step: a 63-bit mix of (base seed, data-parallel rank, step).  Under data parallelism
+    every rank draws its own masks (as DDP ranks do in the reference stack) while the weight-initialisation seed stays
+    common; no collisions between runs once `step` passes 2^20 (the former `(seed << 20) + step`)."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    x = (base_seed * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + step * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 32
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -218,6 +231,11 @@ def adamw_step(p, g, m, v, w16, n_decay, lr, beta1, beta2, eps, weight_decay, st
 def cast_bf16(x: torch.Tensor, y: torch.Tensor):
     check(lib().mxl_cast_f32_bf16(_p(x), _p(y), x.numel(), _stream()), 'mxl_cast_f32_bf16')
     return y
+
+
+def split_bf16(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor):
+    check(lib().mxl_split_f32_bf16x2(_p(x), _p(hi), _p(lo), x.numel(), _stream()), 'mxl_split_f32_bf16x2')
+    return hi, lo
 
 
 def transpose(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, *, ld_src=None, ld_dst=None, batch=1,

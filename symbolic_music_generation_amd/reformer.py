@@ -8,6 +8,7 @@ from typing import Any, Dict, Optional
 
 import torch
 
+from .module import EngineModule
 from .rf_engine import RFEngine
 
 __all__ = ['MyReformerConfig', 'MyReformerModelWithLMHead']
@@ -97,33 +98,16 @@ class ReformerModelWithLMHeadOutput:
         return tuple(v for v in (self.loss, self.logits) if v is not None)[k]
 
 
-class MyReformerModelWithLMHead:
+class MyReformerModelWithLMHead(EngineModule):
+    """`torch.nn.Module` over `RFEngine` (see module.EngineModule): HF's state-dict names, autograd-connected loss."""
     cls_name = 'Reformer'
 
     def __init__(self, config: MyReformerConfig, device='cuda:0', seed: int = 77):
+        super().__init__()
         self.config = config
         self.engine = RFEngine(config, device, seed=seed)
-        self.training = True
         self.device = torch.device(device)
-
-    def train(self, mode: bool = True):
-        self.training = mode
-        return self
-
-    def eval(self):
-        return self.train(False)
-
-    def to(self, *_a, **_k):
-        return self
-
-    def num_parameters(self):
-        return self.engine.num_parameters()
-
-    def state_dict(self):
-        return self.engine.state_dict()
-
-    def load_state_dict(self, sd, strict=True):
-        self.engine.load_state_dict(sd, strict=strict)
+        self._bind_parameters()
 
     def save_pretrained(self, path):
         self.config.save_pretrained(path)
@@ -148,18 +132,13 @@ class MyReformerModelWithLMHead:
             raise NotImplementedError('only the arguments the reference passes (input_ids, labels) are implemented')
         if num_hashes is not None and num_hashes != self.config.num_hashes:
             raise NotImplementedError('per-call num_hashes override')
-        out = self.engine.forward(input_ids.to(self.device), labels=None if labels is None else labels.to(self.device),
-                                  train=self.training, rotations=rotations, buckets_override=buckets)
+        ids = input_ids.to(self.device)
+        lab = None if labels is None else labels.to(self.device)
+        out = self._run_engine(lambda: self.engine.forward(ids, labels=lab, train=self.training, rotations=rotations,
+                                                           buckets_override=buckets),
+                               differentiable=self.training and labels is not None)
         res = ReformerModelWithLMHeadOutput(loss=out['loss'], logits=out['logits'])
         return res[:] if return_dict is False else res
-
-    __call__ = forward
-
-    def backward(self, grad_scale=1.0, layer_done=None):
-        self.engine.backward(grad_scale=grad_scale, layer_done=layer_done)
-
-    def zero_grad(self):
-        self.engine.zero_grad()
 
     @torch.no_grad()
     def generate(self, input_ids=None, max_length: Optional[int] = None, do_sample: bool = False, top_k: Optional[int] = None,
@@ -176,6 +155,7 @@ class MyReformerModelWithLMHead:
             bad = [k for k, v in unsupported.items() if v not in (None, False, 1, 1.0)]
             if bad:
                 raise NotImplementedError(f'generation options not covered: {bad}')
+        self._maybe_resync()
         c = self.config
         was_training = self.training
         self.eval()

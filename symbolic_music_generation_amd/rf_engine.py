@@ -108,6 +108,7 @@ class RFEngine:
         self.G = self.m = self.v = None
         self.WT = None                      # [in][out] weight copies for the dX GEMMs (training only; see XLEngine)
         self.step_count, self.base_seed = 0, seed
+        self.rng_step = 0          # dropout-mask / LSH-rotation stream position (see XLEngine)
         self._ws: Dict = {}
         self._sumsq = torch.zeros(1, device=self.dev)
         self.num_buckets = cfg.num_buckets
@@ -197,7 +198,13 @@ class RFEngine:
         key = (B, T, train)
         ws = self._ws.get(key)
         if ws is not None:
+            self._ws[key] = self._ws.pop(key)      # most recently used last
             return ws
+        # bounded cache: a ragged last batch or a generation loop with a growing T must not pile up workspaces (14.5 GB per
+        # key at 12L/768d, B = 32); keep the two most recent shapes per mode
+        same = [k for k in self._ws if k[-1] == train]
+        for k in same[:max(0, len(same) - 1)]:
+            del self._ws[k]
         c, dev = self.cfg, self.dev
         d, Fi, H, L, n_h = c.hidden_size, c.feed_forward_size, c.num_attention_heads, len(c.attn_layers), c.num_hashes
         N = B * T
@@ -274,7 +281,7 @@ class RFEngine:
         p = float(c.hidden_dropout_prob) if train else 0.0
         p_loc = float(c.local_attention_probs_dropout_prob) if train else 0.0
         p_lsh = float(c.lsh_attention_probs_dropout_prob) if train else 0.0
-        seed = (self.base_seed << 20) + self.step_count
+        seed = ops.mix_seed(self.base_seed, self.rng_step)
         ids = input_ids.contiguous()
         ws.ids, ws.B, ws.T, ws.p, ws.p_loc, ws.p_lsh, ws.seed = ids, B, T, p, p_loc, p_lsh, seed
         d0 = c.axial_pos_embds_dim[0]
@@ -310,7 +317,7 @@ class RFEngine:
                     if rotations is not None and l in rotations:
                         rot = rotations[l].to(self.dev, torch.float32).contiguous()
                     else:   # HF draws fresh rotations from the global RNG every forward (hash_seed=None in the reference)
-                        g = torch.Generator(device=self.dev).manual_seed(seed * 131 + l)
+                        g = torch.Generator(device=self.dev).manual_seed((seed * 131 + l) & 0x7FFFFFFFFFFFFFFF)
                         rot = torch.randn(H, dh, n_h, sum(factors) // 2, device=self.dev, generator=g)
                     ws.rot[l] = rot
                     ops.lsh_hash(qkv, bs, rs, rot, ws.buckets, B, T, H, dh, n_h, factors)
@@ -476,6 +483,7 @@ class RFEngine:
             self.m = torch.zeros_like(self.P)
             self.v = torch.zeros_like(self.P)
         self.step_count += 1
+        self.rng_step += 1
         self._sumsq.zero_()
         if max_grad_norm and max_grad_norm > 0:
             ops.sumsq(self.G, self._sumsq)

@@ -153,28 +153,37 @@ class MyTrainer:
         self.global_step += 1
         return out.loss
 
-    def _shard(self, n: int, epoch: int, shuffle: bool) -> List[int]:
+    def _shard(self, n: int, epoch: int, shuffle: bool, pad: bool) -> List[int]:
+        """This rank's dataset indices.  Training (`pad=True`) follows `DistributedSampler`: the permuted index is padded by
+        wrapping around to a multiple of the world size before striding, so EVERY rank gets ceil(n / world) samples and hence
+        the same number of (equally sized) batches -- the per-layer gradient all-reduces of the ranks always pair up.
+        Evaluation takes the plain strided shard (no duplicated samples; its only collective is one sum at the end)."""
         g = torch.Generator().manual_seed(self.seed + epoch)
         idx = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
-        return idx[mdist.rank()::mdist.world_size()]
+        world = mdist.world_size()
+        if pad and n % world:
+            idx += idx[:world - n % world]
+        return idx[mdist.rank()::world]
 
-    def _batches(self, ds, bsz: int, epoch: int, shuffle: bool):
-        idx = self._shard(len(ds), epoch, shuffle)
-        for i in range(0, len(idx) - bsz + 1 if shuffle else len(idx), bsz):
+    def _batches(self, ds, bsz: int, epoch: int, shuffle: bool, pad: bool = False, with_index: bool = False):
+        """HF Trainer's loader keeps the last partial batch (`dataloader_drop_last=False`)."""
+        idx = self._shard(len(ds), epoch, shuffle, pad)
+        for i in range(0, len(idx), bsz):
             rows = [torch.as_tensor(ds[j]) for j in idx[i:i + bsz]]
             if rows:
-                yield torch.stack(rows).to(self.model.device)
+                b = torch.stack(rows).to(self.model.device)
+                yield (b, idx[i:i + bsz]) if with_index else b
 
     # ---------------------------------------------------------------- loops
     def train(self, max_steps: Optional[int] = None) -> Dict:
         a = self.args
         bsz = a['per_device_train_batch_size']
-        spe = max(1, len(self.train_dataset) // (bsz * mdist.world_size()))
+        spe = max(1, math.ceil(len(self.train_dataset) / (bsz * mdist.world_size())))   # == TrainArgs.steps_per_epoch
         total = max_steps or spe * int(a['num_train_epochs'])
         t0 = time.time()
         done = False
         for epoch in range(int(a['num_train_epochs'])):
-            for ids in self._batches(self.train_dataset, bsz, epoch, shuffle=True):
+            for ids in self._batches(self.train_dataset, bsz, epoch, shuffle=True, pad=True):
                 ids, labels = collate_clm(ids, self.pad_id)
                 lr = lr_at(self.global_step, total, a['learning_rate'], a['lr_scheduler_type'], a['warmup_ratio'])
                 loss = self.training_step(ids, labels, lr)
@@ -191,14 +200,18 @@ class MyTrainer:
                 ev.update(step=self.global_step, epoch=epoch + 1)
                 self.log_history.append(ev)
                 self.log_fn(ev)
-                if a['output_dir'] and mdist.rank() == 0:
+                if a['output_dir']:
+                    # eval_loss is all-reduced and the path is deterministic: every rank tracks the same best checkpoint
                     ck = os.path.join(a['output_dir'], f'checkpoint-{self.global_step}')
-                    self.save_model(ck)
+                    if mdist.rank() == 0:
+                        self.save_model(ck)
                     if ev['eval_loss'] < self.best[0]:
                         self.best = (ev['eval_loss'], ck)
             if done:
                 break
         if a['load_best_model_at_end'] and self.best[1] is not None:
+            if mdist.is_dist():
+                torch.distributed.barrier()         # rank 0 has finished writing before anyone reads
             self.model.load_state_dict(torch.load(os.path.join(self.best[1], 'pytorch_model.bin'), map_location='cpu'))
         return dict(train_runtime=time.time() - t0, global_step=self.global_step)
 
@@ -211,8 +224,8 @@ class MyTrainer:
         self.model.eval()
         bsz = self.args['per_device_eval_batch_size']
         cm = ComputeMetrics(self.tokenizer, mode='vanilla', clm_pred_shifted=False) if self.tokenizer is not None else None
-        tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n, row0 = 0.0, 0, 0.0, 0.0, 0.0, 0, 0
-        for ids in self._batches(self.eval_dataset, bsz, 0, shuffle=False):
+        tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n = 0.0, 0, 0.0, 0.0, 0.0, 0
+        for ids, rows in self._batches(self.eval_dataset, bsz, 0, shuffle=False, with_index=True):
             ids, labels = collate_clm(ids, self.pad_id)
             out = self.model(input_ids=ids, labels=labels)
             preds = max_out_logits(out.logits)
@@ -220,14 +233,13 @@ class MyTrainer:
                 c = cm.counts(preds, labels).cpu().numpy()
                 hit += float(c[:, 12].sum()); cnt += float(c[:, 13].sum())
                 if key_scores is not None:
-                    ks = key_scores[row0:row0 + ids.shape[0]]
+                    ks = key_scores[rows]            # the shard is strided: index by the samples' dataset rows
                     ikr_sum += cm.ikr_from_counts(c, labels, ks) * ids.shape[0]
                     ikr_n += ids.shape[0]
             else:       # no tokenizer: accuracy only, still on device ids
                 msk = labels[:, 1:] != PT_LOSS_PAD
                 hit += (preds[:, :-1][msk] == labels[:, 1:][msk]).float().sum().item()
                 cnt += msk.sum().item()
-            row0 += ids.shape[0]
             tot_loss += out.loss.item() * ids.shape[0]
             tot_n += ids.shape[0]
         stats = torch.tensor([tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n], dtype=torch.float64, device=self.model.device)

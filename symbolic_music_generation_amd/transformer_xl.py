@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
+from .module import EngineModule
 from .xl_engine import XLEngine
 
 __all__ = ['MyTransfoXLConfig', 'MyTransfoXLLMHeadModel', 'TransfoXLLMHeadModelOutput']
@@ -116,34 +117,19 @@ class TransfoXLLMHeadModelOutput:
         return tuple(v for v in (self.loss, self.prediction_scores, self.losses, self.mems) if v is not None)[k]
 
 
-class MyTransfoXLLMHeadModel:
+class MyTransfoXLLMHeadModel(EngineModule):
+    """`torch.nn.Module` (module.EngineModule): parameters are fp32 views into the engine's flat buffer under upstream's
+    state-dict names, and a train-mode `loss` carries an autograd node whose backward is the engine's HIP backward -- the
+    reference's `Trainer` loop (`loss.backward(); clip_grad_norm_; optimizer.step()`) drives it unchanged."""
     cls_name = 'TransformerXl'
 
     def __init__(self, config: MyTransfoXLConfig, device='cuda:0', seed: int = 77):
+        super().__init__()
         self.config = config
         self.engine = XLEngine(config, device, seed=seed)
-        self.training = True
         self.device = torch.device(device)
-
-    # -- nn.Module-like toggles the callers rely on (transformer_xl.py:190 reads self.training)
-    def train(self, mode: bool = True):
-        self.training = mode
-        return self
-
-    def eval(self):
-        return self.train(False)
-
-    def to(self, *_a, **_k):
-        return self
-
-    def num_parameters(self) -> int:
-        return self.engine.num_parameters()
-
-    def state_dict(self):
-        return self.engine.state_dict()
-
-    def load_state_dict(self, sd, strict: bool = True):
-        self.engine.load_state_dict(sd, strict=strict)
+        # upstream ties crit.out_layers.0.weight to the embedding (tie_word_embeddings, div_val == 1)
+        self._bind_parameters(tied={'crit.out_layers.0.weight': 'transformer.word_emb.emb_layers.0.weight'})
 
     def save_pretrained(self, path: str):
         """HF layout: config.json + pytorch_model.bin with upstream parameter names."""
@@ -180,7 +166,9 @@ class MyTransfoXLLMHeadModel:
             labels = labels.to(self.device)
         if mems is not None and len(mems) and mems[0].size(0) != self.config.mem_len:
             raise ValueError('mems must hold exactly mem_len rows (upstream init_mems/_update_mems invariant)')
-        out = self.engine.forward(input_ids, mems=self._mems_in(mems), labels=labels, train=self.training)
+        mems_in = self._mems_in(mems)
+        out = self._run_engine(lambda: self.engine.forward(input_ids, mems=mems_in, labels=labels, train=self.training),
+                               differentiable=self.training and labels is not None)
         in_eval = not self.training
         prediction_scores = out['logprobs'] if (labels is None or in_eval) else ()
         res = TransfoXLLMHeadModelOutput(loss=out['loss'], prediction_scores=prediction_scores, losses=out['losses'],
@@ -188,8 +176,6 @@ class MyTransfoXLLMHeadModel:
         if return_dict is False:
             return res[:]
         return res
-
-    __call__ = forward
 
     def prepare_inputs_for_generation(self, input_ids, past=None, **model_kwargs):
         """transformer_xl.py:223-241"""
@@ -204,6 +190,7 @@ class MyTransfoXLLMHeadModel:
             inputs['input_ids'] = input_ids
         return inputs
 
+    @torch.no_grad()
     def generate(self, input_ids: torch.Tensor = None, max_length: int = None, do_sample: bool = False,
                  top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: float = 1.0, num_beams: int = 1,
                  penalty_alpha=None, typical_p=None, repetition_penalty=None, early_stopping=None,
@@ -212,6 +199,7 @@ class MyTransfoXLLMHeadModel:
         from .generate import XLDecoder
         if num_beams != 1 or penalty_alpha is not None:
             raise NotImplementedError('beam / contrastive search are out of scope for the HIP decode path (SURVEY 8: A10)')
+        self._maybe_resync()
         max_length = max_length or self.config.max_length_
         B = input_ids.shape[0]
         dec = getattr(self, '_decoder', None)
@@ -221,10 +209,3 @@ class MyTransfoXLLMHeadModel:
         return dec.generate(input_ids.to(self.device), max_length, do_sample=do_sample, top_k=top_k, top_p=top_p,
                             temperature=temperature, repetition_penalty=repetition_penalty, typical_p=typical_p,
                             use_graph=use_graph)
-
-    # -- training hooks used by the trainer
-    def backward(self, grad_scale: float = 1.0, layer_done=None):
-        self.engine.backward(grad_scale=grad_scale, layer_done=layer_done)
-
-    def zero_grad(self):
-        self.engine.zero_grad()

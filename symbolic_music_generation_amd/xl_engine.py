@@ -98,7 +98,8 @@ class XLEngine:
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
         self.WT: Optional[Dict[str, torch.Tensor]] = None                  # [in][out] weight copies (training only)
-        self.step_count = 0
+        self.step_count = 0        # optimizer steps taken (AdamW bias correction)
+        self.rng_step = 0          # dropout-mask / LSH-rotation stream position: advances with every backward pass
         self.base_seed = seed
         self._ws: Dict[Tuple, _WS] = {}
         self._sumsq = torch.zeros(1, device=self.dev)
@@ -190,7 +191,13 @@ class XLEngine:
         key = (B, T, Kc, train)
         ws = self._ws.get(key)
         if ws is not None:
+            self._ws[key] = self._ws.pop(key)      # most recently used last
             return ws
+        # bounded cache: a ragged last batch or a generation loop with a growing T must not pile up workspaces (14.5 GB per
+        # key at 12L/768d, B = 32); keep the two most recent shapes per mode
+        same = [k for k in self._ws if k[-1] == train]
+        for k in same[:max(0, len(same) - 1)]:
+            del self._ws[k]
         c, dev = self.cfg, self.dev
         d, Fi, H, L, M = c.d_model, c.d_inner, c.n_head, c.n_layer, c.mem_len
         N = B * T
@@ -226,6 +233,7 @@ class XLEngine:
             ws.qr = torch.empty(B, T, d, **bf)
             ws.d_rd = torch.empty(M, d, **f32)
             ws.d_rd16 = torch.empty(M, d, **bf)
+            ws.d_rd16lo = torch.empty(M, d, **bf)
             ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
         ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32)
         ws.nll = torch.empty(B, max(T - 1, 1), **f32)
@@ -251,7 +259,7 @@ class XLEngine:
         Kc = T + (M if has_mem else 0)
         ws = self._workspace(B, T, Kc, train)
         p = float(c.dropout) if train else 0.0
-        seed = (self.base_seed << 20) + self.step_count
+        seed = ops.mix_seed(self.base_seed, self.rng_step)
         ids = input_ids.contiguous()
         ws.ids, ws.B, ws.T, ws.Kc, ws.p, ws.seed, ws.has_mem = ids, B, T, Kc, p, seed, has_mem
 
@@ -417,9 +425,12 @@ class XLEngine:
                             ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
                             dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr, **st)
             # r_net: dW_r = d_rd^T . phi
-            ops.cast_bf16(ws.d_rd, ws.d_rd16)
-            ops.gemm(ws.d_rd16, ws.phi, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
-                     ksplits=self._ks(d, d))
+            # dRd rows are fp32 sums over every (sequence, query); many of them meet again in this contraction (all distances past
+            # clamp_len share one phi row), so they enter as a (hi, lo) bf16 pair: 16 mantissa bits at the cost of a second tiny GEMM
+            ops.split_bf16(ws.d_rd, ws.d_rd16, ws.d_rd16lo)
+            for part in (ws.d_rd16, ws.d_rd16lo):
+                ops.gemm(part, ws.phi, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
+                         ksplits=self._ks(d, d))
             # qkv_net
             if ws.has_mem:
                 dqkv[:, :M, :d].zero_()   # memory rows carry no query gradient
@@ -447,6 +458,7 @@ class XLEngine:
             self.m = torch.zeros_like(self.P)
             self.v = torch.zeros_like(self.P)
         self.step_count += 1
+        self.rng_step += 1
         self._sumsq.zero_()
         if max_grad_norm and max_grad_norm > 0:
             ops.sumsq(self.G, self._sumsq)

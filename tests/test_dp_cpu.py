@@ -1,0 +1,132 @@
+"""Data-parallel host logic on CPU: `bench.py --gpus N` really starts N ranks (gloo stub), every rank yields the same number
+of equally sized training batches whatever the dataset size, and 2 ranks x B sequences give the gradients and loss of 1 rank
+x 2B through `dist.GradSync` (the oracle model supplies real tiny-model gradients; the HIP engine cannot run here)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port(k=0):
+    return 29700 + (os.getpid() * 7 + k * 131) % 2000
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    env = dict(os.environ, MXL_BENCH_STUB='1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--master-port', str(_port())], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line (rank 0 only)'
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+
+
+def test_bench_spawn_argv_and_world_mismatch():
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(['--gpus', '8', '--steps', '20', '--warmup', '5'])
+    argv = bench.spawn_argv(args, ['--gpus', '8', '--steps', '20', '--warmup', '5'])
+    assert argv[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in argv
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+    assert argv[-6:] == ['--gpus', '8', '--steps', '20', '--warmup', '5'] and argv[-7].endswith('bench.py')
+    # started by a launcher with a different world size: fail loudly instead of reporting the wrong n_gpus
+    env = dict(os.environ, MXL_BENCH_STUB='1', WORLD_SIZE='2', RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize('n,bsz', [(127, 32), (130, 32), (64, 32), (5, 2)])
+def test_every_rank_yields_the_same_batches(monkeypatch, n, bsz):
+    """n % world != 0 gave the ranks different step counts (n=127, world=2, bsz=32: 2 vs 1), which misaligns the
+    per-layer gradient all-reduces.  Now the shard is padded DistributedSampler-style."""
+    from symbolic_music_generation_amd import trainer as tr, dist as mdist
+    from symbolic_music_generation_amd.data import DeviceBatcher
+    world = 2
+    ds = [torch.full((4,), i) for i in range(n)]
+    shapes, seen = [], []
+    for rank in range(world):
+        monkeypatch.setattr(mdist, 'world_size', lambda: world)
+        monkeypatch.setattr(mdist, 'rank', lambda r=rank: r)
+        t = object.__new__(tr.MyTrainer)
+        t.seed = 77
+
+        class M:
+            device = 'cpu'
+        t.model = M()
+        bs = list(t._batches(ds, bsz, epoch=3, shuffle=True, pad=True))
+        shapes.append([b.shape[0] for b in bs])
+        seen += [int(b[j, 0]) for b in bs for j in range(b.shape[0])]
+        # evaluation: plain strided shard, no duplicates
+        ev = [i for b, rows in t._batches(ds, bsz, 0, shuffle=False, with_index=True) for i in rows]
+        assert ev == list(range(n))[rank::world]
+        db = object.__new__(DeviceBatcher)
+        db.tf, db.shuffle, db.seed, db.epoch, db.rank, db.world, db.B, db.drop_last = ds, True, 1, 0, rank, world, bsz, False
+        shapes.append(('db', len(db.order()), len(db)))
+    assert shapes[0] == shapes[2] and shapes[1][1:] == shapes[3][1:], shapes
+    assert set(seen) == set(range(n)) and len(seen) == (n + world - 1) // world * world
+    assert len(shapes[0]) == -(-((n + world - 1) // world) // bsz)
+
+
+_DP_EQUIV_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from symbolic_music_generation_amd.dist import GradSync
+from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig
+from symbolic_music_generation_amd.xl_engine import ParamLayout
+from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
+world = 2
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=int(sys.argv[3]), world_size=world)
+rank = dist.get_rank()
+kw = dict(vocab_size=1190, cutoffs=[], n_layer=2, mem_len=32, max_length=32, dropout=0.0)
+cfg = MyTransfoXLConfig('debug', **kw)
+layout = ParamLayout(cfg)
+torch.manual_seed(5)
+ref = RefTransfoXLLMHeadModel(RefXLConfig.from_preset('debug', **kw)).train()
+ids = torch.randint(4, 1190, (4, 32), generator=torch.Generator().manual_seed(9))
+
+def flat_grads(batch):
+    ref.zero_grad()
+    out = ref(batch, labels=batch)
+    out.loss.backward()
+    G = torch.zeros(layout.total)
+    for n, p in ref.named_parameters():
+        if n in layout.entries:
+            layout.view(G, n).copy_(p.grad)
+    return G, out.loss.item()
+
+class E: pass
+e = E(); e.cfg, e.layout = cfg, layout
+e.G, loss = flat_grads(ids[rank * 2:(rank + 1) * 2])          # this rank's shard: B = 2
+gs = GradSync(e)
+for l in reversed(range(cfg.n_layer)): gs.layer_done(l)
+gs.finish()
+g_dp = e.G / world                                            # the 1/world the fused AdamW folds in (grad_scale)
+l = torch.tensor([loss]); dist.all_reduce(l); loss_dp = l.item() / world
+g_full, loss_full = flat_grads(ids)                           # one rank, 2B = 4
+assert abs(loss_dp - loss_full) < 1e-5 * abs(loss_full), (loss_dp, loss_full)
+err = ((g_dp - g_full).norm() / g_full.norm()).item()
+assert err < 1e-5, err
+assert g_full.abs().sum() > 0
+dist.destroy_process_group()
+print('ok', err)
+'''
+
+
+def test_two_ranks_times_B_equals_one_rank_times_2B(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(_DP_EQUIV_WORKER)
+    port = str(_port(1))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)

@@ -93,3 +93,136 @@ def test_bench_rccl_path_single_rank():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['unit'] == 'tokens/s'
+
+
+def _hf_param_groups(model, wd):
+    """HF Trainer.create_optimizer: no weight decay on names containing 'bias' and on LayerNorm weights"""
+    no_decay = lambda n: 'bias' in n or 'layer_norm' in n
+    named = list(model.named_parameters())
+    return [dict(params=[p for n, p in named if not no_decay(n)], weight_decay=wd),
+            dict(params=[p for n, p in named if no_decay(n)], weight_decay=0.0)]
+
+
+@pytest.mark.parametrize('family', ['transf-xl', 'reformer'])
+def test_reference_trainer_loop_through_autograd(dev, family):
+    """The drop-in boundary: the models are nn.Modules whose parameters()/named_parameters() are fp32 views of the
+    engine's flat buffer and whose train-mode loss carries autograd, so the reference's HF-Trainer sequence
+    (train_util_wrap.py:88-144, train.py:350-367) -- loss = model(**inputs).loss; loss.backward(); clip_grad_norm_;
+    AdamW.step(); zero_grad() -- runs unchanged.  5 steps that way must match 5 steps of the fused engine path."""
+    from symbolic_music_generation_amd.trainer import get_model_n_tokenizer
+    if family == 'transf-xl':
+        mc = dict(max_length=128, mem_len=64, n_layer=2, cutoffs=[], dropout=0.0)
+        size, T_ = 'debug', 128
+    else:
+        mc = dict(max_position_embeddings=128, axial_pos_shape=(8, 16), attn_layers=['local', 'lsh'], num_hashes=1,
+                  hidden_dropout_prob=0.0, local_attention_probs_dropout_prob=0.0)
+        size, T_ = 'debug-large', 128
+    tok, ma, _ = get_model_n_tokenizer(family, size, pitch_kind='midi', model_config=mc, device=dev)
+    _, mb, _ = get_model_n_tokenizer(family, size, pitch_kind='midi', model_config=mc, device=dev)
+    assert isinstance(ma, torch.nn.Module)
+    names = [n for n, _ in ma.named_parameters()]
+    assert len(names) == len(set(names)) and sum(p.numel() for p in ma.parameters()) == ma.num_parameters()
+    assert all(p.is_cuda and p.dtype == torch.float32 and p.requires_grad for p in ma.parameters())
+    sd_keys = set(ma.state_dict().keys())
+    assert set(names) <= sd_keys
+    if family == 'transf-xl':
+        assert 'transformer.layers.1.dec_attn.qkv_net.weight' in names and 'crit.out_layers.0.weight' in sd_keys
+    else:
+        assert 'reformer.encoder.layers.1.attention.self_attention.query_key.weight' in names
+    data = torch.stack(_toy_dataset(tok, 8, T_)).to(dev)
+    labels = data.clone(); labels[labels == tok.pad_token_id] = -100
+    lr, wd = 1e-3, 1e-2
+    ma.train(); mb.train()
+    opt = torch.optim.AdamW(_hf_param_groups(ma, wd), lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    p_start = mb.engine.P.clone()
+    la, lb = [], []
+    kw = {}
+    if family == 'reformer':       # LSH rotations are drawn per step from (seed, step); the fused path advances step itself
+        g = torch.Generator().manual_seed(3)
+        rot_dim = sum(ma.engine._factors(T_)) // 2
+        kw = dict(rotations={1: torch.randn(8, 16, 1, rot_dim, generator=g)})
+    for _ in range(5):
+        out = ma(input_ids=data, labels=labels, **kw)           # reference sequence
+        assert out.loss.requires_grad
+        out.loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        la.append(out.loss.item())
+        mb.zero_grad()                                          # fused sequence
+        ob = mb(input_ids=data, labels=labels, **kw)
+        mb.backward()
+        mb.engine.optimizer_step(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, max_grad_norm=1.0)
+        lb.append(ob.loss.item())
+        assert abs(gn.item() - mb.engine.grad_norm().item()) / gn.item() < 1e-3
+    assert la[-1] < la[0]
+    assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 2e-3, (la, lb)
+    da, db = (ma.engine.P - p_start).double(), (mb.engine.P - p_start).double()
+    rel = ((da - db).norm() / db.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(da, db, dim=0).item()
+    assert rel < 2e-2 and cos > 0.9995, (rel, cos)
+    # the optimizer wrote the fp32 views in place: the next forward refreshed the bf16 operands from them
+    ma.eval()
+    with torch.no_grad():
+        ma(input_ids=data[:2])
+    assert torch.equal(ma.engine.W.float(), ma.engine.P.to(torch.bfloat16).float())
+    with pytest.raises(RuntimeError):
+        ma.half()
+
+
+_GPU_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(sys.argv[3]), 2
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=rank, world_size=world)
+from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+from symbolic_music_generation_amd.dist import GradSync
+dev = torch.device('cuda:0')
+cfg = MyTransfoXLConfig('debug', max_length=128, vocab_size=1190, n_layer=2, mem_len=64, cutoffs=[], dropout=0.0)
+ids = torch.randint(4, 1190, (4, 128), generator=torch.Generator().manual_seed(9)).to(dev)
+
+def grads(model, batch, sync):
+    model.zero_grad()
+    with torch.no_grad():
+        out = model(input_ids=batch, labels=batch)
+    model.engine.backward(layer_done=None if sync is None else sync.layer_done)
+    if sync is not None:
+        sync.finish()
+    torch.cuda.synchronize()
+    return model.engine.G.clone(), out.loss.item()
+
+m = MyTransfoXLLMHeadModel(cfg, device=dev, seed=5).train()
+g_dp, loss = grads(m, ids[rank * 2:(rank + 1) * 2], GradSync(m.engine))     # 2 ranks x B = 2, summed over the ranks
+g_dp /= world                                                               # the 1/world the fused AdamW folds in
+l = torch.tensor([loss]); dist.all_reduce(l); loss_dp = l.item() / world
+g_full, loss_full = grads(m, ids, None)                                     # 1 rank x 2B = 4
+err = ((g_dp - g_full).norm() / g_full.norm()).item()
+assert abs(loss_dp - loss_full) < 2e-3 * abs(loss_full), (loss_dp, loss_full)
+assert err < 2e-2, err              # bf16 activations: per-sequence rounding is identical, only the batch-summed atomics reorder
+# one fused optimizer step on each side keeps the replicas identical
+m.engine.G.copy_(g_dp * world)
+m.engine.optimizer_step(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / world)
+p = m.engine.P.clone(); q = p.clone()
+dist.all_reduce(q)
+assert torch.equal(q, p * world) or ((q - p * world).abs().max().item() < 1e-6)
+dist.destroy_process_group()
+print('ok', err)
+'''
+
+
+def test_two_gpu_ranks_times_B_equals_one_rank_times_2B(dev, tmp_path):
+    """world-size-2 data parallelism with the real HIP engine (two processes sharing this GPU, gloo transport -- RCCL refuses
+    two ranks on one device): per-layer bucketed all-reduce during the backward, gradients and loss equal the 2B single-rank
+    step, replicas stay identical after the fused optimizer step."""
+    import socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    script = tmp_path / 'w.py'
+    script.write_text(_GPU_DP_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)
