@@ -47,9 +47,12 @@ def test_device_batcher_shards_and_shuffles(tmp_path):
         rows = np.concatenate([ids.cpu().numpy() for ids, _ in db])
         seen.append(rows[:, 0] - 2)
     both = np.concatenate(seen)
-    assert sorted(both.tolist()) == list(range(37))             # the two ranks partition the corpus
+    # 37 rows over 2 ranks: like DistributedSampler the shuffled order is padded by wrapping around (one repeated row) so that
+    # both ranks yield the same number of rows -- and therefore of training steps / gradient all-reduces
+    assert sorted(set(both.tolist())) == list(range(37)) and len(both) == 38 and len(seen[0]) == len(seen[1]) == 19
     assert seen[0].tolist() != sorted(seen[0].tolist())         # shuffled
     order = np.arange(37); np.random.default_rng(3).shuffle(order)
+    order = np.concatenate([order, order[:1]])
     assert seen[0].tolist() == order[0::2].tolist() and seen[1].tolist() == order[1::2].tolist()
 
 
