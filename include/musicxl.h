@@ -143,6 +143,11 @@ int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* b
                          void* stream);
 /* out[n] += sum_m X[m][n]  (bias gradients), X (M,N) bf16 with leading dimension ld */
 int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream);
+/* Y[m][n] = X[m][n] - mean_m X[m][n]  (bf16 in / out, fp32 arithmetic; N % 8 == 0).  The positional table enters the r_net
+ * weight gradient dW_r = sum_d dRd[d]^T phi[d] centred over the distance axis: sum_d dRd[d] = 0 exactly (every softmax row's
+ * score gradients sum to zero and every query sees exactly mem_len distances), so the constant part of phi multiplies nothing
+ * but the bf16 rounding noise of the score gradients -- which would otherwise dominate the low-frequency columns. */
+int mxl_center_columns_bf16(const void* X, void* Y, int M, int N, void* stream);
 /* upstream TransfoXLModel._update_mems: out[b] = cat(mem[b], hid[b])[-M:], all (B, len, d) bf16, out != mem */
 int mxl_mem_update(const void* mem, const void* hid, void* out, int B, int M, int T, int d, void* stream);
 
@@ -175,9 +180,6 @@ int mxl_adamw_step(float* p, const float* g, float* m, float* v, void* w16, long
                    float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
                    float max_norm, float grad_scale, void* stream);
 int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
-/* x = hi + lo, hi = bf16(x), lo = bf16(x - hi): operand pair that keeps 16 mantissa bits through a bf16 MFMA contraction
- * (used for dW_r = dRd^T phi, the gradient of upstream's r_net: its fp32 partial sums dRd must not be rounded to 8 bits). */
-int mxl_split_f32_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream);
 /* dst[b][c][r] = src[b][r][c] (bf16; element strides between batch items).  Keeps [in][out] copies of the Linear weights so
  * that the input gradient dX = dY W (autograd of F.linear) runs in the K-contiguous GEMM form. */
 int mxl_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, int batch,

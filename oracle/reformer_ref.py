@@ -213,7 +213,7 @@ class RefReformer:
             out, _ = chunked_attention(q, k, v, pos, c.chunk_length, self_mask=False)
         return self._merge(out)
 
-    def lsh_attn(self, l, h, rotations):
+    def lsh_attn(self, l, h, rotations, buckets=None):
         c, p = self.c, self.p
         pre = f'reformer.encoder.layers.{l}.attention.self_attention.'
         qk = self._split(h @ p[pre + 'query_key.weight'].t())
@@ -228,8 +228,11 @@ class RefReformer:
             return self._merge(torch.softmax(dots, -1) @ v)
         if self.num_buckets is None:
             self.num_buckets = auto_num_buckets(T, c.chunk_length, c.max_position_embeddings)
-        n_h = rotations.shape[2]
-        buckets = lsh_buckets(qk, rotations, self.num_buckets)                       # (B,H,n_h*T)
+        if buckets is None:
+            buckets = lsh_buckets(qk, rotations, self.num_buckets)                   # (B,H,n_h*T)
+        else:            # HF's LSHSelfAttention.forward takes ready-made `buckets` too (HF515:466-476): hashing is skipped
+            buckets = buckets.view(B, H, -1).long()
+        n_h = buckets.shape[-1] // T
         self.last_buckets[l] = buckets
         S = n_h * T
         scaled = S * buckets + (torch.arange(S).view(1, 1, -1) % S)                  # HF515:151-157
@@ -255,7 +258,8 @@ class RefReformer:
         rot = nb if isinstance(nb, int) else sum(nb)
         return (c.num_attention_heads, c.attention_head_size, c.num_hashes, rot // 2)
 
-    def forward(self, ids, rotations: Optional[Dict[int, torch.Tensor]] = None, labels=None):
+    def forward(self, ids, rotations: Optional[Dict[int, torch.Tensor]] = None, labels=None,
+                buckets: Optional[Dict[int, torch.Tensor]] = None):
         """ids (B,T); rotations: {layer index -> (H, dh, n_h, rot/2)} for every LSH layer (explicit input: HF draws them
         from the global RNG inside each layer, HF515:723-731).  Eval-mode semantics (no dropout)."""
         c, p = self.c, self.p
@@ -265,7 +269,7 @@ class RefReformer:
         for l, kind in enumerate(c.attn_layers):
             pre = f'reformer.encoder.layers.{l}.'
             h = F.layer_norm(x2, (d,), p[pre + 'attention.layer_norm.weight'], p[pre + 'attention.layer_norm.bias'], c.layer_norm_eps)
-            a = self.local_attn(l, h) if kind == 'local' else self.lsh_attn(l, h, (rotations or {}).get(l))
+            a = self.local_attn(l, h) if kind == 'local' else self.lsh_attn(l, h, (rotations or {}).get(l), (buckets or {}).get(l))
             y1 = x1 + a @ p[pre + 'attention.output.dense.weight'].t()
             h2 = F.layer_norm(y1, (d,), p[pre + 'feed_forward.layer_norm.weight'], p[pre + 'feed_forward.layer_norm.bias'], c.layer_norm_eps)
             f = torch.relu(h2 @ p[pre + 'feed_forward.dense.dense.weight'].t() + p[pre + 'feed_forward.dense.dense.bias'])

@@ -424,7 +424,46 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* src, 
         if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * ld_dst + r0 + tx] = t[tx][i];
 }
 
+// Y = X - column means: one workgroup per 8 columns (16-byte row pieces), 256 threads stride the rows, fp32 sums through LDS
+__global__ __launch_bounds__(256) void center_columns_kernel(const bf16_t* X, bf16_t* Y, int M, int N) {
+    __shared__ float part[256][8];
+    const int c0 = blockIdx.x * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)m * N + c0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] += bf2f((bf16_t)v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) part[threadIdx.x][j] = s[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int j = 0; j < 8; j++) part[threadIdx.x][j] += part[threadIdx.x + o][j];
+        __syncthreads();
+    }
+    float mean[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) mean[j] = part[0][j] / (float)M;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)m * N + c0);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = bf2f((bf16_t)v[j]) - mean[j];
+        const u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(Y + (size_t)m * N + c0) = w;
+    }
+}
+
 }  // namespace
+
+extern "C" int mxl_center_columns_bf16(const void* X, void* Y, int M, int N, void* stream) {
+    MXL_CHECK_ARG(X && Y && M > 0 && N > 0 && (N % 8) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0);
+    hipLaunchKernelGGL(center_columns_kernel, dim3(N / 8), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (bf16_t*)Y, M, N);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
 
 extern "C" int mxl_dropout_bf16(const void* x, void* y, long long n, float drop_p, unsigned long long seed, unsigned site,
                                 void* stream) {

@@ -53,17 +53,6 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, bf16_t* y, lo
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = f2bf(x[i]);
 }
 
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): a 16-bit-mantissa operand pair for contractions whose fp32 partial sums
-// must not be rounded to 8 bits before they are summed again (the r_net weight gradient, dW_r = dRd^T phi)
-__global__ __launch_bounds__(256) void split_kernel(const float* x, bf16_t* hi, bf16_t* lo, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float v = x[i];
-        const bf16_t h = f2bf(v);
-        hi[i] = h;
-        lo[i] = f2bf(v - bf2f(h));
-    }
-}
-
 inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -96,13 +85,6 @@ extern "C" int mxl_adamw_step(float* p, const float* g, float* m, float* v, void
 extern "C" int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
     MXL_CHECK_ARG(x && y && n > 0);
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
-    MXL_LAUNCH_CHECK();
-    return MXL_OK;
-}
-
-extern "C" int mxl_split_f32_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream) {
-    MXL_CHECK_ARG(x && hi && lo && n > 0);
-    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

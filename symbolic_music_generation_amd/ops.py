@@ -233,9 +233,11 @@ def cast_bf16(x: torch.Tensor, y: torch.Tensor):
     return y
 
 
-def split_bf16(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor):
-    check(lib().mxl_split_f32_bf16x2(_p(x), _p(hi), _p(lo), x.numel(), _stream()), 'mxl_split_f32_bf16x2')
-    return hi, lo
+def center_columns(x: torch.Tensor, y: torch.Tensor):
+    """y = x - mean over rows (bf16, (M, N))"""
+    M, N = x.shape
+    check(lib().mxl_center_columns_bf16(_p(x), _p(y), M, N, _stream()), 'mxl_center_columns_bf16')
+    return y
 
 
 def transpose(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, *, ld_src=None, ld_dst=None, batch=1,

@@ -113,6 +113,7 @@ class RFEngine:
         self._sumsq = torch.zeros(1, device=self.dev)
         self.num_buckets = cfg.num_buckets
         self.last_buckets: Dict[int, torch.Tensor] = {}
+        self.keep_buckets = False          # also keep the bucket ids of train-mode forwards (parity tests)
         self.init_weights(seed)
 
     # ---- params (same interface as XLEngine)
@@ -321,7 +322,7 @@ class RFEngine:
                         rot = torch.randn(H, dh, n_h, sum(factors) // 2, device=self.dev, generator=g)
                     ws.rot[l] = rot
                     ops.lsh_hash(qkv, bs, rs, rot, ws.buckets, B, T, H, dh, n_h, factors)
-                self.last_buckets[l] = ws.buckets.clone() if not train else None
+                self.last_buckets[l] = ws.buckets.clone() if (not train or self.keep_buckets) else None
                 ops.lsh_sort(ws.buckets, ws.sidx, ws.spos[s], B * H, n_h * T, T, NB * n_h)
                 tgt = ws.av[s] if n_h == 1 else ws.out_r[s]
                 ops.chunk_attn_fwd(qkv, qkv, qkv[:, d:], ws.spos[s], tgt, ws.lse[s], B, T, H, dh, n_h, 1, bs, rs,

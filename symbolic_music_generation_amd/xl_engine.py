@@ -233,7 +233,7 @@ class XLEngine:
             ws.qr = torch.empty(B, T, d, **bf)
             ws.d_rd = torch.empty(M, d, **f32)
             ws.d_rd16 = torch.empty(M, d, **bf)
-            ws.d_rd16lo = torch.empty(M, d, **bf)
+            ws.phi_c = torch.empty(M, d, **bf)
             ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
         ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32)
         ws.nll = torch.empty(B, max(T - 1, 1), **f32)
@@ -391,6 +391,10 @@ class XLEngine:
             ops.dropout(dy, dy, p, seed=seed, site=self.SITE_FINAL)
         st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
                   o_bs=T * d, o_rs=d)
+        # r_net's weight gradient uses the positional table centred over the distance axis: sum_d dRd[d] is exactly zero (the
+        # score gradients of a softmax row sum to zero, and every query sees exactly M distances), so the constant part of phi
+        # only ever multiplies the bf16 rounding noise of dG; see mxl_center_columns_bf16
+        ops.center_columns(ws.phi, ws.phi_c)
         for l in reversed(range(L)):
             h_in = ws.h[l]
             # LN2 backward: dres -> dC (into h1 via residual), dx -> dD (into f_out)
@@ -425,12 +429,9 @@ class XLEngine:
                             ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
                             dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr, **st)
             # r_net: dW_r = d_rd^T . phi
-            # dRd rows are fp32 sums over every (sequence, query); many of them meet again in this contraction (all distances past
-            # clamp_len share one phi row), so they enter as a (hi, lo) bf16 pair: 16 mantissa bits at the cost of a second tiny GEMM
-            ops.split_bf16(ws.d_rd, ws.d_rd16, ws.d_rd16lo)
-            for part in (ws.d_rd16, ws.d_rd16lo):
-                ops.gemm(part, ws.phi, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
-                         ksplits=self._ks(d, d))
+            ops.cast_bf16(ws.d_rd, ws.d_rd16)
+            ops.gemm(ws.d_rd16, ws.phi_c, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(d, d))
             # qkv_net
             if ws.has_mem:
                 dqkv[:, :M, :d].zero_()   # memory rows carry no query gradient

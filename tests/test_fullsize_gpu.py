@@ -246,9 +246,19 @@ def test_reformer_model_properties_at_c4(dev):
 
 # ----------------------------------------------------------------------------------------------------------------------
 # Full-size comparisons with the CPU oracle (oracle/transfoxl_ref.py run on the host): BASELINE.json configs[1] = SURVEY C2,
-# configs[2] = C3 and configs[4] = C5.  Weights 3x the reference init (non-trivial attention), dropout 0, B = 1 on the oracle side.
+# configs[2] = C3 and configs[4] = C5; dropout 0, B = 1 on the oracle side.
+#
+# Tolerances (measured with scripts/diag_fullsize_error.py, which also prints the per-layer hidden-state error):
+#  * at the reference's own init scale (`_init_weights`, std 0.02: the scale bench.py runs) the HIP log-probs differ from the fp32
+#    oracle by max 0.024 (C2) / 0.033 (C3), mean 0.003 / 0.005, loss by < 1e-5 relative, arg-max identical everywhere;
+#  * the SAME fp32 oracle with only its module outputs rounded to bf16 (fp32 arithmetic, bf16 storage between operators --
+#    the precision class of the HIP path, which additionally rounds the MFMA operands q + bias, P and the attention output)
+#    differs from itself by max 0.016 / 0.026, mean 0.0024 / 0.0037: the HIP path sits at 1.3-1.45x that envelope at every
+#    quantile and every layer;
+#  * at 3x the init scale a 12-layer model is chaotic in bf16 (envelope itself: mean 0.033, max 0.92 at C3), so the 3x stress
+#    case is asserted at C2 only and RELATIVE to the envelope measured in the same test.
 # ----------------------------------------------------------------------------------------------------------------------
-def _oracle_pair(dev, preset, n_layer, T_, M_, seed):
+def _oracle_pair(dev, preset, n_layer, T_, M_, seed, wscale=1.0):
     from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
     torch.manual_seed(seed)
@@ -257,15 +267,35 @@ def _oracle_pair(dev, preset, n_layer, T_, M_, seed):
     with torch.no_grad():
         for n, p in ref.named_parameters():
             if p.dim() > 1 and 'layer_norm' not in n:
-                p.mul_(3.0)
+                p.mul_(wscale)
             p.copy_(p.to(torch.bfloat16).float())          # bf16-representable: both sides hold the same weights
     m = MyTransfoXLLMHeadModel(MyTransfoXLConfig(preset, **kw), device=dev)
     m.load_state_dict(ref.state_dict())
     return ref.eval(), m.eval()
 
 
-def _fwd_vs_oracle(dev, preset, n_layer, T_, M_, seed, tol_abs):
-    ref, m = _oracle_pair(dev, preset, n_layer, T_, M_, seed)
+def _bf16_storage_forward(ref, ids, lab):
+    """the fp32 oracle with every module output (Linear, LayerNorm, Embedding, positional table) rounded to bf16 as it is written"""
+    from torch import nn
+    from oracle import transfoxl_ref as R
+    kinds = (nn.Linear, nn.LayerNorm, nn.Embedding, R.PositionalEmbedding)
+    rnd = lambda mod, inp, out: out.to(torch.bfloat16).float() if torch.is_tensor(out) else out
+    hooks = [mod.register_forward_hook(rnd) for mod in ref.modules() if isinstance(mod, kinds)]
+    try:
+        with torch.no_grad():
+            return ref(ids, labels=lab)
+    finally:
+        for h in hooks:
+            h.remove()
+
+
+def _quant(x, k):
+    s = x.flatten().sort().values
+    return s[min(int(k * s.numel()), s.numel() - 1)].item()
+
+
+def _fwd_vs_oracle(dev, preset, n_layer, T_, M_, seed, wscale, tol_max, tol_p999, tol_mean, envelope=None):
+    ref, m = _oracle_pair(dev, preset, n_layer, T_, M_, seed, wscale)
     g = torch.Generator().manual_seed(seed + 1)
     ids = torch.randint(4, V, (1, T_), generator=g)
     lab = ids.clone(); lab[0, T_ - 100:] = -100                   # a padded tail, as the collator produces
@@ -273,27 +303,39 @@ def _fwd_vs_oracle(dev, preset, n_layer, T_, M_, seed, tol_abs):
         ro = ref(ids, labels=lab)
         o = m(input_ids=ids.to(dev), labels=lab.to(dev))
     lp, rlp = o.prediction_scores.float().cpu(), ro.prediction_scores
-    err = (lp - rlp).abs()
-    print(f'{preset} {n_layer}L T={T_}: max |dlogp| {err.max().item():.4f} mean {err.mean().item():.5f} '
-          f'loss {o.loss.item():.5f} vs {ro.loss.item():.5f}')
     assert lp.shape == rlp.shape == (1, T_, V)
-    assert err.max().item() < tol_abs                             # log-probs, bf16 activations through n_layer layers
-    assert err.mean().item() < 5e-3
-    assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-2
+    err = (lp - rlp).abs()
+    e_max, e_999, e_mean = err.max().item(), _quant(err, 0.999), err.mean().item()
+    print(f'{preset} {n_layer}L T={T_} x{wscale}: |dlogp| max {e_max:.4f} p99.9 {e_999:.4f} mean {e_mean:.5f}; '
+          f'loss {o.loss.item():.5f} vs {ro.loss.item():.5f}')
+    if envelope is not None:        # relative to the bf16-storage form of the same oracle on the same inputs
+        env = (_bf16_storage_forward(ref, ids, lab).prediction_scores - rlp).abs()
+        v_999, v_mean = _quant(env, 0.999), env.mean().item()
+        print(f'   bf16-storage envelope of the oracle itself: max {env.max().item():.4f} p99.9 {v_999:.4f} mean {v_mean:.5f}')
+        assert e_mean < envelope * v_mean and e_999 < envelope * v_999
+        # hidden states per layer (the mems are the layer inputs): same ratio, no layer stands out
+        for l in range(1, n_layer):
+            hr = ro.mems[l][:, 0]
+            rel = ((o.mems[l][:, 0].float().cpu() - hr).norm() / hr.norm()).item()
+            assert rel < 2.5e-2, (l, rel)
+    assert e_max < tol_max and e_999 < tol_p999 and e_mean < tol_mean
+    assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < (1e-3 if wscale == 1.0 else 1e-2)
     a, b = o.losses.float().cpu().flatten().sort().values, ro.losses.flatten().sort().values
-    assert (a - b).abs().max().item() < tol_abs
-    # argmax agreement wherever the oracle's top-2 margin exceeds twice the tolerance
+    assert (a - b).abs().max().item() < tol_max
+    # arg-max agreement wherever the oracle's top-2 margin exceeds twice the p99.9 tolerance
     top2 = rlp.topk(2, -1).values
-    clear = (top2[..., 0] - top2[..., 1]) > 2 * tol_abs
-    assert (lp.argmax(-1) == rlp.argmax(-1))[clear].all() and clear.float().mean().item() > 0.3
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * tol_p999
+    assert (lp.argmax(-1) == rlp.argmax(-1))[clear].all() and clear.float().mean().item() > 0.2
     return m
 
 
 def test_c2_forward_vs_oracle(dev):
-    """6L / 512d / H8, T = M = 1024 -- HIP log-probs, per-token NLLs and loss vs the fp32 oracle; then the C3-style
-    properties at this shape (normalisation, causality, batch equivariance, segmentation invariance)"""
+    """6L / 512d / H8, T = M = 1024 -- HIP log-probs, per-token NLLs and loss vs the fp32 oracle at the reference's
+    init scale (absolute tolerances) and at 3x that scale (relative to the bf16-storage envelope); then the C3-style properties at
+    this shape (normalisation, causality, batch equivariance, segmentation invariance)"""
     T2 = 1024
-    m = _fwd_vs_oracle(dev, 'small', 6, T2, T2, seed=21, tol_abs=3e-2)
+    _fwd_vs_oracle(dev, 'small', 6, T2, T2, seed=21, wscale=1.0, tol_max=4e-2, tol_p999=2.5e-2, tol_mean=6e-3)
+    m = _fwd_vs_oracle(dev, 'small', 6, T2, T2, seed=21, wscale=3.0, tol_max=2e-1, tol_p999=8e-2, tol_mean=1.6e-2, envelope=1.6)
     torch.manual_seed(2)
     ids = torch.randint(4, V, (3, T2), device=dev)
     lp = m(input_ids=ids).prediction_scores.float()
@@ -305,23 +347,25 @@ def test_c2_forward_vs_oracle(dev):
     assert torch.equal(m(input_ids=ids.flip(0)).prediction_scores.float().flip(0), lp)
     o1 = m(input_ids=ids[:, :512]); o2 = m(input_ids=ids[:, 512:], mems=o1.mems)
     seg = torch.cat([o1.prediction_scores, o2.prediction_scores], 1).float()
-    assert (seg - lp).abs().max().item() < 6e-2 and (seg - lp).abs().mean().item() < 1e-2
+    assert (seg - lp).abs().max().item() < 1e-1 and (seg - lp).abs().mean().item() < 1e-2
 
 
 def test_c3_forward_vs_oracle(dev):
-    """SURVEY C3 (the headline config): 12L / 768d / H12, T = M = 2048, B = 1 -- HIP forward vs the fp32 oracle"""
-    _fwd_vs_oracle(dev, 'base', 12, T, M, seed=23, tol_abs=4e-2)
+    """SURVEY C3 (the headline config): 12L / 768d / H12, T = M = 2048, B = 1, the reference's init scale -- HIP forward vs the
+    fp32 oracle (absolute tolerances; the 3x stress scale is asserted at C2, see the comment block above)"""
+    _fwd_vs_oracle(dev, 'base', 12, T, M, seed=23, wscale=1.0, tol_max=5e-2, tol_p999=3e-2, tol_mean=8e-3)
 
 
 def test_c5_decode_batch64_ring_wrap(dev):
     """12L / 768d, M = 2048, B = 64 prompts x 256 tokens, greedy, one hipGraph replay per token, 1920 generated tokens
-    (positions up to 2176: the K/V rings wrap at 2048).  (i) every generated token is the arg-max of the step's own log-probs;
-    (ii) teacher-forcing the decoded ids through one-shot HIP forwards (two 1088-token segments with carried mems) reproduces
-    the per-step log-probs (segmentation invariance at size: max |dlogp| < 5e-2) and the greedy choice wherever the one-shot
-    top-2 margin is clear; (iii) two of the rows against the CPU oracle's HF-style greedy loop for the first 32 tokens."""
+    (positions up to 2176: the K/V rings wrap at 2048), reference init scale.  (i) every generated token is the arg-max of the
+    step's own log-probs; (ii) teacher-forcing the decoded ids through one-shot HIP forwards (two 1088-token segments with
+    carried mems) reproduces the per-step log-probs (segmentation invariance at size: max |dlogp| < 5e-2) and the greedy choice
+    wherever the one-shot top-2 margin is clear; (iii) two of the rows against the CPU oracle's HF-style greedy loop for the
+    first 32 tokens (token for token; a fork is accepted only at a near-tie of the oracle's own log-probs)."""
     from symbolic_music_generation_amd.generate import XLDecoder
     B, Tp, TOT = 64, 256, 2176
-    ref, m = _oracle_pair(dev, 'base', 12, 2048, 2048, seed=29)
+    ref, m = _oracle_pair(dev, 'base', 12, 2048, 2048, seed=29, wscale=1.0)
     g = torch.Generator().manual_seed(31)
     prompt = torch.randint(4, V, (B, Tp), generator=g)
     dec = XLDecoder(m.engine, B, TOT, seed=1)
@@ -341,19 +385,22 @@ def test_c5_decode_batch64_ring_wrap(dev):
         lp2 = o2.prediction_scores[:, :TOT - 1 - 1088].float()
     one = torch.cat([lp1, lp2], 1)
     err = (one - tr).abs()
-    print(f'C5 decode vs one-shot: max |dlogp| {err.max().item():.4f} mean {err.mean().item():.5f}')
-    assert err.max().item() < 5e-2
+    post = err[:, 2048 - Tp:]                                       # steps taken after the rings wrapped
+    print(f'C5 decode vs one-shot: max |dlogp| {err.max().item():.4f} mean {err.mean().item():.5f}; after the wrap: max '
+          f'{post.max().item():.4f} mean {post.mean().item():.5f}')
+    assert err.max().item() < 5e-2 and err.mean().item() < 5e-3
     top2 = one.topk(2, -1).values
-    clear = (top2[..., 0] - top2[..., 1]) > 0.1
+    clear = (top2[..., 0] - top2[..., 1]) > 5e-2
     agree = one.argmax(-1) == ids[:, Tp:]
     assert agree[clear].all() and agree.float().mean().item() > 0.97, agree.float().mean().item()
-    # the wrap really happened and the post-wrap steps are covered by the comparison
-    assert int(dec.t_dev.item()) >= 2048 + 100
+    assert int(dec.t_dev.item()) >= 2048 + 100                      # the wrap really happened
     # (iii) oracle greedy loop (HF style: prompt, then one token at a time with carried mems) on two rows
     rows = [0, B - 1]
     want = ref.greedy_generate(prompt[rows], max_length=Tp + 32)
     got = ids[rows, :Tp + 32].cpu()
     mism = (got != want).nonzero()
+    print(f'C5 greedy vs oracle: {int((got == want)[:, Tp:].sum())} of {2 * 32} generated tokens identical'
+          + (f', first fork at {mism[0].tolist()}' if mism.numel() else ''))
     if mism.numel():            # a fork is legitimate only at a bf16 near-tie of the oracle's own log-probs
         r0, t0 = mism[0].tolist()
         with torch.no_grad():

@@ -52,13 +52,17 @@ def test_train_step_gradients_vs_oracle(dev):
     ref = RefReformer(cfg, sd)
     ref.num_buckets = blob['num_buckets']
     ids, labels = blob['ids'], blob['labels']
+    m.engine.keep_buckets = True
     m.zero_grad()
     out = m(input_ids=ids.to(dev), labels=labels.to(dev), rotations=blob['rotations'])
     m.backward()
     torch.cuda.synchronize()
-    # oracle with the SAME bucket assignment the HIP path used
-    bk = {l: m.engine._last.buckets.clone() for l in ()}
-    logits, loss = ref.forward(ids, rotations=blob['rotations'], labels=labels)
+    # the oracle with the SAME bucket assignment the HIP path used (HF's LSH attention takes ready-made `buckets` as well): a
+    # bucket is an arg-max over bf16 activations, and one flipped token reroutes its attention -- a discrete difference that is
+    # not a property of the gradient kernels (agreement with HF's own bucket ids is asserted in test_forward_vs_hf_golden)
+    bk = {l: b.cpu() for l, b in m.engine.last_buckets.items() if b is not None}
+    assert len(bk) == sum(k == 'lsh' for k in cfg.attn_layers)
+    logits, loss = ref.forward(ids, rotations=blob['rotations'], labels=labels, buckets=bk)
     loss.backward()
     assert abs(out.loss.item() - loss.item()) / loss.item() < 2e-2
     bad = {}
@@ -66,7 +70,7 @@ def test_train_step_gradients_vs_oracle(dev):
         g = m.engine.g32(k).float().cpu().reshape(v.shape)
         e = ((g - v.grad).norm() / (v.grad.norm() + 1e-12)).item()
         cos = torch.nn.functional.cosine_similarity(g.flatten(), v.grad.flatten(), dim=0).item()
-        if e > 0.12 or cos < 0.99:
+        if e > 0.06 or cos < 0.998:
             bad[k] = (round(e, 3), round(cos, 4))
     assert not bad, bad
 
