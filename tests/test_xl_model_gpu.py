@@ -138,7 +138,7 @@ def test_loss_decreases(dev):
     assert last < 0.6 * first, (first, last)
 
 
-MOVE_REL, MOVE_COS = 0.06, 0.998          # r_net.weight: 0.35 / 0.94 (see the test's docstring)
+MOVE_REL, MOVE_COS = 0.06, 0.998          # r_net.weight: 0.20 / 0.98 (see the test's docstring)
 
 
 def test_training_trajectory_matches_oracle_optimisation(dev):
@@ -148,9 +148,13 @@ def test_training_trajectory_matches_oracle_optimisation(dev):
     token stream (BASELINE configs[0]: "8 tokenized MIDI pieces").  The oracle side is its fp32 autograd model under
     torch.optim.AdamW / clip_grad_norm_; the HIP side is one flat buffer with the fused clip + AdamW kernels.  Loss per step
     within 1.5e-2 relative; per parameter tensor the movement (trained - start) within MOVE_REL relative (Frobenius) and cosine
-    >= MOVE_COS of the oracle's (measured: 0.3-3 % / >= 0.9995 everywhere except r_net.weight, 24-27 % / 0.964-0.971: its
-    gradient comes through the bf16 dG round trip of the attention backward, whose per-element noise is the size of
-    that matrix's smallest gradient entries, and Adam's normalisation turns those into full-size update differences)."""
+    >= MOVE_COS of the oracle's (measured: 0.3-3 % / >= 0.9995 everywhere except r_net.weight, 12-18 % / 0.984-0.993.  That
+    gradient is a cancellation residue: the score gradients of a softmax row sum to zero and every query sees exactly mem_len
+    distances, so sum_d dRd[d] = 0 exactly and only the VARIATION of the positional table over the distance axis carries
+    signal -- with clamp_len = 64 of 256 distances here, three quarters of the rows are one and the same vector.  The engine
+    therefore contracts dRd with the table centred over d (mxl_center_columns_bf16: 24-27 % before, 12-18 % after); what is
+    left is the bf16 rounding of the score gradients themselves, which Adam's normalisation turns into full-size update
+    differences on the entries whose gradient is at that noise level)."""
     import math
     import os
     import numpy as np
@@ -201,7 +205,7 @@ def test_training_trajectory_matches_oracle_optimisation(dev):
         cos = torch.nn.functional.cosine_similarity(dg, dr, dim=0).item()
         stats[n] = (round(e, 4), round(cos, 5))
     print('movement (rel err, cosine):', stats)
-    lim = lambda k: (0.35, 0.94) if k.endswith('r_net.weight') else (MOVE_REL, MOVE_COS)
+    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (MOVE_REL, MOVE_COS)
     bad = {k: v for k, v in stats.items() if v[0] > lim(k)[0] or v[1] < lim(k)[1]}
     assert not bad, f'parameter movement differs from the oracle optimiser: {bad}'
 
