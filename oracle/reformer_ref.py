@@ -129,8 +129,10 @@ def _look_back(x, n_chunks_dim=2):
     return torch.cat([prev, x], dim=3)
 
 
-def lsh_buckets(qk, rotations, num_buckets):
-    """qk (B,H,T,dh), rotations (H, dh, n_h, rot/2) -> offset bucket ids (B,H,n_h*T)   (HF515:698-770, no padding mask)"""
+def lsh_buckets(qk, rotations, num_buckets, pad_mask=None, increase_num_buckets=False):
+    """qk (B,H,T,dh), rotations (H, dh, n_h, rot/2) -> offset bucket ids (B,H,n_h*T)   (HF515:698-770).  `pad_mask` (B,T) bool,
+    True = real token: when any token is padding, pads go to ONE extra bucket and the per-round offsets use num_buckets + 1
+    (HF515:746-756); `increase_num_buckets` widens the offsets the same way for a query hashed against such a cache."""
     rot = torch.einsum('bmtd,mdhr->bmhtr', qk.detach(), rotations)
     n_h = rotations.shape[2]
     if isinstance(num_buckets, int):
@@ -146,6 +148,11 @@ def lsh_buckets(qk, rotations, num_buckets):
             buckets = a if buckets is None else buckets + cur_prod * a
             cur_prod *= f
         nb = cur_prod
+    if pad_mask is not None and not bool(pad_mask.all()):
+        nb += 1
+        buckets = torch.where(pad_mask[:, None, None, :].expand_as(buckets), buckets, torch.tensor(nb - 1))
+    elif increase_num_buckets:
+        nb += 1
     offsets = (torch.arange(n_h) * nb).view(1, 1, -1, 1)
     return (buckets + offsets).flatten(2, 3)
 
@@ -213,7 +220,7 @@ class RefReformer:
             out, _ = chunked_attention(q, k, v, pos, c.chunk_length, self_mask=False)
         return self._merge(out)
 
-    def lsh_attn(self, l, h, rotations, buckets=None):
+    def lsh_attn(self, l, h, rotations, buckets=None, pad_mask=None):
         c, p = self.c, self.p
         pre = f'reformer.encoder.layers.{l}.attention.self_attention.'
         qk = self._split(h @ p[pre + 'query_key.weight'].t())
@@ -229,7 +236,7 @@ class RefReformer:
         if self.num_buckets is None:
             self.num_buckets = auto_num_buckets(T, c.chunk_length, c.max_position_embeddings)
         if buckets is None:
-            buckets = lsh_buckets(qk, rotations, self.num_buckets)                   # (B,H,n_h*T)
+            buckets = lsh_buckets(qk, rotations, self.num_buckets, pad_mask)         # (B,H,n_h*T)
         else:            # HF's LSHSelfAttention.forward takes ready-made `buckets` too (HF515:466-476): hashing is skipped
             buckets = buckets.view(B, H, -1).long()
         n_h = buckets.shape[-1] // T
@@ -282,3 +289,165 @@ class RefReformer:
         if labels is not None:
             loss = F.cross_entropy(logits[:, :-1].reshape(-1, c.vocab_size), labels[:, 1:].reshape(-1), ignore_index=-100)
         return logits, loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Cached (incremental) decoding: `model.generate(...)` as musicnlp/trainer/eval.py:333 drives it runs HF's `use_cache` path --
+# ReformerDynamicCache (HF515:65-148): per layer the LayerNorm'ed attention inputs of every position, plus, for LSH layers, the
+# offset bucket ids (B, H, n_h, n).  A step feeds ONE token:
+#   local layer (HF515:1136-1169, 1327-1329): keys / values = positions ((n // 64) - 1) * 64 .. n of the cache + the new token, no mask
+#   LSH layer, fewer than 64 cached buckets (HF515:513-517, 840-845): standard attention of the query over all positions, self mask
+#     only; once 64 positions exist ALL of them are hashed and the buckets enter the cache (HF515:532-534)
+#   LSH layer with cached buckets (HF515:482-511, 946-1050): hash the query, stable-sort (cached buckets ; new bucket) per hash
+#     round, take the 64-slot chunk that holds the new token and the chunk before it (indices modulo the list length), attend to
+#     the hidden states at those positions (projected afresh; no causal mask -- every one of them is in the past -- self mask
+#     -1e5 on the token itself), combine the rounds by their logsumexp weights.
+# Rotations are an explicit input here ({layer: (H, dh, n_h, rot/2)}), i.e. HF with `config.hash_seed` set: the same rotations at
+# every call.  (With hash_seed=None, the reference's setting, HF redraws them at every forward.)
+# ---------------------------------------------------------------------------------------------------------------------------
+class RefReformerCache:
+    def __init__(self):
+        self.states: List[torch.Tensor] = []          # per layer (B, n, d): LayerNorm(x2) of every position so far
+        self.buckets: List[Optional[torch.Tensor]] = []   # per layer (B, H, n_h, n) or None
+
+
+def _stable_argsort(v):
+    n = v.shape[-1]
+    return torch.argsort(n * v + (torch.arange(n) % n).view(*([1] * (v.dim() - 1)), n), dim=-1)   # HF515:151-157
+
+
+def _rf_prefill(self, ids, rotations):
+    """whole prompt with use_cache (HF515:2012-2040, 1380-1425): padded to a multiple of 64 when longer than one chunk (pads
+    hash to an extra bucket); returns logits of the real positions and the cache"""
+    c, p = self.c, self.p
+    d = c.hidden_size
+    B, Tp = ids.shape
+    pad_mask = None
+    if Tp > c.chunk_length and Tp % c.chunk_length:
+        padn = c.chunk_length - Tp % c.chunk_length
+        ids = torch.cat([ids, torch.full((B, padn), c.pad_token_id, dtype=ids.dtype)], 1)
+        pad_mask = torch.arange(Tp + padn).view(1, -1).expand(B, -1) < Tp
+    cache = RefReformerCache()
+    x = self.embed(ids)
+    x1, x2 = x, x
+    for l, kind in enumerate(c.attn_layers):
+        pre = f'reformer.encoder.layers.{l}.'
+        h = F.layer_norm(x2, (d,), p[pre + 'attention.layer_norm.weight'], p[pre + 'attention.layer_norm.bias'], c.layer_norm_eps)
+        if kind == 'local':
+            a = self.local_attn(l, h)
+            cache.buckets.append(None)
+        else:
+            a = self.lsh_attn(l, h, (rotations or {}).get(l), pad_mask=pad_mask)
+            bk = None
+            if ids.shape[1] > c.chunk_length:
+                H = c.num_attention_heads
+                bk = self.last_buckets[l].view(B, H, -1, ids.shape[1])[..., :Tp].clone()
+            cache.buckets.append(bk)
+        cache.states.append(h[:, :Tp])
+        y1 = x1 + a @ p[pre + 'attention.output.dense.weight'].t()
+        h2 = F.layer_norm(y1, (d,), p[pre + 'feed_forward.layer_norm.weight'], p[pre + 'feed_forward.layer_norm.bias'], c.layer_norm_eps)
+        f = torch.relu(h2 @ p[pre + 'feed_forward.dense.dense.weight'].t() + p[pre + 'feed_forward.dense.dense.bias'])
+        x1, x2 = y1, x2 + f @ p[pre + 'feed_forward.output.dense.weight'].t() + p[pre + 'feed_forward.output.dense.bias']
+    hcat = F.layer_norm(torch.cat([x1, x2], -1), (2 * d,), p['reformer.encoder.layer_norm.weight'],
+                        p['reformer.encoder.layer_norm.bias'], c.layer_norm_eps)
+    logits = hcat @ p['lm_head.decoder.weight'].t() + p['lm_head.bias']
+    return logits[:, :Tp], cache
+
+
+def _rf_step(self, tok, cache, rotations):
+    """one token (B, 1) against the cache -> logits (B, V); the cache grows by one position"""
+    c, p = self.c, self.p
+    d, H, dh, ch = c.hidden_size, c.num_attention_heads, c.attention_head_size, c.chunk_length
+    B = tok.shape[0]
+    t = cache.states[0].shape[1]                                   # position of the new token
+    A0, A1 = c.axial_pos_shape
+    w0, w1 = p['reformer.embeddings.position_embeddings.weights.0'], p['reformer.embeddings.position_embeddings.weights.1']
+    pos = torch.cat([w0[t // A1, 0], w1[0, t % A1]], -1)
+    x = p['reformer.embeddings.word_embeddings.weight'][tok] + pos   # (B, 1, d)
+    x1, x2 = x, x
+    for l, kind in enumerate(c.attn_layers):
+        pre = f'reformer.encoder.layers.{l}.'
+        sa = pre + 'attention.self_attention.'
+        h = F.layer_norm(x2, (d,), p[pre + 'attention.layer_norm.weight'], p[pre + 'attention.layer_norm.bias'], c.layer_norm_eps)
+        past = cache.states[l]
+        if kind == 'local':
+            start = ((past.shape[1] // ch) - 1) * ch                # HF515:1327-1329 (a negative start slices from the end)
+            kv = torch.cat([past[:, start:], h], 1)
+            q = self._split(h @ p[sa + 'query.weight'].t())
+            k = self._split(kv @ p[sa + 'key.weight'].t()) / math.sqrt(dh)
+            v = self._split(kv @ p[sa + 'value.weight'].t())
+            a = self._merge(torch.softmax(q @ k.transpose(-1, -2), -1) @ v)
+        else:
+            rot = rotations[l]
+            n_h = rot.shape[2]
+            q = self._split(h @ p[sa + 'query_key.weight'].t())    # (B, H, 1, dh)
+            allh = torch.cat([past, h], 1)                          # (B, t+1, d)
+            if cache.buckets[l] is None:
+                qk = self._split(allh @ p[sa + 'query_key.weight'].t())
+                v = self._split(allh @ p[sa + 'value.weight'].t())
+                key = qk * torch.rsqrt(torch.mean(qk ** 2, -1, keepdim=True) + 1e-6) / math.sqrt(dh)
+                dots = q @ key.transpose(-1, -2)                    # (B, H, 1, t+1)
+                dots[..., -1] = -1e5                                # self mask on the token itself (HF515:840-845)
+                a = self._merge(torch.softmax(dots, -1) @ v)
+                if t + 1 >= ch:                                     # HF515:532-534: from now on the buckets are cached
+                    if self.num_buckets is None:
+                        raise RuntimeError('num_buckets must be set before cached decoding hashes (HF sets it in the first chunked forward)')
+                    cache.buckets[l] = lsh_buckets(qk, rot, self.num_buckets).view(B, H, n_h, t + 1)
+            else:
+                pb = cache.buckets[l]
+                nbk = self.num_buckets if isinstance(self.num_buckets, int) else math.prod(self.num_buckets)
+                inc = bool(pb.max() > n_h * nbk - 1)                # pad bucket was cached (HF515:961-965)
+                qb = lsh_buckets(q, rot, self.num_buckets, increase_num_buckets=inc).view(B, H, n_h, 1)
+                cb = torch.cat([pb, qb], -1)                        # (B, H, n_h, t+1)
+                order = _stable_argsort(cb)
+                n = t + 1
+                rank = (order == n - 1).float().argmax(-1)          # sorted slot of the new token
+                start = ((rank // ch) - 1) * ch
+                slots = (start.unsqueeze(-1) + torch.arange(2 * ch)) % n
+                posn = order.gather(-1, slots)                      # (B, H, n_h, 128) original positions
+                hs = allh[torch.arange(B).view(B, 1, 1, 1), posn]   # (B, H, n_h, 128, d)
+                wqk = p[sa + 'query_key.weight'].view(H, dh, d)
+                wv = p[sa + 'value.weight'].view(H, dh, d)
+                qk = torch.einsum('bhrld,hed->bhrle', hs, wqk)
+                v = torch.einsum('bhrld,hed->bhrle', hs, wv)
+                key = qk * torch.rsqrt(torch.mean(qk ** 2, -1, keepdim=True) + 1e-6) / math.sqrt(dh)
+                dots = torch.einsum('bhe,bhrle->bhrl', q[:, :, 0], key)
+                dots = torch.where(posn != n - 1, dots, torch.tensor(-1e5))
+                lse = torch.logsumexp(dots, -1, keepdim=True)
+                out = torch.einsum('bhrl,bhrle->bhre', torch.exp(dots - lse), v)
+                if n_h > 1:
+                    wgt = torch.exp(lse - torch.logsumexp(lse, 2, keepdim=True))
+                    out = (out * wgt).sum(2)
+                else:
+                    out = out[:, :, 0]
+                a = self._merge(out.unsqueeze(2))
+                cache.buckets[l] = cb
+        cache.states[l] = torch.cat([past, h], 1)
+        y1 = x1 + a @ p[pre + 'attention.output.dense.weight'].t()
+        h2 = F.layer_norm(y1, (d,), p[pre + 'feed_forward.layer_norm.weight'], p[pre + 'feed_forward.layer_norm.bias'], c.layer_norm_eps)
+        f = torch.relu(h2 @ p[pre + 'feed_forward.dense.dense.weight'].t() + p[pre + 'feed_forward.dense.dense.bias'])
+        x1, x2 = y1, x2 + f @ p[pre + 'feed_forward.output.dense.weight'].t() + p[pre + 'feed_forward.output.dense.bias']
+    hcat = F.layer_norm(torch.cat([x1, x2], -1), (2 * d,), p['reformer.encoder.layer_norm.weight'],
+                        p['reformer.encoder.layer_norm.bias'], c.layer_norm_eps)
+    return (hcat @ p['lm_head.decoder.weight'].t() + p['lm_head.bias'])[:, 0]
+
+
+@torch.no_grad()
+def _rf_greedy_generate(self, ids, max_length, rotations, return_logits=False):
+    """HF GenerationMixin.greedy_search over the cached path: arg-max of the last position's logits"""
+    logits, cache = self.prefill(ids, rotations)
+    last = logits[:, -1]
+    trace = [last]
+    while ids.shape[1] < max_length:
+        nxt = last.argmax(-1, keepdim=True)
+        ids = torch.cat([ids, nxt], 1)
+        if ids.shape[1] == max_length:
+            break
+        last = self.step(nxt, cache, rotations)
+        trace.append(last)
+    return (ids, torch.stack(trace, 1)) if return_logits else ids
+
+
+RefReformer.prefill = _rf_prefill
+RefReformer.step = _rf_step
+RefReformer.greedy_generate = _rf_greedy_generate

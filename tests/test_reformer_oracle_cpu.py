@@ -40,3 +40,16 @@ def test_known_answers():
     assert n == 82_498_980
     assert auto_num_buckets(4096, 64, 4096) == 128
     assert auto_num_buckets(8192, 64, 8192) == [16, 16]
+
+
+@pytest.mark.parametrize('name', ['gen_short', 'gen_padded', 'gen_chunks'])
+def test_cached_decoding_matches_hf(name):
+    """the oracle's restatement of HF's cached decoding (ReformerDynamicCache: hidden states + bucket ids per layer, one token
+    per step) against token ids and per-step logits recorded from the real HF implementation driven the way transformers 4.25.1's
+    generate drove it: prompt shorter than a chunk (standard attention, then the first hashing once 64 positions exist), a
+    padded prefill (pad bucket, widened offsets afterwards) and whole chunks"""
+    blob = _load(name)
+    cfg, m = _ref_from(blob)
+    ids, logits = m.greedy_generate(blob['prompt'], blob['ids'].shape[1], blob['rotations'], return_logits=True)
+    assert torch.equal(ids, blob['ids'])
+    assert (logits - blob['step_logits']).abs().max().item() < 1e-4
