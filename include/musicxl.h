@@ -264,6 +264,29 @@ int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T
 int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r, float* dlse,
                         int B, int T, int H, int dh, int n_h, void* stream);
 
+/* ---- Reformer incremental (cached) decoding: the single-token step of HF's `use_cache` path, i.e. what
+ * `model.generate(...)` at musicnlp/trainer/eval.py:333 runs (ReformerDynamicCache HF515:65-148; LSHSelfAttention.forward with
+ * past_buckets_states HF515:466-516, 946-1050; LocalSelfAttention HF515:1136-1169, 1327-1329).  The caches hold, per layer,
+ * the PROJECTIONS of every position so far ((B, Tmax, H*dh) bf16: k and v for local layers, shared qk and v for LSH layers --
+ * HF caches the LayerNorm'ed hidden states and re-projects what it gathers: the same numbers) and, per LSH layer, the offset
+ * bucket ids (B*H, n_h, Tmax) int32. */
+/* x[b] = E[ids[b, t]] + cat(W0[t / A1], W1[t % A1]): ReformerEmbeddings in eval with start_idx_pos_encodings = t */
+int mxl_rf_decode_embed(const void* ids, int ld_ids, int t, const void* E, const float* W0, const float* W1, void* out, int B,
+                        int d, int V, int A1, int d0, void* stream);
+/* buckets (rows, n_h*T) as written by mxl_lsh_hash (r*NB + b) -> r*(NB+1) + (t < T_real ? b : NB): the padded prefill of HF's
+ * eval mode sends pad positions to ONE extra bucket and widens the per-round offsets (HF515:746-756) */
+int mxl_lsh_fix_buckets(int* buckets, int rows, int n_h, int T, int T_real, int NB, void* stream);
+/* append the new token's bucket ids: raw (rows, n_h) = r*NB + b from mxl_lsh_hash on the one query; cache (rows, n_h, Tmax);
+ * *bkmax = maximum id in the cache.  Offsets widen to NB + 1 when *bkmax > n_h*NB - 1 (HF515:961-970); *bkmax is updated. */
+int mxl_rf_query_bucket(const int* raw, int* cache, int* bkmax, int rows, int n_h, int NB, int Tmax, int t, void* stream);
+/* one query per (sequence, head, round) at position t over <= 128 cached positions.  sorted == NULL: the contiguous range
+ * [start, start + count) -- a local layer (lsh = 0: keys / sqrt(dh), no mask) or an LSH layer before its first hashing (lsh = 1:
+ * shared-QK key normalisation, self mask -1e5 on position t).  sorted (B*H*n_h, n = t + 1) = mxl_lsh_sort of (cached ; new)
+ * bucket ids per round: the 64-slot chunk holding the new token and the chunk before it, slots modulo n (HF515:1032-1050);
+ * rounds merged by softmax of their logsumexp (HF515:636-655).  out (B, H*dh) bf16. */
+int mxl_rf_decode_attn(const void* q, int ldq, const void* kcache, const void* vcache, const int* sorted, void* out, int B, int H,
+                       int dh, int n_h, int Tmax, int n, int t, int start, int count, int lsh, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Evaluation metrics: replaces `preprocess_logits_for_metrics` + ComputeMetrics / IkrMetric on gathered
  * logits (musicnlp/trainer/train.py:265-284, musicnlp/trainer/metrics.py:45-117).

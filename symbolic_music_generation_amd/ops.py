@@ -413,3 +413,25 @@ def lsh_combine(out_r, lse, out, B, T, H, dh, n_h):
 def lsh_combine_bwd(out_r, lse, out, dout, dout_r, dlse, B, T, H, dh, n_h):
     check(lib().mxl_lsh_combine_bwd(_p(out_r), _p(lse), _p(out), _p(dout), _p(dout_r), _p(dlse), B, T, H, dh, n_h, _stream()),
           'mxl_lsh_combine_bwd')
+
+
+# ------------------------------------------------------------------ Reformer cached decoding
+def rf_decode_embed(ids, t, E, W0, W1, out, A1):
+    B, d = out.shape
+    check(lib().mxl_rf_decode_embed(_p(ids), ids.stride(0), t, _p(E), _p(W0), _p(W1), _p(out), B, d, E.shape[0], A1, W0.shape[-1],
+                                    _stream()), 'mxl_rf_decode_embed')
+    return out
+
+
+def lsh_fix_buckets(buckets, rows, n_h, T, T_real, NB):
+    check(lib().mxl_lsh_fix_buckets(_p(buckets), rows, n_h, T, T_real, NB, _stream()), 'mxl_lsh_fix_buckets')
+
+
+def rf_query_bucket(raw, cache, bkmax, rows, n_h, NB, Tmax, t):
+    check(lib().mxl_rf_query_bucket(_p(raw), _p(cache), _p(bkmax), rows, n_h, NB, Tmax, t, _stream()), 'mxl_rf_query_bucket')
+
+
+def rf_decode_attn(q, kcache, vcache, sorted_idx, out, B, H, dh, n_h, Tmax, n, t, start=0, count=0, lsh=False):
+    check(lib().mxl_rf_decode_attn(_p(q), q.stride(0), _p(kcache), _p(vcache), _p(sorted_idx), _p(out), B, H, dh, n_h, Tmax, n, t,
+                                   start, count, int(lsh), _stream()), 'mxl_rf_decode_attn')
+    return out

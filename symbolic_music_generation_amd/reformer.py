@@ -143,13 +143,17 @@ class MyReformerModelWithLMHead(EngineModule):
     @torch.no_grad()
     def generate(self, input_ids=None, max_length: Optional[int] = None, do_sample: bool = False, top_k: Optional[int] = None,
                  top_p: Optional[float] = None, temperature: float = 1.0, repetition_penalty: Optional[float] = None,
-                 typical_p: Optional[float] = None, seed: int = 77, **unsupported):
+                 typical_p: Optional[float] = None, seed: int = 77, use_cache: bool = True, rotations=None, **unsupported):
         """`model.generate(...)` as the reference drives it (musicnlp/trainer/eval.py:277-333): greedy, or sampling with
-        top-k / top-p / typical-p / temperature / repetition penalty (applied, as HF does, to the raw logits).  Every step is a full forward over the tokens so far -- the result HF's cached decoding
-        reproduces for local layers and, for LSH layers, the same procedure with the hash rotations redrawn each forward (what
-        HF does with `hash_seed=None`).  Beyond one chunk the sequence is right-padded to a multiple of the chunk length as HF
-        does in eval mode (`_pad_to_mult_of_chunk_length`); pads sit after every real token, so the causal mask alone keeps
-        them out of the real positions.  Token selection runs on the device (the TransfoXL decoder's sampler kernel)."""
+        top-k / top-p / typical-p / temperature / repetition penalty (applied, as HF does, to the raw logits); token selection
+        runs on the device (the TransfoXL decoder's sampler kernel).
+
+        use_cache=True (HF's default, what the reference gets): incremental decoding -- the prompt in one pass, then one token
+        per step against per-layer caches of projections and LSH bucket ids (rf_generate.RFDecoder; HF `ReformerDynamicCache`).
+        `rotations` ({lsh layer: (H, dh, n_h, rot/2)}) fixes the hash rotations (HF `config.hash_seed`); by default one seeded
+        draw serves the whole generation.
+        use_cache=False: every step is a full forward over the tokens so far, right-padded to a multiple of the chunk length
+        (pads sit after every real token, so the causal mask keeps them out), with the rotations redrawn each forward."""
         from . import ops
         if unsupported:
             bad = [k for k, v in unsupported.items() if v not in (None, False, 1, 1.0)]
@@ -167,23 +171,34 @@ class MyReformerModelWithLMHead(EngineModule):
             raise ValueError('max_length exceeds max_position_embeddings')
         if max_length <= Tp:
             return ids0[:, :max_length]
-        V = c.vocab_size
-        pad = getattr(c, 'pad_token_id', None)
-        pad = 0 if pad is None else int(pad)
-        buf = torch.full((B, max_length + 64), pad, device=self.device, dtype=torch.int64)
-        buf[:, :Tp] = ids0
-        t_dev = torch.full((1,), Tp - 1, device=self.device, dtype=torch.int32)
-        rng = torch.zeros(1, device=self.device, dtype=torch.int64)
-        for cur in range(Tp, max_length):
-            Tf = cur if cur <= 64 else (cur + 63) // 64 * 64
-            out = self.engine.forward(buf[:, :Tf].contiguous(), labels=None, train=False)
-            last = out['logits'][:, cur - 1].contiguous()
-            ops.sample(last, buf, t_dev, rng, seed, do_sample=do_sample, top_k=top_k or 0,
-                       top_p=top_p if top_p is not None else 1.0, temperature=temperature,
-                       repetition_penalty=repetition_penalty, typical_p=typical_p)
-            ops.decode_advance(t_dev, rng)
-            if Tf > cur:
-                buf[:, cur + 1:Tf] = pad          # keep the padding clean (the sampler wrote position `cur` only)
-        if was_training:
-            self.train()
-        return buf[:, :max_length].clone()
+        try:
+            if use_cache:
+                from .rf_generate import RFDecoder
+                dec = getattr(self, '_decoder', None)
+                if dec is None or dec.B != B or dec.Tmax < max_length:
+                    dec = self._decoder = RFDecoder(self.engine, B, max_length, seed=seed)
+                dec.rotations = rotations
+                dec.seed = seed
+                return dec.generate(ids0, max_length, do_sample=do_sample, top_k=top_k, top_p=top_p, temperature=temperature,
+                                    repetition_penalty=repetition_penalty, typical_p=typical_p)
+            V = c.vocab_size
+            pad = getattr(c, 'pad_token_id', None)
+            pad = 0 if pad is None else int(pad)
+            buf = torch.full((B, max_length + 64), pad, device=self.device, dtype=torch.int64)
+            buf[:, :Tp] = ids0
+            t_dev = torch.full((1,), Tp - 1, device=self.device, dtype=torch.int32)
+            rng = torch.zeros(1, device=self.device, dtype=torch.int64)
+            for cur in range(Tp, max_length):
+                Tf = cur if cur <= 64 else (cur + 63) // 64 * 64
+                out = self.engine.forward(buf[:, :Tf].contiguous(), labels=None, train=False)
+                last = out['logits'][:, cur - 1].contiguous()
+                ops.sample(last, buf, t_dev, rng, seed, do_sample=do_sample, top_k=top_k or 0,
+                           top_p=top_p if top_p is not None else 1.0, temperature=temperature,
+                           repetition_penalty=repetition_penalty, typical_p=typical_p)
+                ops.decode_advance(t_dev, rng)
+                if Tf > cur:
+                    buf[:, cur + 1:Tf] = pad          # keep the padding clean (the sampler wrote position `cur` only)
+            return buf[:, :max_length].clone()
+        finally:
+            if was_training:
+                self.train()

@@ -260,7 +260,11 @@ class RFEngine:
 
     # ---- forward
     def forward(self, input_ids, labels=None, train=False, rotations: Optional[Dict[int, torch.Tensor]] = None,
-                buckets_override: Optional[Dict[int, torch.Tensor]] = None):
+                buckets_override: Optional[Dict[int, torch.Tensor]] = None, n_real: Optional[int] = None, layer_sink=None):
+        """`n_real` < T: positions n_real.. are HF's eval-mode padding to a multiple of the chunk length (HF515:2012-2040): they
+        hash to ONE extra bucket and the per-round bucket offsets widen to num_buckets + 1 (HF515:746-756).  `layer_sink(l, kind,
+        qkv, buckets)` sees every layer's projections (N, nproj*d) and bucket ids right after they are computed (cached decoding
+        fills its caches from the prompt pass this way)."""
         c = self.cfg
         B, T = input_ids.shape
         single = T <= 64          # HF's standard-attention case: no hashing, no sort, no look-back chunk (HF515:547-549)
@@ -305,6 +309,8 @@ class RFEngine:
             qkv = ws.qkv[s].view(-1)[:N * nproj * d].view(N, nproj * d)
             ops.gemm(ws.hn[s], self._proj_w(l, kind), qkv, N, nproj * d, d)
             rs, bs = nproj * d, T * nproj * d
+            if layer_sink is not None and (kind == 'local' or single):
+                layer_sink(l, kind, qkv, None)
             if kind == 'local':
                 ops.chunk_attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], None, ws.av[s], ws.lse[s], B, T, H, dh, 1, 0, bs, rs,
                                    drop_p=p_loc, seed=seed, site=self._site(l, 0))
@@ -322,8 +328,13 @@ class RFEngine:
                         rot = torch.randn(H, dh, n_h, sum(factors) // 2, device=self.dev, generator=g)
                     ws.rot[l] = rot
                     ops.lsh_hash(qkv, bs, rs, rot, ws.buckets, B, T, H, dh, n_h, factors)
+                    if n_real is not None and n_real < T:
+                        ops.lsh_fix_buckets(ws.buckets, B * H, n_h, T, n_real, NB)
+                padded = n_real is not None and n_real < T
+                if layer_sink is not None:
+                    layer_sink(l, kind, qkv, ws.buckets)
                 self.last_buckets[l] = ws.buckets.clone() if (not train or self.keep_buckets) else None
-                ops.lsh_sort(ws.buckets, ws.sidx, ws.spos[s], B * H, n_h * T, T, NB * n_h)
+                ops.lsh_sort(ws.buckets, ws.sidx, ws.spos[s], B * H, n_h * T, T, (NB + 1 if padded else NB) * n_h)
                 tgt = ws.av[s] if n_h == 1 else ws.out_r[s]
                 ops.chunk_attn_fwd(qkv, qkv, qkv[:, d:], ws.spos[s], tgt, ws.lse[s], B, T, H, dh, n_h, 1, bs, rs,
                                    drop_p=p_lsh, seed=seed, site=self._site(l, 0))
