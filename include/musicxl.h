@@ -180,6 +180,10 @@ int mxl_adamw_step(float* p, const float* g, float* m, float* v, void* w16, long
                    float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
                    float max_norm, float grad_scale, void* stream);
 int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
+/* y = (float)x.  With mxl_cast_f32_bf16 the two ends of the bf16 gradient exchange: a bucket of the flat fp32 gradient buffer
+ * is narrowed into a bf16 staging buffer, all-reduced over RCCL at half the bytes (186 MB instead of 372 MB per step at
+ * 12L/768d), and widened back in place. */
+int mxl_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
 /* dst[b][c][r] = src[b][r][c] (bf16; element strides between batch items).  Keeps [in][out] copies of the Linear weights so
  * that the input gradient dX = dY W (autograd of F.linear) runs in the K-contiguous GEMM form. */
 int mxl_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, int batch,

@@ -53,6 +53,11 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, bf16_t* y, lo
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = f2bf(x[i]);
 }
 
+// y = (float)x, or y += (float)x: the receive side of the bf16 gradient exchange (dist.GradSync)
+__global__ __launch_bounds__(256) void widen_kernel(const bf16_t* x, float* y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = bf2f(x[i]);
+}
+
 inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -85,6 +90,13 @@ extern "C" int mxl_adamw_step(float* p, const float* g, float* m, float* v, void
 extern "C" int mxl_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
     MXL_CHECK_ARG(x && y && n > 0);
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_cast_bf16_f32(const void* x, float* y, long long n, void* stream) {
+    MXL_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

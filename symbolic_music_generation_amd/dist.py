@@ -72,25 +72,51 @@ def _r8(n):
 
 
 class GradSync:
-    """Overlapped all-reduce (SUM) of the engine's gradient buffer."""
+    """Overlapped all-reduce (SUM) of the engine's gradient buffer.
 
-    def __init__(self, engine):
+    `dtype='bf16'` (the default on the GPU; `MXL_DP_DTYPE=fp32` or dtype='fp32' selects the parity mode): a bucket is narrowed
+    into a bf16 staging buffer by a HIP kernel, all-reduced at half the bytes (186 MB per step at 12L/768d instead
+    of 372 MB), and widened back into the fp32 gradient buffer once it has arrived -- the fp32 master weights, Adam moments and
+    the clip norm never see bf16 storage.  The transport is `torch.distributed` (backend "nccl" = RCCL over xGMI): the
+    communicator, its bootstrap and its stream ordering against torch's allocator are torch's; libmusicxl owns the casts.
+    """
+
+    def __init__(self, engine, dtype: Optional[str] = None):
         self.engine = engine
         n_layer = getattr(engine.cfg, 'n_layer', None) or len(engine.cfg.attn_layers)
         self.per_layer, self.rest = layer_buckets(engine.layout, n_layer)
         self.pending = []
+        self.dtype = (dtype or os.environ.get('MXL_DP_DTYPE') or 'bf16').lower()
+        if self.dtype not in ('bf16', 'fp32'):
+            raise ValueError(f'gradient exchange dtype {self.dtype!r}: bf16 or fp32')
+        self._stage = {}
+
+    def _issue(self, lo: int, hi: int):
+        G = self.engine.G
+        if self.dtype == 'fp32' or not G.is_cuda:        # the narrowing / widening kernels are device code; host tensors (gloo
+            self.pending.append((dist.all_reduce(G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), None, lo, hi))   # tests) go as they are
+            return
+        from . import ops
+        buf = self._stage.get((lo, hi))
+        if buf is None:
+            buf = self._stage[(lo, hi)] = torch.empty(hi - lo, device=G.device, dtype=torch.bfloat16)
+        ops.cast_bf16(G[lo:hi], buf)
+        self.pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf, lo, hi))
 
     def layer_done(self, l: int):
         if not is_dist():
             return
         for lo, hi in self.per_layer[l]:
-            self.pending.append(dist.all_reduce(self.engine.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._issue(lo, hi)
 
     def finish(self):
         if not is_dist():
             return
         for lo, hi in self.rest:
-            self.pending.append(dist.all_reduce(self.engine.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-        for w in self.pending:
-            w.wait()
+            self._issue(lo, hi)
+        for work, buf, lo, hi in self.pending:
+            work.wait()
+            if buf is not None:
+                from . import ops
+                ops.cast_f32(buf, self.engine.G[lo:hi])
         self.pending = []

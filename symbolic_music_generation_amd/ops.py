@@ -233,6 +233,13 @@ def cast_bf16(x: torch.Tensor, y: torch.Tensor):
     return y
 
 
+def cast_f32(x: torch.Tensor, y: torch.Tensor):
+    """y (f32) = x (bf16)"""
+    _req(x, torch.bfloat16, 'x'); _req(y, torch.float32, 'y')
+    check(lib().mxl_cast_bf16_f32(_p(x), _p(y), x.numel(), _stream()), 'mxl_cast_bf16_f32')
+    return y
+
+
 def center_columns(x: torch.Tensor, y: torch.Tensor):
     """y = x - mean over rows (bf16, (M, N))"""
     M, N = x.shape
