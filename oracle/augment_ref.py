@@ -4,6 +4,8 @@
   * TokenPitchShift / PitchShift         musicnlp/preprocess/transform.py:154-237  with ScaleDegreeFinder.map_single
                                          (musicnlp/preprocess/key_finder.py:245-262) and pitch_tok2midi_pitch_meta
                                          (musicnlp/vocab/music_vocab.py:712-722)
+  * ChannelMixer                         musicnlp/preprocess/transform.py:331-450 with MusicConverter.str2tok_elms
+                                         (musicnlp/preprocess/music_converter.py:217-274); the random draws are inputs here
 Parity unpinned (musicnlp is not importable here; no fixtures in the reference).  Only tests/ may import this module."""
 import re
 from typing import List
@@ -84,3 +86,91 @@ def tempo_group(toks: List[str], tempo_bin: int = 5, low: int = 40, high: int = 
             return out
         s = e
     raise AssertionError(n)
+
+
+MEL, BASS, TUP, TUP_END, EOS = '<melody>', '<bass>', '<tup>', '</tup>', '</s>'
+
+
+def split_elements(toks: List[str]):
+    """MusicConverter.str2tok_elms (music_converter.py:217-274): header tokens, then per bar the list of token groups -- a note
+    [pitch, duration], a tuplet [<tup>, pitches..., duration, </tup>] or a lone channel marker; the trailing </s> is dropped"""
+    elms, i = [], 0
+    while i < len(toks):
+        t = toks[i]
+        if t == TUP:
+            j = toks.index(TUP_END, i)
+            assert j - i - 1 >= 3
+            elms.append(toks[i:j + 1]); i = j + 1
+        elif t.startswith('p_'):
+            assert toks[i + 1].startswith('d_')
+            elms.append(toks[i:i + 2]); i += 2
+        else:
+            elms.append([t]); i += 1
+    head = [elms[0][0], elms[1][0]]
+    assert head[0].startswith('TimeSig_') and head[1].startswith('Tempo_')
+    elms = elms[2:]
+    if elms[0][0].startswith('Key_'):
+        head.append(elms[0][0]); elms = elms[1:]
+    if elms[0][0] == OMIT:
+        head.append(OMIT); elms = elms[1:]
+    idx = [i for i, e in enumerate(elms) if e == [BAR]]
+    bars = [elms[a + 1:b] for a, b in zip(idx, idx[1:] + [len(elms)])]
+    if bars[-1] and bars[-1][-1] == [EOS]:
+        bars[-1] = bars[-1][:-1]
+    return head, bars
+
+
+def channel_mix(toks: List[str], mode: str, rand, coin) -> List[str]:
+    """ChannelMixer.__call__ (transform.py:351-361) + _split_bar_toks (:389-404) + _mix_up_bar_toks (:406-450).
+    `rand()` -> float in [0, 1) stands for `torch.rand(1).item()` (mode 'full': one draw per interleaving decision, melody with
+    probability n_melody / (n_melody + n_bass)); `coin()` -> bool for `torch.randint(2, (1,)).item() == 0` (mode 'swap': melody
+    block first).  Includes the reference's quirk that a bass-only bar comes out of mode 'full' without its <bass> marker."""
+    head, bars = split_elements(toks)
+    out = list(head)
+    for elms in bars:
+        assert elms[0][0] in (MEL, BASS)
+        mel, bass, cur = [], [], None
+        for e in elms:
+            if e[0] == MEL:
+                cur = mel
+            elif e[0] == BASS:
+                cur = bass
+            else:
+                cur.append(e)
+        ret = []
+        if mode == 'full':
+            n_m, n_b = len(mel), len(bass)
+            thresh = n_m / (n_m + n_b)
+            im, ib = iter(mel), iter(bass)
+            em, eb = next(im, None), next(ib, None)
+            prev, add_m = None, None
+            while em and eb:
+                add_m = rand() < thresh
+                cur_marker = MEL if add_m else BASS
+                if cur_marker != prev:
+                    ret.append(cur_marker)
+                if add_m:
+                    ret += em; em = next(im, None)
+                else:
+                    ret += eb; eb = next(ib, None)
+                prev = cur_marker
+            if em:
+                if not add_m:
+                    ret.append(MEL)
+                ret += em
+                for e in im:
+                    ret += e
+            else:
+                assert eb
+                if add_m:
+                    ret.append(BASS)
+                ret += eb
+                for e in ib:
+                    ret += e
+        else:
+            tm = [MEL] + sum(mel, [])
+            tb = [BASS] + sum(bass, [])
+            ret = (tm + tb) if coin() else (tb + tm)
+        out += [BAR] + ret
+    out.append(EOS)
+    return out

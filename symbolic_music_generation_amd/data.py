@@ -168,18 +168,92 @@ def pitch_shift_tables(vocab_step, vocab_degree, tok_map: Optional[dict] = None)
     return tab
 
 
+def channel_mix_ids(seq: np.ndarray, ids: dict, mode: str, rng) -> np.ndarray:
+    """`ChannelMixer` (musicnlp/preprocess/transform.py:331-450) on token ids: inside every bar the notes of the melody and the
+    bass channel are re-interleaved at random, each channel keeping its own order and a channel marker emitted at every change
+    (mode 'full': melody next with probability n_melody / (n_melody + n_bass), one draw per decision), or the two channel blocks
+    are emitted in random order (mode 'swap').  A note is [pitch, duration], a tuplet everything from <tup> through </tup>.
+    `ids`: token ids of <bar>, <melody>, <bass>, <tup>, </tup>, </s>, [OMIT] and the first / last key id.  Integer work on the
+    host array while the batch is being gathered; `rng` is a numpy Generator (the draws `torch.rand` / `torch.randint` make in
+    the reference)."""
+    BAR, MEL, BASS, TUP, TUPE, EOS, OMIT = (ids[k] for k in ('bar', 'melody', 'bass', 'tup', 'tup_end', 'eos', 'omit'))
+    seq = np.asarray(seq)
+    n = len(seq)
+    bars = np.flatnonzero(seq == BAR)
+    if len(bars) == 0:
+        return seq
+    out = [seq[:bars[0]]]
+    end = n - 1 if seq[n - 1] == EOS else n
+    bounds = list(bars) + [end]
+    marker = {True: np.asarray([MEL], dtype=seq.dtype), False: np.asarray([BASS], dtype=seq.dtype)}
+    bar_tok = np.asarray([BAR], dtype=seq.dtype)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        i = a + 1
+        if i >= b or seq[i] not in (MEL, BASS):
+            raise MusicXLError('channel mix-up: every bar must open with a channel marker')
+        mel, bass, cur = [], [], None
+        while i < b:
+            t = seq[i]
+            if t == MEL:
+                cur = mel; i += 1
+            elif t == BASS:
+                cur = bass; i += 1
+            elif t == TUP:
+                j = i + 1
+                while seq[j] != TUPE:
+                    j += 1
+                cur.append(seq[i:j + 1]); i = j + 1
+            else:
+                cur.append(seq[i:i + 2]); i += 2
+        out.append(bar_tok)
+        if mode == 'full':
+            n_m, n_b = len(mel), len(bass)
+            thresh = n_m / (n_m + n_b)
+            im = ib = 0
+            prev, add_m = None, None
+            while im < n_m and ib < n_b:
+                add_m = bool(rng.random() < thresh)
+                if add_m != prev:
+                    out.append(marker[add_m])
+                if add_m:
+                    out.append(mel[im]); im += 1
+                else:
+                    out.append(bass[ib]); ib += 1
+                prev = add_m
+            if im < n_m:
+                if not add_m:
+                    out.append(marker[True])
+                out += mel[im:]
+            else:
+                if add_m:                       # (the reference leaves a bass-only bar without its marker: add_m is None there)
+                    out.append(marker[False])
+                out += bass[ib:]
+        else:
+            tm, tb = [marker[True]] + mel, [marker[False]] + bass
+            out += (tm + tb) if int(rng.integers(2)) == 0 else (tb + tm)
+    out.append(np.asarray([EOS], dtype=seq.dtype))
+    return np.concatenate(out)
+
+
 class Augment:
     """Per-sequence augmentation on ids.  `keys[i]`: key name of sequence i ('CMajor', ...) or a {name: weight} dict to sample
     from (KeyInsert with `pt_sample`); needed for key insertion and pitch shift."""
 
     def __init__(self, tokenizer, random_crop: bool = False, min_seg_length: int = 16, crop_mult: int = 1,
                  insert_key: bool = False, keys=None, pitch_shift: bool = False, tokenizer_degree=None, seed: int = 0,
-                 group_tempo: bool = False, tokenizer_group=None):
+                 group_tempo: bool = False, tokenizer_group=None, channel_mixup=False):
         """`group_tempo`: the stored ids are in the ungrouped-tempo vocabulary of `tokenizer`; the batch comes out in the ids
         of the grouped one (`tokenizer_group`, or `tokenizer_degree` built with tempo_bin when pitch shift is on too --
         dataset.py:254-257,338-339 applies TempoGroup before KeyInsert / PitchShift; as tables they compose into one)."""
         v = tokenizer.vocab
         self.bar_id, self.omit_id = v.t2i(v.start_of_bar), v.t2i(v.omitted_segment)
+        # channel mix-up (dataset.py:277-281, 348-350: the LAST transform, after key insertion / pitch shift; as those are
+        # per-token id tables applied on the device, permuting the tokens first gives the same batch)
+        self.channel_mixup = ('full' if channel_mixup is True else channel_mixup) or None
+        if self.channel_mixup not in (None, 'full', 'swap'):
+            raise ValueError(f'channel_mixup {channel_mixup!r}: full or swap')
+        self.mix_ids = dict(bar=self.bar_id, omit=self.omit_id, melody=v.t2i('<melody>'), bass=v.t2i('<bass>'),
+                            tup=v.t2i('<tup>'), tup_end=v.t2i('</tup>'), eos=v.t2i('</s>'))
         self.random_crop, self.min_seg_length, self.crop_mult = random_crop, min_seg_length, crop_mult
         self.insert_key, self.keys, self.pitch_shift = insert_key, keys, pitch_shift
         if (insert_key or pitch_shift) and keys is None:
@@ -229,6 +303,8 @@ class Augment:
             ordinal = KEY_NAMES.index(key)
             head = parts[0]
             parts = [head[:2], np.asarray([self.key_id[key]], dtype=seq.dtype), head[2:]] + parts[1:]
+        if self.channel_mixup:
+            parts = [channel_mix_ids(np.concatenate(parts), self.mix_ids, self.channel_mixup, self.rng)]
         return parts, (ordinal if self.pitch_shift else (0 if self.group_tempo else -1))
 
 class DeviceBatcher:

@@ -101,3 +101,52 @@ def test_tempo_group_table_matches_string_transform(env, pitch_shift):
             assert tg.vocab.i2t(int(tab[ts.vocab.t2i(t)])) == t
     with pytest.raises(ValueError):
         Augment(ts, group_tempo=True, tokenizer_group=ts)
+
+
+@pytest.mark.parametrize('mode', ['full', 'swap'])
+def test_channel_mixup_on_ids_matches_string_transform(env, mode):
+    """ChannelMixer (transform.py:331-450) on ids == on token strings, with the same sequence of random draws"""
+    from symbolic_music_generation_amd.data import Augment, channel_mix_ids
+    ts, td, ids, toks = env
+    assert toks.count('<tup>') > 0 and toks.count('<bass>') > 10
+    aug = Augment(ts, channel_mixup=mode, seed=11)
+    got = channel_mix_ids(ids, aug.mix_ids, mode, np.random.default_rng(3))
+    r = np.random.default_rng(3)
+    want = R.channel_mix(toks, mode, rand=lambda: float(r.random()), coin=lambda: int(r.integers(2)) == 0)
+    assert [ts.vocab.i2t(int(i)) for i in got] == want
+    # a permutation inside every bar that keeps each channel's own order: same multiset of notes, same bar count
+    strip = lambda seq: sorted(t for t in seq if t not in ('<melody>', '<bass>'))
+    assert strip(want) == strip(toks) and want.count('<bar>') == toks.count('<bar>') and want[-1] == '</s>'
+    assert want != toks
+    head, bars0 = R.split_elements(toks)
+    _, bars1 = R.split_elements(want)
+    for b0, b1 in zip(bars0, bars1):
+        def chan(bar):
+            out, cur = {'<melody>': [], '<bass>': []}, None
+            for e in bar:
+                if e[0] in out:
+                    cur = e[0]
+                else:
+                    out[cur].append(e)
+            return out
+        assert chan(b0) == chan(b1)
+    # through Augment.pieces: crop + key insertion first, mix-up last (dataset.py:331-350)
+    aug2 = Augment(ts, random_crop=True, insert_key=True, keys=['GMajor'], channel_mixup=mode, seed=5)
+    parts, _ = aug2.pieces(0, ids, crop_idx=4, key='GMajor')
+    mixed = [ts.vocab.i2t(int(i)) for i in np.concatenate(parts)]
+    base = R.key_insert(R.random_crop(toks, 4), 'GMajor')
+    assert mixed[:4] == base[:4] and strip(mixed) == strip(base)
+
+
+def test_channel_mixup_hand_cases():
+    song = ('TimeSig_4/4 Tempo_120 <bar> <melody> p_1/4 d_1 <tup> p_2/4 p_3/4 p_4/4 d_2 </tup> <bass> p_5/2 d_4 '
+            '<bar> <bass> p_6/2 d_4 </s>').split()
+    draws = iter([0.9, 0.1, 0.1])              # thresh 2/3: bass, melody, (melody exhausted? no) ...
+    out = R.channel_mix(song, 'full', rand=lambda: next(draws), coin=None)
+    assert out[:2] == ['TimeSig_4/4', 'Tempo_120']
+    # bar 1: bass first (0.9 >= 2/3) -> bass exhausted -> remaining melody with its marker; bar 2: bass only -> the reference
+    # emits the notes WITHOUT a marker (add_to_melody is None)
+    assert out[2:] == ['<bar>', '<bass>', 'p_5/2', 'd_4', '<melody>', 'p_1/4', 'd_1', '<tup>', 'p_2/4', 'p_3/4', 'p_4/4', 'd_2',
+                       '</tup>', '<bar>', 'p_6/2', 'd_4', '</s>']
+    sw = R.channel_mix(song, 'swap', rand=None, coin=lambda: False)
+    assert sw[2:9] == ['<bar>', '<bass>', 'p_5/2', 'd_4', '<melody>', 'p_1/4', 'd_1']
