@@ -348,6 +348,10 @@ class DeviceBatcher:
         n = len(self.order())
         return n // self.B if self.drop_last else (n + self.B - 1) // self.B
 
+    def n_rows(self) -> int:
+        """sequences in the whole dataset (all ranks): what steps-per-epoch is computed from"""
+        return len(self.tf)
+
     def _stage(self, slot: int, rows: np.ndarray):
         """gather `rows` (truncated to max_length) into pinned slot `slot`, then enqueue the H2D copies on the side stream"""
         if not self._first[slot]:

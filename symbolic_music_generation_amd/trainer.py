@@ -72,7 +72,9 @@ class TrainArgs:
                     save_strategy='epoch', bf16=True, gradient_accumulation_steps=1, load_best_model_at_end=True,
                     metric_for_best_model='eval_loss', greater_is_better=False, output_dir=None)
 
-    def __call__(self, train_args: Dict = None, n_train: int = None) -> Dict:
+    def __call__(self, train_args: Dict = None, n_train: int = None, my_train_args: Dict = None):
+        """train.py:192-229.  With `my_train_args` given returns (args, my_args) like the reference's
+        `TrainArgs.__call__(train_args, my_train_args, train_dataset)`; without, the args dict alone."""
         args = self._get_default(self.model_name)
         preset = dict(TrainArgs.model_name2preset[self.model_name][self.model_size])
         if 'batch_size' in preset:
@@ -81,10 +83,34 @@ class TrainArgs:
         args.update(preset)
         if train_args:
             args.update(train_args)
+        steps_per_epoch = None
         if n_train is not None:
             bsz = args['per_device_train_batch_size'] * args.get('gradient_accumulation_steps', 1) * mdist.world_size()
-            args['steps_per_epoch'] = math.ceil(n_train / bsz)
-        return args
+            args['steps_per_epoch'] = steps_per_epoch = math.ceil(n_train / bsz)
+        if my_train_args is None:
+            return args
+        my_args = dict(logging_strategy='steps', tqdm=False, insert_key=False, proportional_mixing=False)      # :208-211
+        my_args.update(my_train_args)
+        my_args['steps_per_epoch'] = steps_per_epoch
+        save_epochs = my_args.get('save_epochs')
+        if save_epochs:                                                                                         # :214-221
+            assert args.get('save_strategy') == 'epoch', 'save per k epochs: save_strategy must be "epoch"'
+            if save_epochs > 1 and steps_per_epoch:
+                args['save_strategy'], args['save_steps'] = 'steps', save_epochs * steps_per_epoch
+        if my_args['logging_strategy'] not in ('steps', 'epoch', 'no'):
+            raise ValueError(f'logging_strategy {my_args["logging_strategy"]!r}')
+        if my_args['logging_strategy'] == 'epoch' and steps_per_epoch:
+            my_args['logging_steps'] = steps_per_epoch
+        return {k: v for k, v in args.items() if v is not None}, my_args
+
+
+def get_train_and_my_train_args(model_name: str, model_size: str, train_args: Dict = None, my_train_args: Dict = None,
+                                train_dataset=None):
+    """train.py:232-246"""
+    n = len(train_dataset) if train_dataset is not None else None
+    if n is not None and hasattr(train_dataset, 'n_rows'):
+        n = train_dataset.n_rows()
+    return TrainArgs(model_name, model_size)(train_args, n_train=n, my_train_args=my_train_args or dict())
 
 
 def lr_at(step: int, total_steps: int, base_lr: float, scheduler: str, warmup_ratio: float) -> float:
@@ -125,10 +151,16 @@ class MyTrainer:
 
     def __init__(self, model, tokenizer: Optional[MusicTokenizer], train_dataset=None, eval_dataset=None,
                  train_args: Dict = None, model_name: str = 'transf-xl', model_size: str = 'base',
-                 log_fn: Optional[Callable[[Dict], None]] = None, seed: int = RANDOM_SEED):
+                 log_fn: Optional[Callable[[Dict], None]] = None, seed: int = RANDOM_SEED, my_args: Dict = None,
+                 model_meta: Dict = None):
+        """`train_dataset` / `eval_dataset`: a sequence of equal-length id tensors, or a `data.DeviceBatcher` (token file ->
+        augmentation -> device batches; it shards by rank itself)."""
         self.model, self.tokenizer = model, tokenizer
         self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
-        n_train = len(train_dataset) if train_dataset is not None else None
+        self.my_args, self.model_meta = dict(my_args or {}), model_meta
+        n_train = None
+        if train_dataset is not None:
+            n_train = train_dataset.n_rows() if hasattr(train_dataset, 'n_rows') else len(train_dataset)
         self.args = TrainArgs(model_name, model_size)(train_args, n_train=n_train)
         self.engine = model.engine
         self.sync = mdist.GradSync(self.engine)
@@ -167,6 +199,13 @@ class MyTrainer:
 
     def _batches(self, ds, bsz: int, epoch: int, shuffle: bool, pad: bool = False, with_index: bool = False):
         """HF Trainer's loader keeps the last partial batch (`dataloader_drop_last=False`)."""
+        if hasattr(ds, 'n_rows'):            # a DeviceBatcher: already sharded, shuffled, augmented, collated, on the device
+            if hasattr(ds.tf, 'sample'):
+                ds.tf.sample()               # ProportionMixingDataset re-draws its sub-sample every epoch (dataset.py:422-431)
+            ds.epoch = epoch
+            for ids, labels in ds:
+                yield ((ids, labels), None) if with_index else (ids, labels)
+            return
         idx = self._shard(len(ds), epoch, shuffle, pad)
         for i in range(0, len(idx), bsz):
             rows = [torch.as_tensor(ds[j]) for j in idx[i:i + bsz]]
@@ -178,16 +217,18 @@ class MyTrainer:
     def train(self, max_steps: Optional[int] = None) -> Dict:
         a = self.args
         bsz = a['per_device_train_batch_size']
-        spe = max(1, math.ceil(len(self.train_dataset) / (bsz * mdist.world_size())))   # == TrainArgs.steps_per_epoch
+        n_train = self.train_dataset.n_rows() if hasattr(self.train_dataset, 'n_rows') else len(self.train_dataset)
+        spe = max(1, math.ceil(n_train / (bsz * mdist.world_size())))   # == TrainArgs.steps_per_epoch
         total = max_steps or spe * int(a['num_train_epochs'])
         t0 = time.time()
         done = False
         for epoch in range(int(a['num_train_epochs'])):
             for ids in self._batches(self.train_dataset, bsz, epoch, shuffle=True, pad=True):
-                ids, labels = collate_clm(ids, self.pad_id)
+                ids, labels = ids if isinstance(ids, tuple) else collate_clm(ids, self.pad_id)
                 lr = lr_at(self.global_step, total, a['learning_rate'], a['lr_scheduler_type'], a['warmup_ratio'])
                 loss = self.training_step(ids, labels, lr)
-                if self.global_step % a['logging_steps'] == 0:
+                if self.my_args.get('logging_strategy', 'steps') != 'no' and \
+                        self.global_step % self.my_args.get('logging_steps', a['logging_steps']) == 0:
                     d = dict(step=self.global_step, epoch=epoch + self.global_step / spe % 1, learning_rate=lr,
                              loss=loss.item())
                     self.log_history.append(d)
@@ -226,13 +267,13 @@ class MyTrainer:
         cm = ComputeMetrics(self.tokenizer, mode='vanilla', clm_pred_shifted=False) if self.tokenizer is not None else None
         tot_loss, tot_n, hit, cnt, ikr_sum, ikr_n = 0.0, 0, 0.0, 0.0, 0.0, 0
         for ids, rows in self._batches(self.eval_dataset, bsz, 0, shuffle=False, with_index=True):
-            ids, labels = collate_clm(ids, self.pad_id)
+            ids, labels = ids if isinstance(ids, tuple) else collate_clm(ids, self.pad_id)
             out = self.model(input_ids=ids, labels=labels)
             preds = max_out_logits(out.logits)
             if cm is not None:
                 c = cm.counts(preds, labels).cpu().numpy()
                 hit += float(c[:, 12].sum()); cnt += float(c[:, 13].sum())
-                if key_scores is not None:
+                if key_scores is not None and rows is not None:
                     ks = key_scores[rows]            # the shard is strided: index by the samples' dataset rows
                     ikr_sum += cm.ikr_from_counts(c, labels, ks) * ids.shape[0]
                     ikr_n += ids.shape[0]
@@ -256,3 +297,135 @@ class MyTrainer:
         self.model.save_pretrained(path)
         with open(os.path.join(path, 'trainer_state.json'), 'w') as f:
             json.dump(dict(global_step=self.global_step, log_history=self.log_history[-50:]), f)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's entry points (musicnlp/trainer/train.py:287-368, 417-593).  The reference loads its HuggingFace datasets by
+# name from its own processed-corpus directory (music21 extraction output: out of scope); here `dataset_names` names
+# pre-tokenised token files (data.write_token_file) in the stored vocabulary -- 'step' pitches whenever pitch shift is on,
+# as in the reference (dataset.py:259-262) -- and `dataset_args['keys']` carries the per-song key annotation that KeyInsert /
+# PitchShift read from the reference's `keys` column.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _open_split(names, split: str):
+    from .data import TokenFile
+    if isinstance(names, dict):
+        names = names[split]
+    if isinstance(names, (str, os.PathLike)) or hasattr(names, 'offsets'):
+        names = [names]
+    files = []
+    for nm in names:
+        if hasattr(nm, 'offsets') or hasattr(nm, 'files'):
+            files.append(nm)
+        else:
+            path = str(nm)
+            cand = [path, os.path.join(path, split), f'{path}.{split}', f'{path}-{split}']
+            hit = [c for c in cand if os.path.exists(c + '.json')]
+            if not hit:
+                raise FileNotFoundError(f'no token file for split {split!r} under {path!r}')
+            files.append(TokenFile(hit[0]))
+    return files
+
+
+def get_all_setup(model_name: str = None, model_size: str = None, model_config: Dict = None, dataset_names=None, prec: int = 5,
+                  dataset_args: Dict = None, train_args: Dict = None, my_train_args: Dict = None, trainer_args: Dict = None,
+                  device='cuda:0'):
+    """train.py:287-368 -> (model, tokenizer, trainer).  `my_train_args` keys as the reference reads them (:299-304):
+    random_crop, group_tempo, pitch_kind, insert_key, pitch_shift, channel_mixup, tokenize_scheme, tokenize_fnm,
+    proportional_mixing (+ logging_strategy, save_epochs, tqdm, mode).  `dataset_args`: keys = {'train': [...], 'test': [...]}
+    key name (or {name: weight}) per song for KeyInsert; seed."""
+    from .data import Augment, DeviceBatcher, MixedTokenFiles
+    my_train_args = dict(my_train_args or {})
+    dataset_args = dict(dataset_args or {})
+    names = ['random_crop', 'group_tempo', 'pitch_kind', 'insert_key', 'pitch_shift', 'channel_mixup', 'tokenize_scheme',
+             'tokenize_fnm', 'proportional_mixing']
+    rand_crop, grp_tp, pch_kd, ins_key, pch_shift, mix_up, tok, tok_fnm, prop_mix = (my_train_args.get(k, False) for k in names)
+    tok = tok or 'vanilla'
+    if tok not in ('vanilla', 'wordpiece', 'pairmerge'):
+        raise ValueError(f'Tokenization Scheme mismatch: {tok!r}')
+    pch_kd = pch_kd or 'midi'
+    if pch_shift and not (ins_key and pch_kd == 'degree'):
+        raise ValueError('A key must be inserted and the pitch kind be degree for pitch shifting')       # dataset.py:266-274
+    tokenizer, model, meta = get_model_n_tokenizer(model_name, model_size, prec=prec, tokenize_scheme=tok,
+                                                   tokenizer_filename=tok_fnm or None, pitch_kind=pch_kd, tempo_bin=grp_tp or None,
+                                                   model_config=model_config, device=device)
+    max_length = tokenizer.model_max_length
+    seed = dataset_args.get('shuffle_seed', RANDOM_SEED)
+    stored = MusicTokenizer(precision=prec, pitch_kind='step') if pch_shift else tokenizer     # what the token files hold
+
+    def batcher(split: str, bsz: int):
+        files = _open_split(dataset_names, split)
+        if prop_mix:
+            k = prop_mix if isinstance(prop_mix, int) and not isinstance(prop_mix, bool) else 2048
+            tf = MixedTokenFiles(files, k if split == 'train' else max(k // 10, 1))               # :336-343
+        elif len(files) > 1:
+            tf = MixedTokenFiles(files, max(len(f) for f in files))
+        else:
+            tf = files[0]
+        aug = None
+        crop = bool(rand_crop) and split == 'train'                                                # dataset.py:331
+        if crop or ins_key or pch_shift or mix_up:
+            keys = (dataset_args.get('keys') or {}).get(split)
+            aug = Augment(stored, random_crop=crop, crop_mult=rand_crop if isinstance(rand_crop, int) and rand_crop > 1 else 1,
+                          insert_key=bool(ins_key), keys=keys, pitch_shift=bool(pch_shift),
+                          tokenizer_degree=tokenizer if pch_shift else None, seed=seed + mdist.rank(),
+                          channel_mixup=mix_up or False)
+        return DeviceBatcher(tf, bsz, max_length, tokenizer.pad_token_id, device, shuffle=split == 'train', seed=seed,
+                             rank=mdist.rank(), world=mdist.world_size(), augment=aug)
+
+    pre = TrainArgs(model_name, model_size)(train_args)
+    tr = batcher('train', pre['per_device_train_batch_size'])
+    vl = batcher('test', pre['per_device_eval_batch_size'])
+    args, my_args = get_train_and_my_train_args(model_name, model_size, train_args, my_train_args, tr)
+    trainer_args = dict(trainer_args or {})
+    if 'transf-xl' in model_name and not trainer_args.get('disable_train_metrics', False):
+        raise NotImplementedError('train.py:364-365: additional train metrics are refused for transf-xl (GPU utilisation)')
+    trainer = MyTrainer(model, tokenizer, tr, vl, train_args=args, model_name=model_name, model_size=model_size,
+                        my_args=my_args, model_meta=meta, seed=seed, log_fn=trainer_args.get('log_fn'))
+    return model, tokenizer, trainer
+
+
+def train_xl(dataset_names, model_size: str = 'base', model_config: Dict = None, train_args: Dict = None,
+             my_train_args: Dict = None, dataset_args: Dict = None, device='cuda:0', **train_kwargs):
+    """The reference's `train_xl()` (train.py:492-593) with its hard-wired settings as defaults: max_length 1024, mem_len 512,
+    cutoffs [], degree pitches with key insertion + pitch shift, crop multiple 32, proportional mixing 32768, 24 epochs, batch
+    21 / eval 12, weight decay 0.1, save per epoch; seed 77.  Returns the trainer after `train()` + `save_model(<out>/trained)`."""
+    debug = 'debug' in model_size
+    mc = dict(max_length=1024, mem_len=512, cutoffs=[]); mc.update(model_config or {})
+    ta = dict(save_strategy='epoch', num_train_epochs=24)
+    if not debug:
+        ta.update(weight_decay=1e-1, per_device_train_batch_size=21, per_device_eval_batch_size=12)
+    ta.update(train_args or {})
+    mta = dict(tqdm=True, logging_strategy='no', mode='full', random_crop=32, group_tempo=None, pitch_kind='degree',
+               insert_key=True, pitch_shift=True, channel_mixup=False, tokenize_scheme='vanilla', tokenizer_filename=None,
+               proportional_mixing=32768)
+    mta.update(my_train_args or {})
+    model, tokenizer, trainer = get_all_setup(model_name='transf-xl', model_size=model_size, model_config=mc,
+                                              dataset_names=dataset_names, dataset_args=dataset_args, train_args=ta,
+                                              my_train_args=mta, trainer_args=dict(disable_train_metrics=True), device=device)
+    torch.manual_seed(RANDOM_SEED)
+    trainer.train(**train_kwargs)
+    if trainer.args.get('output_dir'):
+        trainer.save_model(os.path.join(trainer.args['output_dir'], 'trained'))
+    return trainer
+
+
+def train_reformer(dataset_names, model_size: str = 'base', model_config: Dict = None, train_args: Dict = None,
+                   my_train_args: Dict = None, dataset_args: Dict = None, device='cuda:0', **train_kwargs):
+    """The reference's `train_reformer()` (train.py:417-490): max_position_embeddings 4096 / axial (64, 64), degree pitches with
+    key insertion + pitch shift, crop multiple 128, proportional mixing 1280, 64 epochs, batch 32, lr 3e-4.  (The reference runs
+    it with its pair-merge tokenizer; the vanilla scheme is the default here: SURVEY 8(f) N4.)"""
+    mc = dict(max_position_embeddings=4096, axial_pos_shape=(64, 64)); mc.update(model_config or {})
+    ta = dict(save_strategy='epoch', num_train_epochs=64)
+    if 'debug' not in model_size:
+        ta.update(learning_rate=3e-4, per_device_train_batch_size=32, per_device_eval_batch_size=32)
+    ta.update(train_args or {})
+    mta = dict(tqdm=True, logging_strategy='no', mode='full', random_crop=128, pitch_kind='degree', insert_key=True,
+               pitch_shift=True, channel_mixup=False, tokenize_scheme='vanilla', tokenizer_filename=None, proportional_mixing=1280)
+    mta.update(my_train_args or {})
+    model, tokenizer, trainer = get_all_setup(model_name='reformer', model_size=model_size, model_config=mc,
+                                              dataset_names=dataset_names, dataset_args=dataset_args, train_args=ta,
+                                              my_train_args=mta, trainer_args=dict(disable_train_metrics=True), device=device)
+    trainer.train(**train_kwargs)
+    if trainer.args.get('output_dir'):
+        trainer.save_model(os.path.join(trainer.args['output_dir'], 'trained'))
+    return trainer

@@ -170,3 +170,18 @@ def test_data_parallel_gradsync_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+def test_train_and_my_train_args_surface():
+    """TrainArgs.__call__(train_args, my_train_args, train_dataset) of the reference (train.py:192-246)"""
+    from symbolic_music_generation_amd.trainer import get_train_and_my_train_args
+    ds = list(range(1000))
+    args, my = get_train_and_my_train_args('transf-xl', 'base', dict(per_device_train_batch_size=21, save_strategy='epoch'),
+                                           dict(logging_strategy='epoch', save_epochs=4, random_crop=32), ds)
+    assert my['steps_per_epoch'] == math.ceil(1000 / 21) == 48 and my['logging_steps'] == 48
+    assert args['save_strategy'] == 'steps' and args['save_steps'] == 4 * 48            # save every 4 epochs (:214-221)
+    assert my['insert_key'] is False and my['proportional_mixing'] is False and my['random_crop'] == 32 and my['tqdm'] is False
+    assert args['per_device_train_batch_size'] == 21 and args['learning_rate'] == 3e-4 and args['max_grad_norm'] == 1
+    assert all(v is not None for v in args.values())
+    with pytest.raises(ValueError):
+        get_train_and_my_train_args('reformer', 'tiny', None, dict(logging_strategy='sometimes'), ds)
