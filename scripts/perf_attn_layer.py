@@ -16,11 +16,12 @@ st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc*3*d, q_rs=3*d, kv_bs=Kc*3*d,
 q, k, v = qkv[:, Kc - T:, :d], qkv[:, :, d:2*d], qkv[:, :, 2*d:]
 dout = torch.randn(B, T, d, device=dev).bfloat16()
 dqkv = torch.zeros_like(qkv); delta = torch.zeros(B, H, T, device=dev)
-dg = torch.empty(B, H, T, M, device=dev, dtype=torch.bfloat16)
+CH = int(os.environ.get('DG_CHUNK', B))
+dg = torch.empty(CH, H, T, M, device=dev, dtype=torch.bfloat16)
 a, c = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
 d_rd = torch.zeros(M, d, device=dev); qr = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-for it in range(3):
+for it in range(int(os.environ.get('ITERS', 3))):
     ev[0].record()
     ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, **st)
     ev[1].record()
@@ -29,5 +30,7 @@ for it in range(3):
     ev[2].record()
     fin()
     ev[3].record()
+    if CH < B:      # chunked: the dRd contraction runs inside the loop, so the two brackets are one
+        pass
 torch.cuda.synchronize()
-print(f'B={B}: fwd {ev[0].elapsed_time(ev[1]):.3f} ms, bwd (delta+dq+dkv) {ev[1].elapsed_time(ev[2]):.3f} ms, drd {ev[2].elapsed_time(ev[3]):.3f} ms')
+print(f'B={B} dg chunk {CH}: fwd {ev[0].elapsed_time(ev[1]):.3f} ms, bwd (delta+dq+dkv) {ev[1].elapsed_time(ev[2]):.3f} ms, drd {ev[2].elapsed_time(ev[3]):.3f} ms')

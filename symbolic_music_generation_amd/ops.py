@@ -276,22 +276,41 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
     """Backward of relattn_fwd.  If `d_rd` (M, H*dh) f32 is given, also contracts dG with (q + r_r_bias):
     d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf).
     When that contraction runs as the streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0) it also produces d_rrb, and the
-    backward proper is launched without it -- its query-owner kernel then takes the faster 8-wave form."""
+    backward proper is launched without it -- its query-owner kernel then takes the faster 8-wave form.
+
+    `dg` may hold FEWER sequences than B: the batch is then walked in chunks of dg.shape[0] sequences, each chunk's attention
+    backward followed at once by its dRd contraction, so the un-skewed score gradient of a chunk (B_c * H * T * M * 2 bytes) is
+    produced and consumed while it is still in the 256 MB Infinity Cache instead of making a round trip through HBM (per-sequence
+    outputs are unaffected; the batch-summed ones are atomically accumulated in any case)."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     fused_rrb = (d_rd is not None and dg is not None and dh == 64 and T % 32 == 0 and M % 8 == 0 and M >= 8
                  and os.environ.get('MXL_NO_DQ8') != '1')
-    check(lib().mxl_relattn_bwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse),
-                                _p(delta), _p(dq), _p(dk), _p(dv), _p(dg), _p(d_rwb), None if fused_rrb else _p(d_rrb), B, T, H,
-                                dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                                float(scale), _stream()), 'mxl_relattn_bwd')
-    def finish():
+    Bc = B if dg is None else min(B, dg.shape[0])
+
+    def launch(b0, n):
+        sl = slice(b0, b0 + n)
+        check(lib().mxl_relattn_bwd(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]), _p(dout[sl]),
+                                    _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]), _p(dg), _p(d_rwb),
+                                    None if fused_rrb else _p(d_rrb), n, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
+                                    o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale), _stream()), 'mxl_relattn_bwd')
+
+    def drd(b0, n):
         if d_rd is not None:
-            relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, B=B, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs,
+            relattn_drd(q[b0:b0 + n], r_r_bias, dg, d_rd, qr_buf, B=n, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs,
                         rd=rd if fused_rrb else None, rd_rs=rd_rs, d_rrb=d_rrb if fused_rrb else None,
                         d_rwb=d_rwb if fused_rrb else None)
-    if defer_drd:          # (bench.py brackets the attention-backward launches alone)
-        return finish
-    finish()
+
+    if Bc >= B:
+        launch(0, B)
+        if defer_drd:          # (bench.py brackets the attention-backward launches alone)
+            return lambda: drd(0, B)
+        drd(0, B)
+        return None
+    for b0 in range(0, B, Bc):
+        n = min(Bc, B - b0)
+        launch(b0, n)
+        drd(b0, n)
+    return (lambda: None) if defer_drd else None
 
 
 def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs, rd=None, rd_rs=0, d_rrb=None, d_rwb=None):
