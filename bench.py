@@ -30,7 +30,7 @@ import torch  # noqa: E402   (importing torch does not initialise the GPU)
 WORKLOADS = {
     # BASELINE.json configs[2] / SURVEY C3: the config the metric is quoted on (seq 2048); fits one GPU
     'c3': dict(name='TransfoXL 12L/768d H12 dh64 F3072 T=2048 M=2048 V=1190 cutoffs=[] (SURVEY C3, mode R: fresh zero mems)',
-               size='base', n_layer=12, T=2048, M=2048, B=32),
+               size='base', n_layer=12, T=2048, M=2048, B=64),
     # BASELINE.json configs[1] / SURVEY C2
     'c2': dict(name='TransfoXL 6L/512d H8 dh64 F2048 T=1024 M=1024 V=1190 cutoffs=[] (SURVEY C2, mode R)',
                size='small', n_layer=6, T=1024, M=1024, B=64),

@@ -28,10 +28,18 @@ def get_model_n_tokenizer(model_name: str, model_size: str, prec: int = 5, token
     """train.py:31-59.  Returns (tokenizer, model, model_meta)."""
     if model_name not in ('transf-xl', 'reformer'):
         raise ValueError(f'Model Name mismatch: {model_name!r} not in [transf-xl, reformer]')
-    if tokenize_scheme != 'vanilla':
-        raise NotImplementedError('wordpiece / pairmerge tokenizers need trained tokenizer files the reference does not '
-                                  'ship (SURVEY 2.1 #11)')
-    tokenizer = MusicTokenizer(precision=prec, pitch_kind=pitch_kind or 'midi', tempo_bin=tempo_bin)
+    if tokenize_scheme not in ('vanilla', 'wordpiece', 'pairmerge'):
+        raise ValueError(f'Tokenization Scheme mismatch: {tokenize_scheme!r} not in [vanilla, wordpiece, pairmerge]')
+    if tokenize_scheme == 'vanilla':
+        tokenizer = MusicTokenizer(precision=prec, pitch_kind=pitch_kind or 'midi', tempo_bin=tempo_bin)
+    else:       # train.py:38-45: a trained sub-word tokenizer loaded from its file (the reference ships none: train one with
+        # subword.PairMergeTokenizerTrainer / WordPieceMusicTokenizerTrainer)
+        from .subword import PairMergeTokenizer, WordPieceMusicTokenizer
+        if not tokenizer_filename:
+            raise ValueError(f'tokenize_scheme={tokenize_scheme!r} needs `tokenizer_filename`: the path of a trained tokenizer')
+        cls = WordPieceMusicTokenizer if tokenize_scheme == 'wordpiece' else PairMergeTokenizer
+        kw = dict(tempo_bin=tempo_bin, **(dict(pitch_kind=pitch_kind) if pitch_kind else {}))
+        tokenizer = cls.from_file(tokenizer_filename, **kw)
     assert tokenizer.precision == prec
     if model_name == 'transf-xl':
         cls_config, cls_model = MyTransfoXLConfig, MyTransfoXLLMHeadModel

@@ -51,9 +51,7 @@ class MusicVocabulary:
                  with_rare_step: bool = True, tempo_bin: Union[bool, int, None] = None):
         if pitch_kind not in ('midi', 'step', 'degree'):
             raise ValueError(f'Unique Pitch Kind mismatch: {pitch_kind}')
-        if is_wordpiece:
-            raise NotImplementedError('wordpiece vocabularies need the trained tokenizer files, which the reference does '
-                                      'not ship (SURVEY 2.1 #11)')
+        # `is_wordpiece` only changes how the reference colours tokens on a terminal (music_vocab.py:754-756): ids are the same
         self.precision, self.pitch_kind, self.with_rare_step = precision, pitch_kind, with_rare_step
         self.is_wordpiece = is_wordpiece
         self.tempo_bin = (5 if tempo_bin is True else tempo_bin) if tempo_bin else None

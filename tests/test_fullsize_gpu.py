@@ -85,11 +85,13 @@ def test_attention_normalisation_and_causality_at_c3(dev):
     assert same2[100:].all() and (~same2[:100]).any()
 
 
-def test_attention_backward_batch_replication_at_bench_batch(dev):
-    """bench.py's per-GPU batch (32 sequences: dG holds 1.6 G elements, the fused qkv gradient 302 M): with the same
+@pytest.mark.parametrize('B', [32, 64])
+def test_attention_backward_batch_replication_at_bench_batch(dev, B):
+    """bench.py's per-GPU batch (64 sequences: dG holds 3.2 G elements -- past 2^31, the 64-bit offset paths -- and the fused qkv
+    gradient 604 M; 32 was round 1's default): with the same
     sequence in every batch slot the per-sequence outputs (dq, dk, dv, dG, delta) of the last slot equal those of the first
     bit for bit (owner-computes kernels, no cross-sequence accumulation), and the batch-summed ones (d_rd, bias gradients)
-    are 32 x a B = 1 call up to fp32 atomic ordering -- an index that wrapped at these offsets would break either."""
+    are B x a B = 1 call up to fp32 atomic ordering -- an index that wrapped at these offsets would break either."""
     from symbolic_music_generation_amd import ops
     Kc = T
     d = H * DH
@@ -116,7 +118,6 @@ def test_attention_backward_batch_replication_at_bench_batch(dev):
         torch.cuda.synchronize()
         return out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb
 
-    B = 32
     out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb = run(B)
     assert not torch.isnan(dg[-1].float()).any() and not torch.isnan(dg[0].float()).any()
     for nm, t in [('out', out), ('lse', lse), ('dqkv', dqkv), ('delta', delta), ('dg', dg)]:
