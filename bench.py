@@ -370,7 +370,7 @@ def decode_leg(args, ranks: Ranks, warmup: int):
                           'batch': B, 'positions_timed': [done, done + steps], 'hipgraph': not args.eager},
                'roofline': {'kernel': 'whole decode step (one hipGraph replay: 12 x [qkv+append, bd, ring attention, o, LN, ffn1, '
                                       'ffn2 slabs, LN] + head + sampler)', 'bound': 'hbm', 'achieved': ach,
-                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, **decode_pmc_traffic(),
                             'basis': 'written ring slots, averaged over the timed generation',
                             'algorithmic_bytes_per_step': bytes_step, 'mean_valid_ring_slots': valid}}
         if dt_full:
@@ -408,6 +408,20 @@ def pmc_traffic(workload, B):
     if not all(n in k for n in names):
         return None, None
     return sum(k[n]['hbm_bytes_per_launch'] * k[n].get('launches_per_group', 1) for n in names), os.path.basename(path)
+
+
+def decode_pmc_traffic():
+    """HBM bytes per decode step from the newest committed PMC passes of an EAGER decode window (profiles/r*_c5_decode_eager_
+    pmc_traffic.json: rocprofv3 cannot collect counters over hipGraph replays; same kernels, launched one by one, over the ring
+    positions stated in the file)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_c5_decode_eager_pmc_traffic.json')))
+    if not files:
+        return {'traffic': None}
+    rec = json.load(open(files[-1]))
+    return {'traffic': rec.get('hbm_bytes_per_decode_step'), 'traffic_unit': 'HBM bytes per decode step (PMC, eager launches)',
+            'traffic_source': os.path.basename(files[-1]), 'traffic_positions': rec.get('positions'),
+            'traffic_algorithmic_bytes_at_those_positions': rec.get('algorithmic_bytes_per_step_at_these_positions')}
 
 
 # ------------------------------------------------------------------------------------------------ CPU oracle baselines
