@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from symbolic_music_generation_amd import ops
 dev = torch.device('cuda:0')
-B, T, H, dh, M, Kc = int(os.environ.get('B', 16)), 2048, 12, 64, 2048, 2048
+B, T, H, dh, M, Kc = int(os.environ.get('B', 16)), 2048, 12, 64, 2048, int(os.environ.get('KC', 2048))
 d = H * dh
 torch.manual_seed(0)
 qkv = torch.randn(B, Kc, 3 * d, device=dev).bfloat16()
