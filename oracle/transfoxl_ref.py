@@ -444,5 +444,106 @@ class RefTransfoXLLMHeadModel(nn.Module):
         return ids
 
 
+class _RefBeamHyps:
+    """HF 4.25.1 generation/beam_search.py `BeamHypotheses`: the n best finished hypotheses of one batch item, scored
+    sum_logprobs / len ** length_penalty"""
+
+    def __init__(self, num_beams, length_penalty, early_stopping):
+        self.n, self.lp, self.early = num_beams, length_penalty, early_stopping
+        self.beams, self.worst = [], 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (hyp.shape[-1] ** self.lp)
+        if len(self.beams) < self.n or score > self.worst:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.n:
+                order = sorted((sc, i) for i, (sc, _) in enumerate(self.beams))
+                del self.beams[order[0][1]]
+                self.worst = order[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.n:
+            return False
+        if self.early:
+            return True
+        return self.worst >= best_sum_logprobs / cur_len ** self.lp
+
+
+@torch.no_grad()
+def ref_beam_search(model: 'RefTransfoXLLMHeadModel', input_ids, max_length, num_beams=3, early_stopping=True,
+                    length_penalty=1.0, num_return_sequences=1, return_scores=False):
+    """HF 4.25.1 `GenerationMixin.beam_search` + `BeamSearchScorer.process / finalize` restated for this model (the
+    `strategy='beam'` branch of musicnlp/trainer/eval.py:302-321 with do_sample=False; test infrastructure).  The prompt is
+    expanded num_beams times (repeat_interleave), beam 0 of each item starts at score 0 and the others at -1e9, each step takes
+    the 2 * num_beams best (beam, token) continuations per item in score order, finished ones (eos) go to the hypothesis heap,
+    the first num_beams open ones continue, and the mems follow their beams (`_reorder_cache`: index_select(1, beam_idx)).
+    Returns (B * num_return_sequences, L) ids padded with pad = eos as HF does when the config has no pad token."""
+    model.eval()
+    eos = model.config.eos_token_id
+    pad = eos
+    B, nb = input_ids.shape[0], num_beams
+    ids = input_ids.repeat_interleave(nb, 0)
+    beam_scores = torch.zeros(B, nb)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_RefBeamHyps(nb, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    past = None
+    while True:
+        inp = model.prepare_inputs_for_generation(ids, past)
+        out = model(inp['input_ids'], mems=inp.get('mems'))
+        logp = out.prediction_scores[:, -1, :]                   # already log-probabilities
+        V = logp.shape[-1]
+        sc = (logp + beam_scores[:, None]).view(B, nb * V)
+        top_s, top_i = sc.topk(2 * nb, dim=1, largest=True, sorted=True)
+        top_b, top_t = top_i // V, top_i % V
+        cur_len = ids.shape[-1]
+        n_scores, n_tok, n_idx = torch.zeros(B, nb), torch.zeros(B, nb, dtype=torch.long), torch.zeros(B, nb, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                n_tok[b] = pad
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                tok, s_, src = int(top_t[b, rank]), float(top_s[b, rank]), b * nb + int(top_b[b, rank])
+                if tok == eos:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(ids[src].clone(), s_)
+                else:
+                    n_scores[b, k], n_tok[b, k], n_idx[b, k] = s_, tok, src
+                    k += 1
+                if k == nb:
+                    break
+            assert k == nb
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+        beam_scores, beam_tok, beam_idx = n_scores.view(-1), n_tok.view(-1), n_idx.view(-1)
+        ids = torch.cat([ids[beam_idx], beam_tok[:, None]], 1)
+        past = [m.index_select(1, beam_idx) for m in out.mems]
+        if all(done) or ids.shape[-1] >= max_length:
+            break
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(ids[b * nb + j], float(beam_scores[b * nb + j]))
+    best, scores = [], []
+    for b in range(B):
+        srt = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(num_return_sequences):
+            sc_, h = srt.pop()
+            best.append(h); scores.append(sc_)
+    lens = torch.tensor([len(h) for h in best])
+    L = min(int(lens.max()) + 1, max_length)
+    outp = torch.full((len(best), L), pad, dtype=torch.long)
+    for i, h in enumerate(best):
+        outp[i, :len(h)] = h
+        if len(h) < L:
+            outp[i, len(h)] = eos
+    return (outp, torch.tensor(scores)) if return_scores else outp
+
+
 def count_parameters(m: nn.Module) -> int:
     return sum(p.numel() for p in m.parameters())  # shared (tied) tensors counted once

@@ -7,7 +7,10 @@ reference calls it (musicnlp/trainer/eval.py:277-333; HF 4.25.1 GenerationMixin.
 
 Strategies mirrored from `MusicGenerator` (eval.py:277-326): greedy (do_sample=False) and sampling with
 `top_k`, `top_p`, `typical_p`, `temperature`, `repetition_penalty` and renormalised logits -- every key the `sample`
-strategy accepts (eval.py:279).  Beam / contrastive search are out of this round's scope and raise.
+strategy accepts (eval.py:279) -- and beam search (`strategy='beam'`, eval.py:302-321: HF `beam_search` / `beam_sample` with
+`BeamSearchScorer`), which runs the same per-token kernels eagerly with the beam bookkeeping between steps (XLDecoder.beam_search).
+Contrastive search raises: HF 4.25.1's `contrastive_search` requires `past_key_values` in the model output, which neither
+TransfoXL (`mems`) nor Reformer (`past_buckets_states`) returns, so that strategy fails in the reference too.
 """
 import math
 from typing import Optional
@@ -91,12 +94,20 @@ class XLDecoder:
         ops.adaptive_logprob(last, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         self.t_dev.fill_(Tp - 1)
         self._trace()
-        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
-        ops.decode_advance(self.t_dev, self.rng)       # t = Tp: position of the token just sampled
+        if sampling is not None:                       # None: the caller picks the token from self.logp (beam search)
+            ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
+            ops.decode_advance(self.t_dev, self.rng)   # t = Tp: position of the token just sampled
         return out
 
     # ---------------------------------------------------------------- one token
     def step(self, sampling: dict):
+        self._forward_token()
+        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
+        ops.decode_advance(self.t_dev, self.rng)
+
+    def _forward_token(self):
+        """the token at position t (ids[:, t], t on the device) through the model: K/V appended to the rings at slot t mod M,
+        self.logp = log-probabilities of position t + 1"""
         e, c = self.eng, self.eng.cfg
         B, d, H, dh, M, Fi, L = self.B, c.d_model, c.n_head, c.d_head, c.mem_len, c.d_inner, c.n_layer
         E = e.w16('transformer.word_emb.emb_layers.0.weight')
@@ -136,8 +147,6 @@ class XLDecoder:
         G(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
         ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         self._trace()
-        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
-        ops.decode_advance(self.t_dev, self.rng)
 
     def _trace(self):
         if self.trace is not None:
@@ -188,6 +197,165 @@ class XLDecoder:
                 for _ in range(steps):
                     self.step(sampling)
         return self.ids[:, :max_length].clone()
+
+
+class _BeamHyps:
+    """HF 4.25.1 generation/beam_search.py `BeamHypotheses`: the best finished hypotheses of one batch item"""
+
+    def __init__(self, num_beams: int, length_penalty: float, early_stopping: bool):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams, self.worst_score = [], 1e9
+
+    def add(self, hyp: torch.Tensor, sum_logprobs: float):
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.num_beams:
+                ranked = sorted((sc, i) for i, (sc, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        if len(self.beams) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+def beam_search(dec: XLDecoder, prompt: torch.Tensor, max_length: int, num_beams: int = 3, do_sample: bool = False,
+                top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: float = 1.0,
+                typical_p: Optional[float] = None, early_stopping: bool = True, length_penalty: float = 1.0,
+                num_return_sequences: int = 1, eos_token_id: int = 0, pad_token_id: Optional[int] = None,
+                renormalize_logits: bool = True, generator: Optional[torch.Generator] = None, return_scores: bool = False):
+    """HF 4.25.1 `beam_search` (do_sample=False) / `beam_sample` (do_sample=True) with `BeamSearchScorer.process / finalize`,
+    as `model.generate(num_beams=...)` reaches them from musicnlp/trainer/eval.py:302-333.  `dec` holds one row per beam:
+    B * num_beams rows (times num_return_sequences for beam_sample, as HF expands).  Per step: the device computes the
+    log-probabilities of every beam's next token (the same kernels as `step`), the 2 * num_beams best (or sampled) continuations
+    per item are taken on the device, the scorer's walk over them runs on the host (it is a data-dependent loop over a handful
+    of scalars, as in HF), and the K/V rings and the id history follow their beams (HF `_reorder_cache`).
+    Returns (B * num_return_sequences, L) ids, padded with pad_token_id (= eos when the config has none, as HF does)."""
+    e, c = dec.eng, dec.eng.cfg
+    dev, V = e.dev, c.vocab_size
+    nb = num_beams
+    if nb < 2:
+        raise MusicXLError('beam search needs num_beams > 1')
+    pad = eos_token_id if pad_token_id is None else pad_token_id
+    B0, Tp = prompt.shape
+    Bs = B0 * (num_return_sequences if do_sample else 1)              # scorer batch (HF: batch_size * num_return_sequences)
+    keep = 1 if do_sample else num_return_sequences
+    if keep > nb:
+        raise MusicXLError('num_return_sequences has to be smaller or equal to num_beams')
+    rows = Bs * nb
+    if dec.B != rows or max_length > dec.Tmax:
+        raise MusicXLError(f'the decoder was built for {dec.B} rows x {dec.Tmax} positions, beam search needs {rows} x {max_length}')
+    expanded = prompt.repeat_interleave(rows // B0, 0).to(dev)
+    dec.prefill(expanded, None)
+    beam_scores = torch.zeros(Bs, nb, device=dev)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(nb, length_penalty, early_stopping) for _ in range(Bs)]
+    done = [False] * Bs
+    cur_len = Tp
+    ident = torch.arange(rows, device=dev)
+    while True:
+        sc = dec.logp + beam_scores[:, None]
+        if do_sample:              # HF beam_sample: warp log p + beam score, renormalise, draw 2 * num_beams, sort
+            sc = _warp(sc, top_k, top_p, typical_p, temperature, min_keep=2, renormalize=renormalize_logits)
+            flat = sc.view(Bs, nb * V)
+            pick = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=generator)
+            top_s, order = flat.gather(-1, pick).sort(descending=True, dim=1)
+            top_i = pick.gather(-1, order)
+        else:
+            top_s, top_i = sc.view(Bs, nb * V).topk(2 * nb, dim=1, largest=True, sorted=True)
+        top_b, top_t = (top_i // V).tolist(), (top_i % V).tolist()
+        top_sl = top_s.tolist()
+        n_s, n_t, n_i = [[0.0] * nb for _ in range(Bs)], [[pad] * nb for _ in range(Bs)], [[0] * nb for _ in range(Bs)]
+        for b in range(Bs):
+            if done[b]:
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                tok, s_, src = top_t[b][rank], top_sl[b][rank], b * nb + top_b[b][rank]
+                if tok == eos_token_id:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(dec.ids[src, :cur_len].clone(), s_)
+                else:
+                    n_s[b][k], n_t[b][k], n_i[b][k] = s_, tok, src
+                    k += 1
+                if k == nb:
+                    break
+            if k < nb:
+                raise MusicXLError(f'at most {nb} tokens in the top {2 * nb} can be eos')
+            done[b] = done[b] or hyps[b].is_done(max(top_sl[b]), cur_len)
+        beam_scores = torch.tensor(n_s, device=dev).view(-1)
+        beam_idx = torch.tensor(n_i, device=dev).view(-1)
+        if not torch.equal(beam_idx, ident):          # rows follow their beams: id history and both rings of every layer
+            dec.ids.copy_(dec.ids.index_select(0, beam_idx))
+            for ring in dec.kc + dec.vc:
+                ring.copy_(ring.index_select(0, beam_idx))
+        dec.ids[:, cur_len] = torch.tensor(n_t, device=dev).view(-1)
+        cur_len += 1
+        if all(done) or cur_len >= max_length:
+            break
+        dec.t_dev.fill_(cur_len - 1)
+        dec._forward_token()
+    final = beam_scores.tolist()
+    for b in range(Bs):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(dec.ids[b * nb + j, :cur_len].clone(), final[b * nb + j])
+    best, scores = [], []
+    for b in range(Bs):
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(keep):
+            sc_, h = ranked.pop()
+            best.append(h); scores.append(sc_)
+    L = min(max(len(h) for h in best) + 1, max_length)
+    out = torch.full((len(best), L), pad, dtype=torch.int64, device=dev)
+    for i, h in enumerate(best):
+        out[i, :len(h)] = h
+        if len(h) < L:
+            out[i, len(h)] = eos_token_id
+    return (out, torch.tensor(scores)) if return_scores else out
+
+
+def _warp(scores: torch.Tensor, top_k, top_p, typical_p, temperature, min_keep: int, renormalize: bool = True) -> torch.Tensor:
+    """HF 4.25.1 logits warpers in `_get_logits_warper` order (temperature, top-k, top-p, typical-p, then
+    LogitNormalization when renormalize_logits is set -- the reference sets it for every sampling call, eval.py:323) on a
+    (rows, V) score matrix; min_tokens_to_keep = 2 under beam search.  Used by beam_sample only -- plain sampling runs in the
+    sampler kernel.  HF applies the warpers AFTER adding the running beam scores, so with LogitNormalization every beam's row is
+    renormalised to log-sum-exp 0 each step and the running score drops out of the draw; that is the reference's behaviour and
+    it is kept."""
+    neg = float('-inf')
+    if temperature is not None and temperature != 1.0:
+        scores = scores / temperature
+    if top_k:
+        k = min(max(top_k, min_keep), scores.shape[-1])
+        scores = scores.masked_fill(scores < scores.topk(k, -1).values[..., -1:], neg)
+    if top_p is not None and top_p < 1.0:
+        srt, idx = scores.sort(descending=False, dim=-1)
+        remove = srt.softmax(-1).cumsum(-1) <= (1 - top_p)
+        remove[..., -min_keep:] = False
+        scores = scores.masked_fill(remove.scatter(-1, idx, remove), neg)
+    if typical_p is not None and typical_p < 1.0:
+        logp = scores.log_softmax(-1)
+        p = logp.exp()
+        ent = -(torch.nan_to_num(logp * p, nan=0.0)).sum(-1, keepdim=True)
+        shifted = ((-logp) - ent).abs()
+        srt, idx = shifted.sort(descending=False, dim=-1)
+        cum = scores.gather(-1, idx).softmax(-1).cumsum(-1)
+        last = (cum < typical_p).sum(-1)
+        last[last < 0] = 0
+        remove = srt > srt.gather(-1, last.view(-1, 1).clamp(max=scores.shape[-1] - 1))
+        if min_keep > 1:
+            remove[..., :min_keep] = False
+        scores = scores.masked_fill(remove.scatter(-1, idx, remove), neg)
+    return scores.log_softmax(-1) if renormalize else scores
 
 
 # -------------------------------------------------------------------- bar-aligned cuts around generation

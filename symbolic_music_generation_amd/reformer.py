@@ -155,8 +155,17 @@ class MyReformerModelWithLMHead(EngineModule):
         use_cache=False: every step is a full forward over the tokens so far, right-padded to a multiple of the chunk length
         (pads sit after every real token, so the causal mask keeps them out), with the rotations redrawn each forward."""
         from . import ops
+        top_k = getattr(self.config, 'top_k', 50) if top_k is None else top_k        # HF fills it from the config: default 50
+        if unsupported.get('penalty_alpha') and not do_sample and top_k is not None and top_k > 1:
+            raise ValueError(f'{type(self).__name__} does not support caching through `past_key_values` and therefore '
+                             "**can't** be used for contrastive search (the message HF 4.25.1 raises for this model)")
+        if unsupported.get('num_return_sequences', 1) not in (None, 1):
+            if not do_sample:
+                raise ValueError('num_return_sequences has to be 1 when doing greedy search')
+            input_ids = input_ids.repeat_interleave(int(unsupported.pop('num_return_sequences')), 0)
         if unsupported:
-            bad = [k for k, v in unsupported.items() if v not in (None, False, 1, 1.0)]
+            ok = {'early_stopping', 'renormalize_logits'}      # no effect: eos never ends a row; the sampler always renormalises
+            bad = [k for k, v in unsupported.items() if k not in ok and v not in (None, False, 1, 1.0)]
             if bad:
                 raise NotImplementedError(f'generation options not covered: {bad}')
         self._maybe_resync()

@@ -194,13 +194,36 @@ class MyTransfoXLLMHeadModel(EngineModule):
     def generate(self, input_ids: torch.Tensor = None, max_length: int = None, do_sample: bool = False,
                  top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: float = 1.0, num_beams: int = 1,
                  penalty_alpha=None, typical_p=None, repetition_penalty=None, early_stopping=None,
-                 renormalize_logits=None, use_graph: bool = True, seed: int = 77, **unused) -> torch.Tensor:
-        """`model.generate(**inputs, **args)` as called at musicnlp/trainer/eval.py:333 (greedy / sampling strategies)."""
-        from .generate import XLDecoder
-        if num_beams != 1 or penalty_alpha is not None:
-            raise NotImplementedError('beam / contrastive search are out of scope for the HIP decode path (SURVEY 8: A10)')
+                 renormalize_logits=None, num_return_sequences: int = 1, num_beam_groups: int = 1, length_penalty: float = 1.0,
+                 use_graph: bool = True, seed: int = 77, **unused) -> torch.Tensor:
+        """`model.generate(**inputs, **args)` as called at musicnlp/trainer/eval.py:333: the greedy, sample and beam strategies
+        (eval.py:277-321).  `num_return_sequences` expands the prompts as HF does (repeat_interleave).  Contrastive search
+        (`penalty_alpha`) raises as it does in the reference stack: HF 4.25.1 requires `past_key_values` in the model output for
+        it, and TransfoXL returns `mems`.  Diverse (group) beam search is not implemented."""
+        from .generate import XLDecoder, beam_search
+        # HF 4.25.1 fills unspecified generation arguments from the model config; PretrainedConfig's default top_k is 50, so
+        # `generate(do_sample=True)` without top_k samples from the 50 best tokens (the reference relies on these defaults)
+        top_k = getattr(self.config, 'top_k', 50) if top_k is None else top_k
+        if penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and not do_sample:
+            raise ValueError(f'{type(self).__name__} does not support caching through `past_key_values` and therefore '
+                             "**can't** be used for contrastive search (the message HF 4.25.1 raises for this model)")
+        if num_beam_groups != 1:
+            raise NotImplementedError('diverse (group) beam search is not implemented on the HIP decode path')
         self._maybe_resync()
         max_length = max_length or self.config.max_length_
+        if num_beams > 1:
+            rows = input_ids.shape[0] * num_beams * (num_return_sequences if do_sample else 1)
+            dec = XLDecoder(self.engine, rows, max_length, seed=seed)
+            gen = torch.Generator(device=self.device).manual_seed(seed) if do_sample else None
+            return beam_search(dec, input_ids, max_length, num_beams=num_beams, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                               temperature=temperature, typical_p=typical_p, early_stopping=bool(early_stopping),
+                               renormalize_logits=bool(renormalize_logits),
+                               length_penalty=length_penalty, num_return_sequences=num_return_sequences,
+                               eos_token_id=self.config.eos_token_id, pad_token_id=self.config.pad_token_id, generator=gen)
+        if num_return_sequences > 1:
+            if not do_sample:
+                raise ValueError('num_return_sequences has to be 1 when doing greedy search')       # HF's message
+            input_ids = input_ids.repeat_interleave(num_return_sequences, 0)
         B = input_ids.shape[0]
         dec = getattr(self, '_decoder', None)
         if dec is None or dec.B != B or dec.Tmax < max_length:

@@ -200,3 +200,57 @@ def test_decode_bd_vs_einsum(dev, B, H, M):
                      sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
     assert torch.allclose(bd[:B], bd2, rtol=1e-6, atol=1e-5)
     assert lib().mxl_decode_bd(qr.data_ptr(), rd.data_ptr(), bd.data_ptr(), 65, H, dh, M, d, d, None) < 0     # B > 64: argument error
+
+
+def test_beam_search_matches_oracle(dev):
+    """`model.generate(num_beams=3)` (the reference's 'beam' strategy with do_sample=False, eval.py:302-321) against the oracle's
+    restatement of HF 4.25.1 beam_search + BeamSearchScorer: same best hypothesis per prompt, token for token, and the same
+    length-normalised score.  Weights 3x the init so that beams really compete (at the init scale the distribution is flat);
+    a fork is accepted only where the oracle's own two best continuations are within bf16 noise of each other."""
+    from oracle.transfoxl_ref import ref_beam_search
+    ref, m = _pair(dev, n_layer=2, mem_len=64, max_length=160, seed=13)
+    ref.eval(); m.eval()
+    g = torch.Generator().manual_seed(14)
+    prompt = torch.randint(4, 1190, (2, 20), generator=g)
+    L = 90                                                          # crosses the mem_len = 64 ring boundary
+    want, w_sc = ref_beam_search(ref, prompt, L, num_beams=3, early_stopping=True, return_scores=True)
+    from symbolic_music_generation_amd.generate import XLDecoder, beam_search
+    dec = XLDecoder(m.engine, 2 * 3, L)
+    got, g_sc = beam_search(dec, prompt.to(dev), L, num_beams=3, early_stopping=True, return_scores=True)
+    got = got.cpu()
+    assert got.shape == want.shape and torch.equal(got[:, :20], prompt)
+    print('beam scores (sum log p / len): HIP', g_sc.tolist(), 'oracle', w_sc.tolist())
+    assert (g_sc - w_sc).abs().max().item() < 2e-2
+    same = (got == want).all(1)
+    if not same.all():          # a different hypothesis may win only if it scores the same to within the bf16 envelope
+        for b in (~same).nonzero().flatten().tolist():
+            lp = ref(got[b:b + 1, :-1]).prediction_scores[0]
+            s_got = lp[torch.arange(19, L - 1), got[b, 20:]].sum().item() / L
+            assert abs(s_got - w_sc[b].item()) < 5e-3, (b, s_got, w_sc[b].item())
+    # through the public API, two hypotheses per prompt
+    out = m.generate(input_ids=prompt.to(dev), max_length=60, num_beams=3, num_return_sequences=2, early_stopping=True).cpu()
+    want2 = ref_beam_search(ref, prompt, 60, num_beams=3, early_stopping=True, num_return_sequences=2)
+    assert out.shape == want2.shape == (4, 60)
+    assert (out == want2).float().mean().item() > 0.9
+
+
+def test_beam_sample_and_return_sequences(dev):
+    """beam_sample (the reference's default for strategy='beam': do_sample=True, eval.py:318) and sampling with
+    num_return_sequences: shapes, prompts kept, ids inside the vocabulary, reproducible under the same seed; contrastive search
+    raises the error HF raises for a model without `past_key_values`"""
+    ref, m = _pair(dev, n_layer=2, mem_len=64, max_length=160, seed=13)
+    m.eval()
+    prompt = torch.randint(4, 1190, (2, 12), device=dev)
+    kw = dict(input_ids=prompt, max_length=50, num_beams=3, do_sample=True, top_k=16, temperature=0.9, renormalize_logits=True,
+              early_stopping=True)
+    a = m.generate(**kw, num_return_sequences=2, seed=5)
+    b = m.generate(**kw, num_return_sequences=2, seed=5)
+    c = m.generate(**kw, num_return_sequences=2, seed=6)
+    assert a.shape == (4, 50) and torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(a[:, :12], prompt.repeat_interleave(2, 0)) and (a >= 0).all() and (a < 1190).all()
+    s = m.generate(input_ids=prompt, max_length=40, do_sample=True, num_return_sequences=3)        # HF default top_k = 50
+    assert s.shape == (6, 40) and torch.equal(s[:, :12], prompt.repeat_interleave(3, 0))
+    with pytest.raises(ValueError, match='contrastive search'):
+        m.generate(input_ids=prompt, max_length=40, penalty_alpha=0.6, top_k=4)
+    with pytest.raises(ValueError, match='num_return_sequences'):
+        m.generate(input_ids=prompt, max_length=40, num_return_sequences=2)

@@ -114,3 +114,32 @@ def test_oracle_reproduces_its_committed_selfgolden():
     assert (o2.prediction_scores - blob['logp2'].float()).abs().max().item() < 2e-2
     assert abs(o1.loss.item() - blob['loss1'].item()) < 1e-5 and abs(o2.loss.item() - blob['loss2'].item()) < 1e-5
     assert torch.equal(gen, blob['greedy'])
+
+
+def test_oracle_beam_search_scores_are_sequence_logprobs_and_beat_greedy():
+    """the beam-search restatement (HF 4.25.1 beam_search + BeamSearchScorer): the returned score of every best hypothesis is
+    its generated tokens' summed log-probability under the model divided by the sequence length, it is never below the greedy
+    continuation's, and num_return_sequences hypotheses come out best first"""
+    from oracle.transfoxl_ref import RefXLConfig, RefTransfoXLLMHeadModel, ref_beam_search
+    torch.manual_seed(0)
+    c = RefXLConfig.from_preset('debug', vocab_size=60, max_length=64, mem_len=32, cutoffs=[], n_layer=2)
+    m = RefTransfoXLLMHeadModel(c).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() > 1:
+                p.mul_(4)
+    ids = torch.randint(4, 60, (2, 5))
+    L = 24
+    out, sc = ref_beam_search(m, ids, L, num_beams=3, return_scores=True, num_return_sequences=2)
+    assert out.shape == (4, L) and torch.equal(out[::2, :5], ids) and torch.equal(out[1::2, :5], ids)
+    greedy = m.greedy_generate(ids, L)
+
+    def seq_logp(seq):
+        with torch.no_grad():
+            lp = m(seq[None, :-1]).prediction_scores[0]
+        return lp[torch.arange(4, seq.numel() - 1), seq[5:]].sum().item()
+
+    for b in range(2):
+        best, second = seq_logp(out[2 * b]), seq_logp(out[2 * b + 1])
+        assert abs(best / L - sc[2 * b].item()) < 1e-4 and abs(second / L - sc[2 * b + 1].item()) < 1e-4
+        assert best >= second and best >= seq_logp(greedy[b]) - 1e-4
