@@ -148,6 +148,24 @@ class XLDecoder:
         ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         self._trace()
 
+    # ---------------------------------------------------------------- beam-search hooks (see beam_search below)
+    def beam_prefill(self, prompt: torch.Tensor):
+        self.prefill(prompt, None)
+
+    def beam_logp(self) -> torch.Tensor:
+        return self.logp
+
+    def beam_reorder(self, beam_idx: torch.Tensor):
+        """rows follow their beams: id history and both rings of every layer (HF `_reorder_cache`: index_select on the mems)"""
+        self.ids.copy_(self.ids.index_select(0, beam_idx))
+        for ring in self.kc + self.vc:
+            ring.copy_(ring.index_select(0, beam_idx))
+
+    def beam_advance(self, cur_len: int):
+        """the token at position cur_len - 1 through the model -> log-probs of position cur_len"""
+        self.t_dev.fill_(cur_len - 1)
+        self._forward_token()
+
     def _trace(self):
         if self.trace is not None:
             self.trace.index_copy_(1, self.t_dev.to(torch.int64), self.logp.unsqueeze(1))
@@ -225,13 +243,14 @@ class _BeamHyps:
         return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
-def beam_search(dec: XLDecoder, prompt: torch.Tensor, max_length: int, num_beams: int = 3, do_sample: bool = False,
+def beam_search(dec, prompt: torch.Tensor, max_length: int, num_beams: int = 3, do_sample: bool = False,
                 top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: float = 1.0,
                 typical_p: Optional[float] = None, early_stopping: bool = True, length_penalty: float = 1.0,
                 num_return_sequences: int = 1, eos_token_id: int = 0, pad_token_id: Optional[int] = None,
                 renormalize_logits: bool = True, generator: Optional[torch.Generator] = None, return_scores: bool = False):
     """HF 4.25.1 `beam_search` (do_sample=False) / `beam_sample` (do_sample=True) with `BeamSearchScorer.process / finalize`,
-    as `model.generate(num_beams=...)` reaches them from musicnlp/trainer/eval.py:302-333.  `dec` holds one row per beam:
+    as `model.generate(num_beams=...)` reaches them from musicnlp/trainer/eval.py:302-333.  `dec` is an XLDecoder or an
+    rf_generate.RFDecoder (anything with beam_prefill / beam_logp / beam_reorder / beam_advance and `ids`) with one row per beam:
     B * num_beams rows (times num_return_sequences for beam_sample, as HF expands).  Per step: the device computes the
     log-probabilities of every beam's next token (the same kernels as `step`), the 2 * num_beams best (or sampled) continuations
     per item are taken on the device, the scorer's walk over them runs on the host (it is a data-dependent loop over a handful
@@ -252,7 +271,7 @@ def beam_search(dec: XLDecoder, prompt: torch.Tensor, max_length: int, num_beams
     if dec.B != rows or max_length > dec.Tmax:
         raise MusicXLError(f'the decoder was built for {dec.B} rows x {dec.Tmax} positions, beam search needs {rows} x {max_length}')
     expanded = prompt.repeat_interleave(rows // B0, 0).to(dev)
-    dec.prefill(expanded, None)
+    dec.beam_prefill(expanded)
     beam_scores = torch.zeros(Bs, nb, device=dev)
     beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(-1)
@@ -261,7 +280,7 @@ def beam_search(dec: XLDecoder, prompt: torch.Tensor, max_length: int, num_beams
     cur_len = Tp
     ident = torch.arange(rows, device=dev)
     while True:
-        sc = dec.logp + beam_scores[:, None]
+        sc = dec.beam_logp() + beam_scores[:, None]
         if do_sample:              # HF beam_sample: warp log p + beam score, renormalise, draw 2 * num_beams, sort
             sc = _warp(sc, top_k, top_p, typical_p, temperature, min_keep=2, renormalize=renormalize_logits)
             flat = sc.view(Bs, nb * V)
@@ -293,16 +312,13 @@ def beam_search(dec: XLDecoder, prompt: torch.Tensor, max_length: int, num_beams
             done[b] = done[b] or hyps[b].is_done(max(top_sl[b]), cur_len)
         beam_scores = torch.tensor(n_s, device=dev).view(-1)
         beam_idx = torch.tensor(n_i, device=dev).view(-1)
-        if not torch.equal(beam_idx, ident):          # rows follow their beams: id history and both rings of every layer
-            dec.ids.copy_(dec.ids.index_select(0, beam_idx))
-            for ring in dec.kc + dec.vc:
-                ring.copy_(ring.index_select(0, beam_idx))
+        if not torch.equal(beam_idx, ident):
+            dec.beam_reorder(beam_idx)
         dec.ids[:, cur_len] = torch.tensor(n_t, device=dev).view(-1)
         cur_len += 1
         if all(done) or cur_len >= max_length:
             break
-        dec.t_dev.fill_(cur_len - 1)
-        dec._forward_token()
+        dec.beam_advance(cur_len)
     final = beam_scores.tolist()
     for b in range(Bs):
         if done[b]:

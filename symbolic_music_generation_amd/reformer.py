@@ -98,6 +98,10 @@ class ReformerModelWithLMHeadOutput:
         return tuple(v for v in (self.loss, self.logits) if v is not None)[k]
 
 
+def c_max_len(cfg) -> int:
+    return cfg.axial_pos_shape[0] * cfg.axial_pos_shape[1]
+
+
 class MyReformerModelWithLMHead(EngineModule):
     """`torch.nn.Module` over `RFEngine` (see module.EngineModule): HF's state-dict names, autograd-connected loss."""
     cls_name = 'Reformer'
@@ -159,10 +163,35 @@ class MyReformerModelWithLMHead(EngineModule):
         if unsupported.get('penalty_alpha') and not do_sample and top_k is not None and top_k > 1:
             raise ValueError(f'{type(self).__name__} does not support caching through `past_key_values` and therefore '
                              "**can't** be used for contrastive search (the message HF 4.25.1 raises for this model)")
-        if unsupported.get('num_return_sequences', 1) not in (None, 1):
+        if unsupported.get('num_return_sequences', 1) not in (None, 1) and (unsupported.get('num_beams', 1) or 1) == 1:
             if not do_sample:
                 raise ValueError('num_return_sequences has to be 1 when doing greedy search')
             input_ids = input_ids.repeat_interleave(int(unsupported.pop('num_return_sequences')), 0)
+        num_beams = unsupported.pop('num_beams', 1) or 1
+        if unsupported.get('num_beam_groups', 1) not in (None, 1):
+            raise NotImplementedError('diverse (group) beam search is not implemented on the HIP decode path')
+        if num_beams > 1:
+            # the reference's 'beam' strategy (eval.py:302-321): HF beam_search / beam_sample over the cached decoder
+            from .generate import beam_search
+            from .rf_generate import RFDecoder
+            nrs = int(unsupported.pop('num_return_sequences', 1) or 1)
+            self._maybe_resync()
+            was = self.training
+            self.eval()
+            try:
+                max_length = int(max_length or c_max_len(self.config))
+                dec = RFDecoder(self.engine, input_ids.shape[0] * num_beams * (nrs if do_sample else 1), max_length,
+                                rotations=rotations, seed=seed)
+                gen = torch.Generator(device=self.device).manual_seed(seed) if do_sample else None
+                return beam_search(dec, input_ids, max_length, num_beams=num_beams, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                                   temperature=temperature, typical_p=typical_p,
+                                   early_stopping=bool(unsupported.get('early_stopping')),
+                                   length_penalty=float(unsupported.get('length_penalty', 1.0) or 1.0),
+                                   renormalize_logits=bool(unsupported.get('renormalize_logits')), num_return_sequences=nrs,
+                                   eos_token_id=self.config.eos_token_id, pad_token_id=self.config.pad_token_id, generator=gen)
+            finally:
+                if was:
+                    self.train()
         if unsupported:
             ok = {'early_stopping', 'renormalize_logits'}      # no effect: eos never ends a row; the sampler always renormalises
             bad = [k for k, v in unsupported.items() if k not in ok and v not in (None, False, 1, 1.0)]

@@ -134,6 +134,9 @@ class RFDecoder:
     def _sample(self, logits, sampling):
         if self.trace is not None:
             self.trace.index_copy_(1, self.t_dev.to(torch.int64), logits[:, :self.trace.shape[-1]].unsqueeze(1))
+        self._last = logits
+        if sampling is None:                 # the caller picks the token (beam search)
+            return
         ops.sample(logits[:, :self.eng.cfg.vocab_size], self.ids, self.t_dev, self.rng, self.seed, **sampling)
         ops.decode_advance(self.t_dev, self.rng)
 
@@ -215,6 +218,27 @@ class RFDecoder:
         V = c.vocab_size
         ops.gemm_skinny(self.hcat, head_w, self.logits, B, V, 2 * d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.p32('lm_head.bias'))
         self._sample(self.logits, sampling)
+
+    # ---------------------------------------------------------------- beam-search hooks (generate.beam_search)
+    def beam_prefill(self, prompt: torch.Tensor):
+        self.prefill(prompt, None)
+
+    def beam_logp(self) -> torch.Tensor:
+        return torch.log_softmax(self._last[:, :self.eng.cfg.vocab_size].float(), -1)
+
+    def beam_reorder(self, beam_idx: torch.Tensor):
+        """rows follow their beams: id history, the projection caches and the bucket ids of every cached position"""
+        H = self.eng.cfg.num_attention_heads
+        self.ids.copy_(self.ids.index_select(0, beam_idx))
+        for cache in self.kc + self.vc:
+            cache.copy_(cache.index_select(0, beam_idx))
+        for l, bk in self.bk.items():
+            v = bk.view(self.B, H, self.n_h, self.Tmax)
+            v.copy_(v.index_select(0, beam_idx))
+
+    def beam_advance(self, cur_len: int):
+        self.t_dev.fill_(cur_len - 1)
+        self.step(cur_len - 1, None)
 
     # ---------------------------------------------------------------- loop
     @torch.no_grad()

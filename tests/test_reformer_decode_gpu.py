@@ -119,3 +119,48 @@ def test_generate_api_cached_vs_full_forward_local_only(dev):
     assert agree > 0.95          # bf16 near-ties fork a row now and then; with these weights the rows re-converge
     s = m.generate(input_ids=prompt, max_length=120, do_sample=True, top_k=8, temperature=0.9)
     assert s.shape == (4, 120) and (s >= 0).all() and (s < 120).all() and torch.equal(s[:, :37], prompt)
+
+
+def test_beam_search_over_the_cached_decoder(dev):
+    """`generate(num_beams=3)` on the Reformer (the reference's 'beam' strategy, eval.py:302-321) runs generate.beam_search over
+    RFDecoder rows.  The scorer itself is checked against the oracle on the TransfoXL side (tests/test_decode_gpu.py); here: the
+    best hypothesis' score is the summed log-probability of its tokens under the same cached decoding (teacher-forced through a
+    fresh decoder) over its length, it is not below the greedy continuation's, prompts are kept, two hypotheses come best first."""
+    from symbolic_music_generation_amd.generate import beam_search
+    from symbolic_music_generation_amd.rf_generate import RFDecoder
+    blob = _load('gen_padded')
+    m = _model(dev, blob)
+    rot = blob['rotations']
+    g = torch.Generator().manual_seed(3)
+    V = m.config.vocab_size
+    prompt = torch.cat([blob['prompt'], torch.randint(4, V, blob['prompt'].shape, generator=g)], 0)
+    B, Tp = prompt.shape
+    L = min(Tp + 60, 140)
+    dec = RFDecoder(m.engine, B * 3, L, rotations={l: r.clone() for l, r in rot.items()})
+    with torch.no_grad():
+        # eos disabled (-1 is never produced): every hypothesis runs to L, so that scores compare at equal length
+        out, sc = beam_search(dec, prompt.to(dev), L, num_beams=3, early_stopping=True, eos_token_id=-1, pad_token_id=0,
+                              return_scores=True)
+    out = out.cpu()
+    assert out.shape == (B, L) and torch.equal(out[:, :Tp], prompt)
+
+    def score(seqs):
+        got, _ = _forced_decode(dev, m, prompt, seqs, rot)            # logits of steps Tp-1 .. L-2
+        lp = torch.log_softmax(got.float(), -1)
+        return lp.gather(-1, seqs[:, Tp:, None]).squeeze(-1).sum(1) / L
+
+    s_beam = score(out)
+    greedy = m.generate(input_ids=prompt.to(dev), max_length=L, do_sample=False, rotations=rot).cpu()
+    s_greedy = score(greedy)
+    print('reformer beam: returned', sc.tolist(), 'teacher-forced', s_beam.tolist(), 'greedy', s_greedy.tolist())
+    assert (s_beam - sc).abs().max().item() < 2e-2
+    assert (s_beam >= s_greedy - 2e-2).all()
+    # through the public API with the config's eos (a hypothesis ends when it draws it; shorter rows are padded, as HF pads)
+    two = m.generate(input_ids=prompt.to(dev), max_length=L, num_beams=3, num_return_sequences=2, early_stopping=True,
+                     rotations=rot).cpu()
+    dec2 = RFDecoder(m.engine, B * 3, L, rotations={l: r.clone() for l, r in rot.items()})
+    with torch.no_grad():
+        want = beam_search(dec2, prompt.to(dev), L, num_beams=3, early_stopping=True, num_return_sequences=2,
+                           eos_token_id=m.config.eos_token_id, pad_token_id=m.config.pad_token_id).cpu()
+    assert two.shape == want.shape and two.shape[0] == 2 * B and torch.equal(two, want)
+    assert torch.equal(two[::2, :Tp], prompt) and torch.equal(two[1::2, :Tp], prompt)
