@@ -166,6 +166,12 @@ int mxl_adaptive_nll_fwd(const float* logits, int ldl, const void* labels, float
 int mxl_adaptive_nll_bwd(const float* logits, int ldl, const void* labels, const float* nll, const float* lse,
                          const float* acc2, void* dlogits, int ldd, int B, int T, int V, int ncl,
                          const int* cutoffs_host, float grad_scale, void* stream);
+/* the same gradient as a two-term bf16 sum: dlogits_hi = bf16(d), dlogits_lo = bf16(d - dlogits_hi).  The consumers (the head's
+ * input-gradient and weight-gradient GEMMs, the bias column sum) run once per term and accumulate: a confident prediction of a
+ * token that is not the label has d near 1 / count, where one bf16 term is too coarse for sums over tokens that cancel. */
+int mxl_adaptive_nll_bwd_split(const float* logits, int ldl, const void* labels, const float* nll, const float* lse,
+                               const float* acc2, void* dlogits_hi, void* dlogits_lo, int ldd, int B, int T, int V, int ncl,
+                               const int* cutoffs_host, float grad_scale, void* stream);
 /* labels=None branch: out (N, ldo) f32 full log-probabilities over the V tokens */
 int mxl_adaptive_logprob(const float* logits, int ldl, float* out, int ldo, int N, int V, int ncl,
                          const int* cutoffs_host, void* stream);

@@ -107,20 +107,29 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logits, int l
     }
 }
 
-// dlogits (bf16, ld = ldd, pad columns zeroed) for loss = sum(nll[nll != 0]) / count  (transformer_xl.py:200)
+// dlogits (bf16, ld = ldd, pad columns zeroed) for loss = sum(nll[nll != 0]) / count  (transformer_xl.py:200).
+// dlo (optional, same shape): the bf16 remainder d - bf16(d).  A probability near 1 on a token that is NOT the label (an
+// untrained tied-embedding model predicts its own input) is a logit gradient near 1/count whose bf16 spacing, 2^-8 relative,
+// is as large as the quantity the column sums of dlogits are made of (sum_t p_t[v] - count_t[label = v]: two nearly equal
+// numbers); with the remainder carried as a second bf16 term the GEMMs and column sums that consume dlogits see it to 2^-16.
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* logits, int ldl, const long long* labels,
                                                       const float* nll, const float* lse_in, const float* acc,
-                                                      bf16_t* dlogits, int ldd, int B, int T, HeadGeom g, float gscale) {
+                                                      bf16_t* dlogits, bf16_t* dlo, int ldd, int B, int T, HeadGeom g,
+                                                      float gscale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * T) return;
     const int lane = threadIdx.x & 63;
     const int b = row / T, t = row % T;
     bf16_t* dr = dlogits + (size_t)row * ldd;
+    bf16_t* dl = dlo ? dlo + (size_t)row * ldd : nullptr;
     long long lab = -100;
     float v = 0.f;
     if (t < T - 1) { lab = labels[(size_t)b * T + t + 1]; v = nll[(size_t)b * (T - 1) + t]; }
     if (lab < 0 || lab >= g.V || v == 0.f) {
-        for (int j = lane; j < ldd; j += 64) dr[j] = 0;
+        for (int j = lane; j < ldd; j += 64) {
+            dr[j] = 0;
+            if (dl) dl[j] = 0;
+        }
         return;
     }
     const float cnt = fmaxf(acc[1], 1.f);
@@ -139,7 +148,9 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* logits, int l
         } else if (ci > 0 && j >= g.cut[ci] && j < g.cut[ci + 1]) {
             d = __expf(lr[j] - tail_lse) - (j == lab ? 1.f : 0.f);
         }
-        dr[j] = f2bf(d * gs);
+        const bf16_t hi = f2bf(d * gs);
+        dr[j] = hi;
+        if (dl) dl[j] = f2bf(d * gs - bf2f(hi));
     }
 }
 
@@ -203,7 +214,22 @@ extern "C" int mxl_adaptive_nll_bwd(const float* logits, int ldl, const void* la
     if (rc) return rc;
     MXL_CHECK_ARG(ldl >= V + ncl && ldd >= V + ncl);
     hipLaunchKernelGGL(nll_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
-                       (const long long*)labels, nll, lse, acc2, (bf16_t*)dlogits, ldd, B, T, g, grad_scale);
+                       (const long long*)labels, nll, lse, acc2, (bf16_t*)dlogits, (bf16_t*)nullptr, ldd, B, T, g, grad_scale);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_adaptive_nll_bwd_split(const float* logits, int ldl, const void* labels, const float* nll, const float* lse,
+                                          const float* acc2, void* dlogits_hi, void* dlogits_lo, int ldd, int B, int T, int V,
+                                          int ncl, const int* cutoffs_host, float grad_scale, void* stream) {
+    MXL_CHECK_ARG(logits && labels && nll && lse && acc2 && dlogits_hi && dlogits_lo && B > 0 && T > 1);
+    HeadGeom g;
+    int rc = make_geom(g, V, ncl, cutoffs_host);
+    if (rc) return rc;
+    MXL_CHECK_ARG(ldl >= V + ncl && ldd >= V + ncl);
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+                       (const long long*)labels, nll, lse, acc2, (bf16_t*)dlogits_hi, (bf16_t*)dlogits_lo, ldd, B, T, g,
+                       grad_scale);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -201,8 +201,15 @@ def adaptive_nll_fwd(logits, labels, nll, lse, acc2, B, T, V, cutoffs=()):
           'mxl_adaptive_nll_fwd')
 
 
-def adaptive_nll_bwd(logits, labels, nll, lse, acc2, dlogits, B, T, V, cutoffs=(), grad_scale=1.0):
+def adaptive_nll_bwd(logits, labels, nll, lse, acc2, dlogits, B, T, V, cutoffs=(), grad_scale=1.0, dlogits_lo=None):
     n, arr = _cut(cutoffs)
+    if dlogits_lo is not None:          # two-term form: dlogits + dlogits_lo carries the gradient to 2^-16
+        assert dlogits_lo.shape == dlogits.shape and dlogits_lo.stride(0) == dlogits.stride(0)
+        check(lib().mxl_adaptive_nll_bwd_split(_p(logits), logits.stride(0), _p(labels), _p(nll), _p(lse), _p(acc2), _p(dlogits),
+                                               _p(dlogits_lo), dlogits.stride(0), B, T, V, n,
+                                               C.cast(arr, C.c_void_p) if arr is not None else None, float(grad_scale),
+                                               _stream()), 'mxl_adaptive_nll_bwd_split')
+        return
     check(lib().mxl_adaptive_nll_bwd(_p(logits), logits.stride(0), _p(labels), _p(nll), _p(lse), _p(acc2), _p(dlogits),
                                      dlogits.stride(0), B, T, V, n,
                                      C.cast(arr, C.c_void_p) if arr is not None else None, float(grad_scale), _stream()),

@@ -235,6 +235,7 @@ class XLEngine:
             ws.d_rd16 = torch.empty(M, d, **bf)
             ws.phi_c = torch.empty(M, d, **bf)
             ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
+            ws.dlogits_lo = torch.empty(N, self.layout.head_rows_padded, **bf)
         ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32)
         ws.nll = torch.empty(B, max(T - 1, 1), **f32)
         ws.hlse = torch.empty(N, 2, **f32)
@@ -378,15 +379,20 @@ class XLEngine:
             return self._lw(l, suffix, G)
 
         # ---- head
-        ops.adaptive_nll_bwd(ws.logits, ws.labels, ws.nll, ws.hlse, ws.acc, ws.dlogits, B, T, V, cut, grad_scale)
+        # the logit gradient travels as a two-term bf16 sum (mxl_adaptive_nll_bwd_split): every consumer runs once per term and
+        # accumulates -- the small term first where the output is rounded (the input gradient), so that it is rounded once
+        ops.adaptive_nll_bwd(ws.logits, ws.labels, ws.nll, ws.hlse, ws.acc, ws.dlogits, B, T, V, cut, grad_scale,
+                             dlogits_lo=ws.dlogits_lo)
         head_w = self.W[:nrow_p * d].view(nrow_p, d)
         g_head_w = G[:nrow_p * d].view(nrow_p, d)
         boff = self.layout.entries['crit.out_layers.0.bias'][0]
-        ops.colsum(ws.dlogits, G[boff:boff + nrow], N, nrow)
-        ops.gemm(ws.dlogits, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
-                 ksplits=self._ks(nrow_p, d, N))
         dy, dy2 = ws.dA, None
-        ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True)
+        for term in (ws.dlogits_lo, ws.dlogits):
+            ops.colsum(term, G[boff:boff + nrow], N, nrow)
+            ops.gemm(term, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
+                     ksplits=self._ks(nrow_p, d, N))
+        ops.gemm(ws.dlogits_lo, head_w, dy, N, d, nrow_p, trans_b=True)
+        ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True, flags=F.GEMM_ADD_AUX, aux=dy)
         if p > 0:
             ops.dropout(dy, dy, p, seed=seed, site=self.SITE_FINAL)
         st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,

@@ -458,6 +458,44 @@ def test_c2_train_step_gradients_vs_oracle(dev):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('with_mem', [False, True])
+def test_c3_shape_two_layer_gradients_vs_oracle(dev, with_mem):
+    """The C3 layer shapes exactly as the bench runs them (768d / H12 / dh64 / F3072, T = M = 2048, V = 1190) in a TWO-layer model,
+    so that the oracle's autograd fits the host comfortably (the 12-layer step needs ~25 GB): loss and every parameter's gradient,
+    B = 1, (a) mode R -- no carried mems, the reference's training, half of every window is phantom distances -- and (b) with
+    2048 carried memory rows per layer (Kc = 4096: the attention kernels' other regime).  Same limits as the small shapes, with
+    one documented exception: an untrained model with tied embeddings predicts its own INPUT token with p near 1 while the label
+    is the next token, so the column sums over tokens of the logit gradient (sum_t p_t[v] - count_t[label = v]) are differences of
+    nearly equal numbers.  The output bias gradient is such a sum -- exact here because the logit gradient is carried as a two-term
+    bf16 sum (mxl_adaptive_nll_bwd_split; with one term it was 20 % off) -- and so is the last LayerNorm's bias gradient,
+    sum_t dh_t, whose terms are rounded to bf16 per token: 7 % / cosine 0.997 measured, limit 10 % / 0.995."""
+    ref, m = _oracle_pair(dev, 'base', 2, T, M, seed=41, wscale=1.0)
+    ref.train(); m.train()
+    g = torch.Generator().manual_seed(42)
+    ids = torch.randint(4, V, (1, T), generator=g)
+    lab = ids.clone(); lab[0, T - 100:] = -100
+    mems_r = mems_h = None
+    if with_mem:
+        mems_r = [(torch.randn(M, 1, D, generator=g) * 0.5).to(torch.bfloat16).float() for _ in range(2)]
+        mems_h = [x.to(dev) for x in mems_r]
+    ro = ref(ids, labels=lab, mems=mems_r)
+    ro.loss.backward()
+    m.zero_grad()
+    o = m(input_ids=ids.to(dev), labels=lab.to(dev), mems=mems_h)
+    m.backward()
+    torch.cuda.synchronize()
+    assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-3
+    last_ln_bias = 'transformer.layers.1.pos_ff.layer_norm.bias'
+    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (0.10, 0.995) if k == last_ln_bias else (0.06, 0.998)
+    bad, worst = _grad_table([(n, p.grad) for n, p in ref.named_parameters() if n != last_ln_bias], m.engine, lim,
+                             skip=('crit.out_layers.0.weight',))
+    bad2, w2 = _grad_table([(last_ln_bias, dict(ref.named_parameters())[last_ln_bias].grad)], m.engine, lim)
+    bad.update(bad2)
+    print(f'C3-shape 2-layer gradients vs oracle (mems: {with_mem}): worst rel {worst[0]:.4f}, worst cosine {worst[1]:.5f}; '
+          f'last LayerNorm bias {w2[0]:.4f} / {w2[1]:.5f}')
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('wscale', [1.0, 4.0])
 def test_c4_reformer_train_step_gradients_vs_oracle(dev, wscale):
     """SURVEY C4 at full size, one training step's backward: Reformer 6L / 512d (3 local + 3 LSH), T = 8192, B = 1, dropout 0 --
