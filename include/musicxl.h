@@ -110,6 +110,22 @@ int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd,
 int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs,
                     int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, float* d_r_w_bias_fix, void* stream);
 
+/* The pair that keeps phantom distances out of HBM (dh = 64, M % 256 == 0, T % 32 == 0).  With fresh zero memories -- the
+ * reference's training: HF Trainer never carries mems, so TransfoXLModel.init_mems supplies zeros every step -- the key positions
+ * before the first stored one have k = v = 0 and their score gradient depends on the distance alone:
+ *     dG[b,h,i,d] = -scale * delta[b,h,i] * exp(scale * (q + r_r_bias)[b,i,h,:] . rd[d,h,:] - lse[b,h,i]).
+ * mxl_relattn_bwd_sparse_dg = mxl_relattn_bwd with d_r_r_bias = NULL that leaves every (32 queries x 256 distances) block of dg
+ * lying entirely on such distances UNWRITTEN; mxl_relattn_drd_recompute = mxl_relattn_drd that rebuilds exactly those blocks on
+ * MFMA from qr, rd, lse and delta (the buffers mxl_relattn_bwd read / wrote) instead of streaming them.  Half of dg in mode R. */
+int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                              const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta, void* dq,
+                              void* dk, void* dv, void* dg, float* d_r_w_bias, int B, int T, int H, int dh, int M, int Kc,
+                              long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                              long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream);
+int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs,
+                              int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, float* d_r_w_bias_fix,
+                              const float* lse, const float* delta, float scale, int Kc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.
  * ---------------------------------------------------------------------------------------------------------- */

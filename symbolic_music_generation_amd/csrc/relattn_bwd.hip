@@ -37,6 +37,9 @@ struct BwdP {
     long long q_bs, kv_bs, o_bs, dq_bs, dkv_bs;
     int q_rs, kv_rs, rd_rs, o_rs, dq_rs, dkv_rs;
     float scale, scale_log2e;
+    // 8-wave query-owner kernel only: do not store dG for 32-distance blocks whose 256-distance block lies entirely on phantom
+    // distances of the wave's 32 queries -- mxl_relattn_drd_recompute rebuilds exactly those cells itself
+    int dg_skip_phantom;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -762,7 +765,10 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                             *reinterpret_cast<u32x2*>(myDG + 8 * grp + 4 * hh) = w;
                         }
                     } else {
-                        if (dgrow && (M & 7) == 0) {
+                        // wave-uniform: the whole 256-distance block is phantom for all 32 queries -> the dRd kernel recomputes it
+                        const bool skipdg = p.dg_skip_phantom && ((dblk & ~255) > iw0 + 31 - pz);
+                        if (skipdg) {
+                        } else if (dgrow && (M & 7) == 0) {
                             // lanes l and l + 32 (same query, distance groups 4 apart) trade one packed quad each, so that every
                             // lane stores 8 consecutive distances with one 16-byte store instead of two 8-byte ones (the store
                             // path's cost is per instruction and per row segment: scripts/ubench/stores.hip)
@@ -1358,6 +1364,9 @@ struct DrdP {
     // optional: d r_r_bias[h, :] += colsum_i(dG)[delta] . Rd[delta, h, :], and the same amount is taken OUT of d_rwb (the 8-wave
     // query-owner kernel leaves d r_w_bias + d r_r_bias there)
     const bf16_t* rd; int rd_rs; float* d_rrb; float* d_rwb;
+    // recompute form (mxl_relattn_drd_recompute): the cells the query-owner kernel did not store are phantom distances, whose
+    // score gradient needs no K / V:  dG[i, d] = -scale * delta_i * exp(scale * (q_i + r_r_bias) . Rd[d] - lse_i)
+    const float* lse; const float* delta; float scale; int pz; int recompute;
 };
 constexpr int DRD_A = 32 * 512;        // dG tile  [32 i][256 delta] bf16
 constexpr int DRD_B = 32 * 128;        // Qr tile  [32 i][64 e] bf16
@@ -1372,32 +1381,14 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     int bx_, h, bz_;
     xcd_block(bx_, h, bz_);      // the distance blocks of one (head, batch group) read the same Qr tiles: keep them on one XCD
-    const int d0 = bx_ * 256, b0 = bz_ * p.bgroup;
+    const int b0 = bz_ * p.bgroup;
     const int nb = min(p.bgroup, p.B - b0);
     const int spb = p.T >> 5;                       // 32-row steps per batch item
-    const int S = nb * spb;
 
-    // dG tile: DMA instruction j (0..3) of wave w fills rows 2(4j + w), +1 (512-byte rows): lane -> row l >> 5, 16-byte slot
-    // l & 31; slot s of row k holds source block ((s >> 1) ^ drd_swzA(k)), half s & 1.  Qr tile: one instruction per wave, rows
-    // 8w .. 8w+7 (128-byte rows): lane -> row l >> 3, slot l & 7, block ((s >> 1) ^ (k & 3)).
-    int arow[4], acol[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        arow[j] = 2 * (4 * j + wid) + (l >> 5);
-        acol[j] = min(d0 + ((((l & 31) >> 1) ^ drd_swzA(arow[j])) << 4) + ((l & 1) << 3), p.M - 8);
-    }
+    // Qr tile: one DMA instruction per wave, rows 8w .. 8w+7 (128-byte rows): lane -> row l >> 3, slot l & 7, block
+    // ((s >> 1) ^ (k & 3)).
     const int brow = 8 * wid + (l >> 3);
     const int bcol = ((((l & 7) >> 1) ^ (brow & 3)) << 4) + ((l & 1) << 3);
-    auto issue = [&](int g) {
-        char* st = smem + (g & 3) * DRD_STAGE;
-        const int b = b0 + g / spb, i0 = (g % spb) << 5;
-        const bf16_t* a = p.dg + (((size_t)b * p.H + h) * p.T + i0) * (size_t)p.M;
-        const bf16_t* q = p.qr + (size_t)b * p.qr_bs + (size_t)i0 * p.qr_rs + (size_t)h * 64;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a + (size_t)arow[j] * p.M + acol[j]), (lptr_t)(st + (4 * j + wid) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(q + (size_t)brow * p.qr_rs + bcol), (lptr_t)(st + DRD_A + wid * 1024), 16, 0, 0);
-    };
     // transposed fragments for v_mfma_f32_16x16x32_bf16 (one K-step = 32 rows): lane (g = l >> 4, q = (l & 15) >> 2, pp = l & 3)
     // addresses k-row 8g + q, columns rb + 4pp..+3; rows +0 / +4 give the lane its 8 k-values of output row rb + (l & 15)
     const int fk = 8 * (l >> 4) + ((l & 15) >> 2);
@@ -1413,6 +1404,35 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a + pitch4));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
+    const bool want_rrb = p.d_rrb != nullptr;
+    const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+    const int d0 = bx_ * 256;
+    // tiles [0, nph) of every batch item lie entirely on phantom distances for this 256-distance block (i0 + 31 - pz < d0, the
+    // rule by which the query-owner kernel skipped their dG stores): recomputed below; the others are streamed
+    const int nph = p.recompute ? max(0, min(spb, (d0 + p.pz) >> 5)) : 0;
+    const int nst = spb - nph;
+    const int S = nb * nst;
+
+    // dG tile: DMA instruction j (0..3) of wave w fills rows 2(4j + w), +1 (512-byte rows): lane -> row l >> 5, 16-byte slot
+    // l & 31; slot s of row k holds source block ((s >> 1) ^ drd_swzA(k)), half s & 1.
+    int arow[4], acol[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        arow[j] = 2 * (4 * j + wid) + (l >> 5);
+        acol[j] = min(d0 + ((((l & 31) >> 1) ^ drd_swzA(arow[j])) << 4) + ((l & 1) << 3), p.M - 8);
+    }
+    auto issue = [&](int g) {
+        char* st = smem + (g & 3) * DRD_STAGE;
+        const int b = b0 + g / nst, i0 = (nph + g % nst) << 5;
+        const bf16_t* a = p.dg + (((size_t)b * p.H + h) * p.T + i0) * (size_t)p.M;
+        const bf16_t* q = p.qr + (size_t)b * p.qr_bs + (size_t)i0 * p.qr_rs + (size_t)h * 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a + (size_t)arow[j] * p.M + acol[j]), (lptr_t)(st + (4 * j + wid) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(q + (size_t)brow * p.qr_rs + bcol), (lptr_t)(st + DRD_A + wid * 1024), 16, 0, 0);
+    };
 
     f32x4 acc[4][4], accs[4];          // accs: dG^T . 1 = column sums of dG over i (every output column the same)
 #pragma unroll
@@ -1421,17 +1441,119 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bool want_rrb = p.d_rrb != nullptr;
-    const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-    issue(0);
-    if (S > 1) issue(1);
-    if (S > 2) issue(2);
-    if (S > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (S > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // ---- recomputed tiles.  A step needs only the [32 i][64 e] Qr tile and lse / delta of its 32 queries (a 4-byte DMA into
+    // this wave's own 256 bytes), 5 KB: the 80 KB of LDS hold sixteen such stages, loads run twelve steps ahead.
+    // G[i, delta] = Qr . Rd^T on MFMA with the wave's 64 Rd rows held in registers for the whole pass, dG from the
+    // accumulators -- whose layout, lane = delta with rows i = 4 (l >> 4) + r of the two 16-row halves, IS the A operand of the
+    // contraction once the Qr^T fragments are read in that same k order (k-rows 4g + q and 16 + 4g + q instead of 8g + q and
+    // 8g + 4 + q): no LDS round trip, no HBM bytes.
+    const int SA = nb * nph;
+    if (SA > 0) {
+        constexpr int STA = 5120, NSTA = 16, PA = 12;      // stage bytes (4 KB Qr + 4 x 256 B), stages, prefetch distance
+        static_assert(STA * NSTA <= DRD_SMEM, "recompute ring exceeds the kernel's LDS");
+        const int gq = l >> 4, q4 = (l & 15) >> 2;
+        bf16x8 rdf[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int dd = min(d0 + 64 * wid + 16 * f + (l & 15), p.M - 1);
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.rd + (size_t)dd * p.rd_rs + h * 64 + 32 * ks + 8 * gq);
+                // scale * log2(e) rides on the Rd operand (the attention kernels put it on the query operand: the same single
+                // bf16 rounding of one factor), so the MFMA result is the exponent and -lse enters as the accumulator's start
+#pragma unroll
+                for (int j = 0; j < 8; j++) rdf[f][ks][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * (p.scale * LOG2E));
+            }
+        int qo[2][2], bo2[4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int row = 16 * t + (l & 15), blk = 2 * ks + (gq >> 1);
+                qo[t][ks] = row * 128 + ((blk ^ (row & 3)) << 5) + ((gq & 1) << 4);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int fk2 = 4 * gq + q4, cb = 16 * t + 4 * (l & 3);
+            bo2[t] = fk2 * 128 + (((cb >> 4) ^ (fk2 & 3)) << 5) + ((cb & 15) << 1);
+        }
+        auto issueA = [&](int g) {
+            char* st = smem + (g & (NSTA - 1)) * STA;
+            const int b = b0 + g / nph, i0 = (g % nph) << 5;
+            const bf16_t* q = p.qr + (size_t)b * p.qr_bs + (size_t)i0 * p.qr_rs + (size_t)h * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t)(q + (size_t)brow * p.qr_rs + bcol), (lptr_t)(st + wid * 1024), 16, 0, 0);
+            const size_t row = ((size_t)b * p.H + h) * p.T + i0 + (l & 31);
+            const float* src = (l < 32) ? p.lse + row : p.delta + row;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + 4096 + wid * 256), 4, 0, 0);
+        };
+        const float nsc = -p.scale;
+        for (int g = 0; g < min(PA, SA); g++) issueA(g);
+        if (SA > PA) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");      // 2 (PA - 1): step 0 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int g = 0; g < SA; g++) {
+            // stage (g + PA) % 16 was last read in step g + PA - 16 < g: every wave passed that step's barrier long ago
+            const bool issued = g + PA < SA;
+            if (issued) issueA(g + PA);
+            const char* st = smem + (g & (NSTA - 1)) * STA;
+            const float* sv = reinterpret_cast<const float*>(st + 4096 + wid * 256);
+            const f32x4 ls0 = *reinterpret_cast<const f32x4*>(sv + 4 * gq), ls1 = *reinterpret_cast<const f32x4*>(sv + 16 + 4 * gq);
+            const f32x4 dl0 = *reinterpret_cast<const f32x4*>(sv + 32 + 4 * gq), dl1 = *reinterpret_cast<const f32x4*>(sv + 48 + 4 * gq);
+            float l0[4], l1[4], n0[4], n1[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { l0[r] = -ls0[r] * LOG2E; l1[r] = -ls1[r] * LOG2E; n0[r] = nsc * dl0[r]; n1[r] = nsc * dl1[r]; }
+            bf16x8 qa[2][2], fb[4];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) qa[t][ks] = *reinterpret_cast<const bf16x8*>(st + qo[t][ks]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) fb[t] = trfrag(st + bo2[t], 16 * 128);
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                f32x4 c0 = {l0[0], l0[1], l0[2], l0[3]}, c1 = {l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[0][ks]),
+                                                                 __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[1][ks]),
+                                                                 __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), c1, 0, 0, 0);
+                }
+                float g0[4], g1[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    g0[r] = __builtin_amdgcn_exp2f(c0[r]) * n0[r];
+                    g1[r] = __builtin_amdgcn_exp2f(c1[r]) * n1[r];
+                }
+                const u32x4 fw = {pack2bf(g0[0], g0[1]), pack2bf(g0[2], g0[3]), pack2bf(g1[0], g1[1]), pack2bf(g1[2], g1[3])};
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, fw);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa),
+                                                                        __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[f][j], 0, 0, 0);
+                if (want_rrb)
+                    accs[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa),
+                                                                      __builtin_bit_cast(mfma_bf16x8, ones), accs[f], 0, 0, 0);
+            }
+            // step g + 1 must have landed before the next iteration reads it; in the tail (nothing left to issue) drain once
+            if (issued) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    if (S > 0) {
+        issue(0);
+        if (S > 1) issue(1);
+        if (S > 2) issue(2);
+        if (S > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (S > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll 1
     for (int g = 0; g < S; g++) {
         // stage (g + 3) & 3 == (g - 1) & 3 was read in step g - 1, before that step's barrier
@@ -1525,13 +1647,16 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                               const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
-                               void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
-                               int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
-                               long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
-                               float scale, void* stream) {
+static int relattn_bwd_impl(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                            const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                            void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
+                            int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                            long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
+                            float scale, int skip_phantom_dg, void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv);
+    // the skipped cells are rebuilt by mxl_relattn_drd_recompute, which tiles 256 distances x 32 queries and needs d r_r_bias
+    // left to it (the 8-wave query-owner kernel)
+    if (skip_phantom_dg) MXL_CHECK_ARG(dg && d_r_r_bias == nullptr && dh == 64 && (M % 256) == 0 && (T % 32) == 0);
     MXL_CHECK_ARG(d_r_w_bias);      // d_r_r_bias == NULL: it is left to mxl_relattn_drd (see there)
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && (M % 8) == 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 8) == 0 && (dq_rs % 4) == 0 && (dkv_rs % 4) == 0);
@@ -1546,6 +1671,7 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.dq_bs = dq_bs; p.dkv_bs = dkv_bs;
     p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dq_rs = dq_rs; p.dkv_rs = dkv_rs;
     p.scale = scale; p.scale_log2e = scale * LOG2E;
+    p.dg_skip_phantom = skip_phantom_dg ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_bwd<16>(p, s);
@@ -1555,10 +1681,32 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
     }
 }
 
-extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
-                               long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
-                               float* d_r_w_bias_fix, void* stream) {
+extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                               const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
+                               int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                               long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
+                               float scale, void* stream) {
+    return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, d_r_r_bias, B, T, H,
+                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 0, stream);
+}
+
+extern "C" int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                         const float* r_r_bias, const void* out, const void* dout, const float* lse,
+                                         float* delta, void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, int B, int T,
+                                         int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs,
+                                         int rd_rs, long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs,
+                                         int dkv_rs, float scale, void* stream) {
+    return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, nullptr, B, T, H,
+                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 1, stream);
+}
+
+static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
+                            long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
+                            float* d_r_w_bias_fix, const float* lse, const float* delta, float scale, int Kc, int recompute,
+                            void* stream) {
     MXL_CHECK_ARG(dg && qr && d_rd && B > 0 && T > 0 && H > 0 && M > 0);
+    if (recompute) MXL_CHECK_ARG(rd && lse && delta && (M % 256) == 0 && Kc >= T && Kc <= M + T);
     if (dh != 64 || (T % 32) != 0 || (M % 8) != 0 || M < 8) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG((qr_rs % 8) == 0 && (qr_bs % 8) == 0 && drd_ld >= H * dh && ((uintptr_t)dg % 16) == 0 && ((uintptr_t)qr % 16) == 0);
     static bool attr_set = false;
@@ -1573,6 +1721,11 @@ extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int 
     p.B = B; p.T = T; p.H = H; p.M = M; p.qr_bs = qr_bs; p.qr_rs = qr_rs; p.drd_ld = drd_ld;
     MXL_CHECK_ARG(!d_r_r_bias || rd);
     p.rd = (const bf16_t*)rd; p.rd_rs = rd_rs; p.d_rrb = d_r_r_bias; p.d_rwb = d_r_w_bias_fix;
+    p.lse = lse; p.delta = delta; p.scale = scale; p.recompute = recompute ? 1 : 0;
+    {   // first stored key tile of the attention kernels (floor(p0 / 64) * 64, p0 = T - Kc <= 0): key positions below it are phantom
+        const int p0 = T - Kc;
+        p.pz = recompute ? -(((-p0) + 63) / 64) * 64 : 0;
+    }
     // batch groups: fill the 512 resident workgroup slots about once (each workgroup ends with 64 KB of fp32 atomics)
     const int tiles = ((M + 255) / 256) * H;
     int groups = 512 / tiles;
@@ -1583,4 +1736,19 @@ extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int 
     hipLaunchKernelGGL(relattn_drd_kernel, dim3((M + 255) / 256, H, groups), dim3(256), DRD_SMEM, (hipStream_t)stream, p);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
+}
+
+extern "C" int mxl_relattn_drd(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
+                               long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
+                               float* d_r_w_bias_fix, void* stream) {
+    return relattn_drd_impl(dg, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, d_r_r_bias, d_r_w_bias_fix, nullptr,
+                            nullptr, 0.f, T, 0, stream);
+}
+
+extern "C" int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
+                                         long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
+                                         float* d_r_w_bias_fix, const float* lse, const float* delta, float scale, int Kc,
+                                         void* stream) {
+    return relattn_drd_impl(dg, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, d_r_r_bias, d_r_w_bias_fix, lse, delta,
+                            scale, Kc, 1, stream);
 }

@@ -293,9 +293,19 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
     fused_rrb = (d_rd is not None and dg is not None and dh == 64 and T % 32 == 0 and M % 8 == 0 and M >= 8
                  and os.environ.get('MXL_NO_DQ8') != '1')
     Bc = B if dg is None else min(B, dg.shape[0])
+    # phantom distances (zero memories: k = v = 0) stay out of HBM: the backward leaves their dG blocks unwritten and the dRd
+    # contraction rebuilds them from qr, rd, lse and delta (mxl_relattn_bwd_sparse_dg / mxl_relattn_drd_recompute)
+    sparse = fused_rrb and M % 256 == 0 and Kc < M + T and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0'
 
     def launch(b0, n):
         sl = slice(b0, b0 + n)
+        if sparse:
+            check(lib().mxl_relattn_bwd_sparse_dg(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]),
+                                                  _p(dout[sl]), _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]),
+                                                  _p(dg), _p(d_rwb), n, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
+                                                  o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale), _stream()),
+                  'mxl_relattn_bwd_sparse_dg')
+            return
         check(lib().mxl_relattn_bwd(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]), _p(dout[sl]),
                                     _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]), _p(dg), _p(d_rwb),
                                     None if fused_rrb else _p(d_rrb), n, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
@@ -305,7 +315,8 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
         if d_rd is not None:
             relattn_drd(q[b0:b0 + n], r_r_bias, dg, d_rd, qr_buf, B=n, T=T, H=H, dh=dh, M=M, q_bs=q_bs, q_rs=q_rs,
                         rd=rd if fused_rrb else None, rd_rs=rd_rs, d_rrb=d_rrb if fused_rrb else None,
-                        d_rwb=d_rwb if fused_rrb else None)
+                        d_rwb=d_rwb if fused_rrb else None,
+                        recompute=dict(lse=lse[b0:b0 + n], delta=delta[b0:b0 + n], scale=scale, Kc=Kc) if sparse else None)
 
     if Bc >= B:
         launch(0, B)
@@ -320,11 +331,18 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
     return (lambda: None) if defer_drd else None
 
 
-def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs, rd=None, rd_rs=0, d_rrb=None, d_rwb=None):
+def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs, rd=None, rd_rs=0, d_rrb=None, d_rwb=None,
+                recompute=None):
     """d_rd[delta, h*dh:(h+1)*dh] (M x dh, fp32, +=) = sum_b dG[b,h]^T (M x T) @ (q + r_r_bias)[b,:,h,:] (T x dh); with rd /
     d_rrb (/ d_rwb) also d_rrb += colsum(dG) . Rd (and d_rwb -= the same): see mxl_relattn_drd"""
     d = H * dh
     add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
+    if recompute is not None:        # dg came from mxl_relattn_bwd_sparse_dg: its all-phantom blocks are rebuilt, not read
+        check(lib().mxl_relattn_drd_recompute(_p(dg), _p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d, _p(rd), int(rd_rs),
+                                              _p(d_rrb), _p(d_rwb), _p(recompute['lse']), _p(recompute['delta']),
+                                              float(recompute['scale']), int(recompute['Kc']), _stream()),
+              'mxl_relattn_drd_recompute')
+        return
     rc = lib().mxl_relattn_drd(_p(dg), _p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d, _p(rd), int(rd_rs), _p(d_rrb),
                                _p(d_rwb), _stream())
     if rc == -2:      # MXL_EUNSUPPORTED shape: the batched GEMM form

@@ -119,13 +119,20 @@ def test_attention_backward_batch_replication_at_bench_batch(dev, B):
         return out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb
 
     out, lse, dqkv, delta, dg, d_rd, d_rwb, d_rrb = run(B)
-    assert not torch.isnan(dg[-1].float()).any() and not torch.isnan(dg[0].float()).any()
+    # mode R at M % 256 == 0: the (32 queries x 256 distances) blocks of dG that lie on phantom distances only are not stored
+    # (the dRd contraction rebuilds them); everything else is written
+    ii = torch.arange(T, device=dev)[:, None] | 31
+    dd = torch.arange(M, device=dev)[None, :] & ~255
+    unwritten = (dd > ii).expand(H, T, M)
+    for b in (0, B - 1):
+        assert torch.equal(torch.isnan(dg[b].float()), unwritten), 'wrong set of dG blocks left to the recompute'
+    dg = dg.view(torch.int16)                    # bit patterns: the NaN filler compares equal to itself
     for nm, t in [('out', out), ('lse', lse), ('dqkv', dqkv), ('delta', delta), ('dg', dg)]:
         for b in (1, B // 2, B - 1):
             assert torch.equal(t[b], t[0]), f'{nm}: batch slot {b} differs from slot 0'
     assert dqkv[0].float().abs().sum().item() > 0
     out1, lse1, dqkv1, delta1, dg1, d_rd1, d_rwb1, d_rrb1 = run(1)
-    assert torch.equal(dqkv[B - 1], dqkv1[0]) and torch.equal(dg[B - 1], dg1[0]) and torch.equal(out[B - 1], out1[0])
+    assert torch.equal(dqkv[B - 1], dqkv1[0]) and torch.equal(dg[B - 1], dg1.view(torch.int16)[0]) and torch.equal(out[B - 1], out1[0])
     for nm, a, b in [('d_rd', d_rd, d_rd1), ('d_rwb', d_rwb, d_rwb1), ('d_rrb', d_rrb, d_rrb1)]:
         assert _rel(a, B * b) < 1e-4, f'{nm}: {_rel(a, B * b)}'
 

@@ -292,6 +292,11 @@ BWD_CASES = [
     (2, 256, 8, 16, 256, 256, 'C1-shape dh16'),
     (1, 160, 4, 32, 128, 160 + 40, 'dh32 partial mem'),
     (1, 70, 2, 64, 320, 70, 'T<M nomem'),
+    # M % 256 == 0, dh = 64, fewer than M carried rows: dG blocks lying entirely on phantom distances are not stored, the dRd
+    # contraction rebuilds them (mxl_relattn_bwd_sparse_dg / mxl_relattn_drd_recompute)
+    (2, 512, 2, 64, 512, 512, 'phantom-recompute nomem'),
+    (3, 768, 1, 64, 1024, 768 + 192, 'phantom-recompute partial mem'),
+    (1, 1024, 2, 64, 768, 1024 + 64, 'phantom-recompute T>M'),
 ]
 
 
@@ -332,7 +337,16 @@ def test_relattn_bwd(dev, B, T, H, dh, M, Kc, name):
                     dqkv[:, :, 2 * d:], dg, d_rwb, d_rrb, dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
                     d_rd=d_rd, qr_buf=qr_buf, **st)
     torch.cuda.synchronize()
-    assert not torch.isnan(dg.float()).any(), f'{name}: dG not fully written'
+    written = ~torch.isnan(dg.float())
+    if name.startswith('phantom-recompute'):
+        # exactly the (32 queries x 256 distances) blocks that lie on phantom distances only are left unwritten
+        pz = -((Kc - T + 63) // 64) * 64
+        ii = torch.arange(T, device=dev)[:, None] | 31
+        dd = torch.arange(M, device=dev)[None, :] & ~255
+        want_unwritten = (dd > ii - pz).expand(B, H, T, M)
+        assert want_unwritten.any() and torch.equal(~written, want_unwritten), f'{name}: wrong set of dG blocks skipped'
+    else:
+        assert written.all(), f'{name}: dG not fully written'
     got_dq = dqkv[:, Kc - T:, :d].float().cpu().view(B, T, H, dh)
     got_dk = dqkv[:, :, d:2 * d].float().cpu().view(B, Kc, H, dh)
     got_dv = dqkv[:, :, 2 * d:].float().cpu().view(B, Kc, H, dh)
