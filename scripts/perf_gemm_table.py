@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from symbolic_music_generation_amd import ops
 dev = torch.device('cuda:0')
-NT = 32768
+NT = int(os.environ.get('NT', 131072))          # tokens: per-GPU batch 64 x 2048 (round 1 ran this at 32768)
 d, F = 768, 3072
 
 def timeit(fn, n=20, warm=3):
