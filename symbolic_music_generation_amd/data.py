@@ -17,7 +17,6 @@ On-the-fly augmentation happens on ids, not strings (`Augment`)
 PitchShift (:154-237) an id -> id table per key applied by the pack kernel.
 """
 import json
-import os
 from typing import Iterable, Iterator, Optional, Sequence, Tuple
 
 import numpy as np

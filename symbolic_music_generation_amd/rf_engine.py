@@ -9,7 +9,7 @@ HF state-dict names, explicit layer loop over libmusicxl kernels, saved activati
 """
 import math
 from collections import OrderedDict
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

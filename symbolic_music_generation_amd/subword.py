@@ -14,7 +14,6 @@ more switches `MyTransfoXLConfig` to an adaptive softmax with cutoffs (musicnlp/
 head kernels cover.  Host-side string work: none of this is on the device path.
 """
 import json
-import os
 from collections import Counter
 from typing import Dict, Iterable, List, Optional, Sequence, Union
 

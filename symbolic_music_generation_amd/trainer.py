@@ -10,7 +10,7 @@ import math
 import os
 import time
 from collections import OrderedDict
-from typing import Callable, Dict, Iterable, List, Optional, Tuple, Union
+from typing import Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 
