@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from symbolic_music_generation_amd import ops
 dev = torch.device('cuda:0')
-NT = 32768
+NT = int(os.environ.get('NT', 32768))
 SHAPES = [('qkv fwd', 2304, 768), ('o fwd/dX', 768, 768), ('ffn1 fwd', 3072, 768), ('ffn2 fwd', 768, 3072), ('qkv dX', 768, 2304),
           ('head-ish', 1216, 768), ('K=8192', 2048, 8192)]
 screen = '--screen' in sys.argv
