@@ -517,3 +517,41 @@ def test_skinny_partial_plus_layernorm_matches_unfused(dev, M, d, K, KS):
     assert diff.max().item() < 4e-2 and (diff > 0).float().mean().item() < 0.02     # a rare one-ulp bf16 flip, nothing more
     ref = torch.nn.functional.layer_norm((x.float() @ w.float().t() + b) + res.float(), (d,), gam, bet)
     assert rel_err(got.cpu(), ref.cpu()) < 1e-2
+
+
+@pytest.mark.parametrize('B,T,H,dh,M,Kc', [(3, 256, 2, 64, 128, 256 + 64), (3, 512, 1, 64, 512, 512 + 64)])
+def test_relattn_bwd_with_a_dg_buffer_of_fewer_sequences(dev, B, T, H, dh, M, Kc):
+    """`dg` may hold fewer sequences than the batch (ops.relattn_bwd walks the batch in chunks, each chunk's backward followed by
+    its dRd contraction): per-sequence outputs identical bit for bit, batch-summed ones equal up to fp32 atomic ordering -- with
+    every dG block stored (M = 128) and with the phantom blocks rebuilt in the contraction (M = 512)."""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(B * T + M)
+    d = H * dh
+    qkv = bf(torch.randn(B, Kc, 3 * d) * 0.8).to(dev)
+    rd = bf(torch.randn(M, d) * 0.8).to(dev)
+    rwb, rrb = (torch.randn(H, dh) * 0.5).to(dev), (torch.randn(H, dh) * 0.5).to(dev)
+    dout = bf(torch.randn(B, T, d)).to(dev)
+    st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+              o_bs=T * d, o_rs=d)
+    qv, kv, vv = qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+    out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=dev)
+    ops.relattn_fwd(qv, kv, vv, rd, rwb, rrb, out, lse, **st)
+
+    def run(n_dg):
+        dqkv = torch.zeros(B, Kc, 3 * d, device=dev, dtype=torch.bfloat16)
+        delta = torch.zeros(B, H, T, device=dev)
+        dg = torch.zeros(n_dg, H, T, M, device=dev, dtype=torch.bfloat16)
+        d_rwb, d_rrb = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
+        d_rd = torch.zeros(M, d, device=dev)
+        qr_buf = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
+        ops.relattn_bwd(qv, kv, vv, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d],
+                        dqkv[:, :, 2 * d:], dg, d_rwb, d_rrb, dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
+                        d_rd=d_rd, qr_buf=qr_buf, **st)
+        torch.cuda.synchronize()
+        return dqkv, d_rd, d_rwb, d_rrb
+
+    full, one = run(B), run(1)
+    assert torch.equal(full[0], one[0])
+    for nm, a, b_ in zip(('d_rd', 'd_rwb', 'd_rrb'), full[1:], one[1:]):
+        assert rel_err(b_.cpu(), a.cpu()) < 1e-4, nm
