@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument('--decode-steps', type=int, default=0, help='decode steps to time (0 = the whole C5 generation)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--grad-exchange', default='fp32', choices=['fp32', 'bf16'],
+                    help='dtype of the data-parallel gradient all-reduce (fp32 = what HF DDP exchanges in the reference stack)')
     ap.add_argument('--master-port', type=int, default=29533)
     return ap.parse_args(argv)
 
@@ -89,6 +91,7 @@ class Ranks:
     """process-group plumbing shared by the legs (and by the CPU stub used in tests)"""
 
     def __init__(self, backend, dev):
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL on this pool, also under an external torchrun
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.dev = dev
@@ -174,24 +177,28 @@ def train_leg(args, ranks: Ranks):
     cfg = MyTransfoXLConfig(wl['size'], max_length=T, vocab_size=V, n_layer=wl['n_layer'], mem_len=M, cutoffs=[])
     model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
     eng = model.engine
-    sync = GradSync(eng)
+    sync = GradSync(eng, dtype=args.grad_exchange)
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)          # musicnlp/util/config.json "random-seed": 77
     ids = torch.randint(4, V, (B, T), generator=gen).to(dev)            # skip the special ids
     labels = ids.clone()
     lr, wd = 3e-4, 0.1            # train_xl's weight decay (train.py:570); the lr value is irrelevant to throughput
 
-    # live roofline timing of the dominant kernel group (attention backward)
+    # live roofline timing of the dominant kernel group: EVERY launch of one layer's attention backward (delta, query-owner,
+    # key-owner, the q + r_r_bias operand, the dRd contraction) inside one HIP-event bracket on the launch stream, plus the
+    # library's own per-kernel event pairs (mxl_ktime_*) for the forward and each backward kernel
     br = EventBracket()
     orig_bwd = ops.relattn_bwd
 
     def timed_relattn_bwd(*a, **k):
-        if not br.on:
-            return orig_bwd(*a, **k)
-        finish = br.run(lambda: orig_bwd(*a, defer_drd=True, **k))     # the attention-backward launches only
-        finish()                                                       # whatever the wrapper runs after them
+        return br.run(lambda: orig_bwd(*a, **k))
 
     if not args.no_roofline:
         ops.relattn_bwd = timed_relattn_bwd
+
+    def on_timed(on):
+        br.on = on and not args.no_roofline
+        if not args.no_roofline:
+            ops.ktime_enable(on)
 
     def step():
         with torch.no_grad():          # the fused path: explicit engine backward, no autograd node needed
@@ -201,8 +208,9 @@ def train_leg(args, ranks: Ranks):
             sync.finish()
             eng.optimizer_step(lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_scale=1.0 / world)
 
-    dt = timed_steps(ranks, step, args.steps, args.warmup, on_timed=lambda on: setattr(br, 'on', on and not args.no_roofline))
+    dt = timed_steps(ranks, step, args.steps, args.warmup, on_timed=on_timed)
     ops.relattn_bwd = orig_bwd
+    kt = ops.ktime_collect() if not args.no_roofline else {}
     with torch.no_grad():
         loss = model(input_ids=ids, labels=labels).loss.item()
     out = None
@@ -214,7 +222,7 @@ def train_leg(args, ranks: Ranks):
             'metric': 'train tokens/sec (TransfoXL seq2048 bf16), whole job', 'value': tokens / dt, 'unit': 'tokens/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'rccl_ranks': ranks.rccl_ranks(),
+            'rccl_ranks': ranks.rccl_ranks(), 'grad_exchange_dtype': sync.dtype,
             'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T, 'mem_len': M,
                        'parallelism': f'dp{world}', 'dropout': cfg.dropout, 'final_loss': loss,
                        'train_flops_per_token': 3 * f_fwd,
@@ -223,16 +231,32 @@ def train_leg(args, ranks: Ranks):
         if br.ev:
             ms = br.total_ms() / len(br.ev)
             # algorithmic flops of ONE attention-backward call (one layer, this rank's batch): backward = 2 x forward of the
-            # banded attention core, forward = B*T*(4*d*n_bar + 2*d*M)
+            # banded attention core, forward = B*T*(4*d*n_bar + 2*d*M).  Split by the kernel that owns each gradient product:
+            # query-owner dP + dQw (4 d n_bar) + dQr (2 d M), key-owner dK + dV (4 d n_bar), dRd contraction (2 d M); the
+            # recomputed S / G products are not algorithmic work.
             nbar = (T + 1) / 2 if T <= M else M
-            alg = 2 * B * T * (4 * d * nbar + 2 * d * M)
+            fwd_alg = B * T * (4 * d * nbar + 2 * d * M)
+            alg = 2 * fwd_alg
             ach = alg / (ms * 1e-3) / 1e12
             traffic, src = pmc_traffic(args.workload, B)
-            out['roofline'] = {'kernel': 'relattn_bwd (all attention-backward launches of one layer)', 'bound': 'mfma',
-                               'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg), 'delta': ('relattn_bwd_delta_kernel', 0.0),
+                    'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M)),
+                    'dkv': ('relattn_bwd_dkv_kernel', B * T * 4 * d * nbar), 'rowbias': ('add_rowbias_kernel', 0.0),
+                    'drd': ('relattn_drd_kernel', B * T * 2 * d * M)}
+            kernels = {}
+            for key, (kname, kflop) in kalg.items():
+                if key in kt and kt[key][1]:
+                    kms = kt[key][0] / kt[key][1]
+                    kernels[key] = {'kernel': kname, 'ms': kms, 'launches_timed': kt[key][1], 'alg_flop': kflop,
+                                    'frac': kflop / (kms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+            bwd_sum = sum(kernels[k]['ms'] for k in ('delta', 'dq8', 'dkv', 'rowbias', 'drd') if k in kernels)
+            out['roofline'] = {'kernel': 'attention backward of one layer: relattn_bwd_delta + relattn_bwd_dq8 + relattn_bwd_dkv + '
+                                         'add_rowbias + relattn_drd (one HIP-event bracket around all five launches)',
+                               'bound': 'mfma', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'HBM bytes per launch group (PMC)', 'traffic_source': src,
-                               'avg_launch_ms': ms, 'launches_timed': len(br.ev)}
+                               'avg_launch_ms': ms, 'launches_timed': len(br.ev), 'alg_flop_per_launch_group': alg,
+                               'sum_of_kernel_ms': bwd_sum, 'kernels': kernels}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_train(wl, T, M)
     del model, eng, sync

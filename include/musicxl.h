@@ -346,6 +346,23 @@ int mxl_pack_clm_batch(const void* tokens, int elem_bytes, const int* offsets, v
  * (eval.py:187-198, which = n_bar). */
 int mxl_find_token(const void* ids, int ld_ids, int B, int T, long long token, int which, int* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement hook (no reference counterpart).  While enabled, the launch functions of the attention path bracket
+ * EACH of their kernels with a hipEvent pair on the launch stream, so that bench.py can report per-kernel durations measured
+ * live inside its timed region.  Enqueue-time cost: two hipEventRecord per kernel; NOT capture-safe (leave it off while a
+ * hipGraph is being captured).  Kernel ids: */
+#define MXL_KT_RELATTN_FWD   0   /* relattn_fwd_kernel                                  */
+#define MXL_KT_RELATTN_DELTA 1   /* relattn_bwd_delta_kernel                            */
+#define MXL_KT_RELATTN_DQ    2   /* relattn_bwd_dq8_kernel / relattn_bwd_dq_kernel      */
+#define MXL_KT_RELATTN_DKV   3   /* relattn_bwd_dkv_kernel                              */
+#define MXL_KT_RELATTN_DRD   4   /* relattn_drd_kernel                                  */
+#define MXL_KT_ROWBIAS       5   /* add_rowbias (the q + r_r_bias operand of the dRd contraction) */
+#define MXL_KT_COUNT         6
+int mxl_ktime_enable(int on);
+/* waits for every recorded event, adds each kernel's elapsed milliseconds into ms_sum[id] and its launch count into
+ * launches[id] (HOST arrays of n >= MXL_KT_COUNT entries, overwritten), and forgets the recorded events */
+int mxl_ktime_collect(float* ms_sum, int* launches, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -480,8 +480,11 @@ extern "C" int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, con
                                     int n, void* stream) {
     MXL_CHECK_ARG(x && bias && out && B > 0 && T > 0 && n > 0 && (n % 8) == 0 && (x_rs % 8) == 0 && (x_bs % 8) == 0);
     const long long tot = (long long)B * T * (n / 8);
-    hipLaunchKernelGGL(add_rowbias_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, x_bs, x_rs, bias, (bf16_t*)out, B, T, n);
+    {
+        mxl_kt::Scope kt(MXL_KT_ROWBIAS, (hipStream_t)stream);
+        hipLaunchKernelGGL(add_rowbias_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, x_bs, x_rs, bias, (bf16_t*)out, B, T, n);
+    }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -1693,7 +1693,10 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(relattn_bwd_delta_kernel, dim3((p.B * p.T + 3) / 4), dim3(256), 0, s, p, DH);
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DELTA, s);
+        hipLaunchKernelGGL(relattn_bwd_delta_kernel, dim3((p.B * p.T + 3) / 4), dim3(256), 0, s, p, DH);
+    }
     if (p.d_rrb == nullptr) {
         static bool attr8 = false;
         if (!attr8) {
@@ -1702,10 +1705,16 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
             if (e != hipSuccess) return (int)e;
             attr8 = true;
         }
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DQ, s);
         hipLaunchKernelGGL((relattn_bwd_dq8_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(512), GeoQ<DH>::SMEM, s, p);
-    } else
-    hipLaunchKernelGGL((relattn_bwd_dq_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(256), GeoQ<DH>::SMEM, s, p);
-    hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
+    } else {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DQ, s);
+        hipLaunchKernelGGL((relattn_bwd_dq_kernel<DH>), dim3((p.T + QB - 1) / QB, p.H, p.B), dim3(256), GeoQ<DH>::SMEM, s, p);
+    }
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DKV, s);
+        hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
+    }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
@@ -1798,7 +1807,10 @@ static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, 
     if (groups > B) groups = B;
     p.bgroup = (B + groups - 1) / groups;
     groups = (B + p.bgroup - 1) / p.bgroup;
-    hipLaunchKernelGGL(relattn_drd_kernel, dim3((M + 255) / 256, H, groups), dim3(256), DRD_SMEM, (hipStream_t)stream, p);
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DRD, (hipStream_t)stream);
+        hipLaunchKernelGGL(relattn_drd_kernel, dim3((M + 255) / 256, H, groups), dim3(256), DRD_SMEM, (hipStream_t)stream, p);
+    }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -494,7 +494,10 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((p.T + QB - 1) / QB, p.H, p.B);
-    hipLaunchKernelGGL((relattn_fwd_kernel<DH>), grid, dim3(256), G::SMEM, s, p);
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_FWD, s);
+        hipLaunchKernelGGL((relattn_fwd_kernel<DH>), grid, dim3(256), G::SMEM, s, p);
+    }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -67,11 +67,16 @@ class MixedTokenFiles:
     once per epoch, dataset.py:422-431).  Index order as the reference: dataset 0's (sub-sampled) entries, then dataset 1's, ...
     Quacks like a `TokenFile` for `DeviceBatcher` (`len`, `[i]`, `dtype`, `vocab_size`); `flat_index(i)` is the position of
     entry i in the plain concatenation of the full datasets (what per-sequence side tables such as `Augment.keys` are indexed by).
-    The draw is `torch.randperm(size)[:k]` on torch's global generator, as in the reference, unless a generator is passed."""
+    The draw is `torch.randperm(size)[:k]` as in the reference -- on torch's global generator when neither `generator` nor
+    `seed` is given (the reference's behaviour), on a private generator re-seeded from (seed, epoch) by `sample(epoch)` when
+    `seed` is: every data-parallel rank then draws the SAME sub-sample, which the rank-strided shards partition."""
 
-    def __init__(self, files: Sequence[TokenFile], k: int, generator: Optional[torch.Generator] = None):
+    def __init__(self, files: Sequence[TokenFile], k: int, generator: Optional[torch.Generator] = None,
+                 seed: Optional[int] = None):
         assert k is not None and len(files) > 0
-        self.files, self.k, self.generator = list(files), int(k), generator
+        self.files, self.k, self.generator, self.seed = list(files), int(k), generator, seed
+        if seed is not None and generator is None:
+            self.generator = torch.Generator()
         if len({f.dtype for f in self.files}) != 1 or len({f.vocab_size for f in self.files}) != 1:
             raise ValueError('mixed token files must share one vocabulary and id width')
         self.dtype, self.vocab_size = self.files[0].dtype, self.files[0].vocab_size
@@ -81,7 +86,9 @@ class MixedTokenFiles:
         self._sampled: list = [None] * len(self.files)
         self.sample()
 
-    def sample(self):
+    def sample(self, epoch: int = 0):
+        if self.seed is not None:
+            self.generator.manual_seed(int(self.seed) * 1000003 + int(epoch))
         for j, f in enumerate(self.files):
             if len(f) > self.k:
                 self._sampled[j] = torch.randperm(len(f), generator=self.generator)[:self.k].numpy()
@@ -339,7 +346,9 @@ class DeviceBatcher:
         idx = np.arange(len(self.tf))
         if self.shuffle:
             np.random.default_rng(self.seed + self.epoch).shuffle(idx)
-        if self.world > 1 and len(idx) % self.world:
+        # evaluation (shuffle off) takes the plain strided shard: no duplicated rows in the all-reduced sums, and its only
+        # collective is one sum at the end, so ranks may differ by one batch
+        if self.shuffle and self.world > 1 and len(idx) % self.world:
             idx = np.concatenate([idx, idx[:self.world - len(idx) % self.world]])
         return idx[self.rank::self.world]
 

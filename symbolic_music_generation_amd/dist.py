@@ -74,10 +74,12 @@ def _r8(n):
 class GradSync:
     """Overlapped all-reduce (SUM) of the engine's gradient buffer.
 
-    `dtype='bf16'` (the default on the GPU; `MXL_DP_DTYPE=fp32` or dtype='fp32' selects the parity mode): a bucket is narrowed
-    into a bf16 staging buffer by a HIP kernel, all-reduced at half the bytes (186 MB per step at 12L/768d instead
-    of 372 MB), and widened back into the fp32 gradient buffer once it has arrived -- the fp32 master weights, Adam moments and
-    the clip norm never see bf16 storage.  The transport is `torch.distributed` (backend "nccl" = RCCL over xGMI): the
+    `dtype='fp32'` (the default, what HF's DDP exchanges in the reference stack) all-reduces the slices of the fp32 gradient
+    buffer in place.  `dtype='bf16'` (opt-in: `GradSync(engine, 'bf16')`, the `grad_exchange_dtype` train argument, or
+    `MXL_DP_DTYPE=bf16`): a bucket is narrowed into a bf16 staging buffer by a HIP kernel, all-reduced at half the bytes
+    (186 MB per step at 12L/768d instead of 372 MB), and widened back into the fp32 gradient buffer once it has
+    arrived -- the fp32 master weights, Adam moments and the clip norm never see bf16 storage; each rank's contribution is
+    rounded to 8 significant bits and RCCL sums in bf16 (error bound: tests/test_dp_cpu.py::test_bf16_exchange_error_bound).  The transport is `torch.distributed` (backend "nccl" = RCCL over xGMI): the
     communicator, its bootstrap and its stream ordering against torch's allocator are torch's; libmusicxl owns the casts.
     """
 
@@ -86,7 +88,8 @@ class GradSync:
         n_layer = getattr(engine.cfg, 'n_layer', None) or len(engine.cfg.attn_layers)
         self.per_layer, self.rest = layer_buckets(engine.layout, n_layer)
         self.pending = []
-        self.dtype = (dtype or os.environ.get('MXL_DP_DTYPE') or 'bf16').lower()
+        self.dtype = (dtype or os.environ.get('MXL_DP_DTYPE') or 'fp32').lower()
+        self.dtype = {'f32': 'fp32', 'float32': 'fp32', 'bfloat16': 'bf16'}.get(self.dtype, self.dtype)
         if self.dtype not in ('bf16', 'fp32'):
             raise ValueError(f'gradient exchange dtype {self.dtype!r}: bf16 or fp32')
         self._stage = {}

@@ -9,8 +9,8 @@ state is ONE flat fp32 buffer `P`:
   tree of plain container modules, so `named_parameters()`, `state_dict()`, HF's weight-decay grouping by name and any
   `torch.optim` optimizer work unchanged;
 * a train-mode forward returns a `loss` produced by a `torch.autograd.Function` whose backward runs the engine's explicit
-  HIP backward and hands autograd views of the flat gradient buffer (a fresh buffer per backward, so gradient accumulation
-  over micro-batches is autograd's own `+=`);
+  HIP backward and hands autograd views of the flat gradient buffer (recycled between steps unless a parameter's `.grad`
+  still aliases it, so gradient accumulation over micro-batches is autograd's own `+=`);
 * an optimizer writes the fp32 views in place; views share `P`'s version counter, so the next forward sees the bump and
   refreshes the bf16 MFMA operands (`engine.sync_weights()`).
 
@@ -45,8 +45,19 @@ class _EngineLoss(torch.autograd.Function):
             raise RuntimeError('backward() of a loss whose activations were overwritten by a later train-mode forward: the '
                                'engine keeps the activations of ONE forward (call backward before the next forward)')
         eng = model.engine
-        # a fresh buffer per backward: autograd may keep the returned views as `.grad`, and accumulates micro-batches itself
-        eng.G = torch.zeros_like(eng.P)
+        # autograd may keep the returned views as the parameters' `.grad` (and then accumulates micro-batches itself with `+=`),
+        # so the flat buffer can only be recycled when no parameter still holds a view of it -- the usual case, after
+        # `optimizer.zero_grad()` (set_to_none) -- otherwise a fresh one is taken (372 MB at C3: not something to do per step)
+        G = eng.G
+        if G is not None and G.shape == eng.P.shape:
+            base = G.untyped_storage().data_ptr()
+            held = any(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in model.parameters())
+        else:
+            held = True
+        if held:
+            eng.G = torch.zeros_like(eng.P)
+        else:
+            G.zero_()
         sync = model._grad_sync
         scale = float(gout)
         if sync is not None:

@@ -55,6 +55,22 @@ def _cut(cutoffs: Sequence[int]):
     return n, arr
 
 
+KT_NAMES = ('fwd', 'delta', 'dq8', 'dkv', 'drd', 'rowbias')      # MXL_KT_* ids of include/musicxl.h
+
+
+def ktime_enable(on: bool):
+    """per-kernel hipEvent brackets inside the attention launch functions (bench.py's roofline); off while capturing graphs"""
+    check(lib().mxl_ktime_enable(int(bool(on))), 'mxl_ktime_enable')
+
+
+def ktime_collect():
+    """{kernel: (milliseconds summed, launches)} since the last collect; synchronises the recorded events"""
+    n = len(KT_NAMES)
+    ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+    check(lib().mxl_ktime_collect(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), n), 'mxl_ktime_collect')
+    return {KT_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,
          flags=0, alpha=1.0, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, ksplits=1,
          lda=None, ldb=None, ldc=None, ldaux=None, drop_p=0.0, seed=0, site=0):

@@ -171,7 +171,9 @@ class MyTrainer:
             n_train = train_dataset.n_rows() if hasattr(train_dataset, 'n_rows') else len(train_dataset)
         self.args = TrainArgs(model_name, model_size)(train_args, n_train=n_train)
         self.engine = model.engine
-        self.sync = mdist.GradSync(self.engine)
+        # gradient exchange: fp32 as HF's DDP unless `grad_exchange_dtype='bf16'` is asked for (half the bytes, ~2^-9 relative
+        # rounding per rank's contribution: tests/test_dp_cpu.py::test_bf16_exchange_error_bound)
+        self.sync = mdist.GradSync(self.engine, dtype=self.args.get('grad_exchange_dtype'))
         self.log_fn = log_fn or (lambda d: None)
         self.seed = seed
         self.global_step = 0
@@ -180,12 +182,20 @@ class MyTrainer:
         self.best = (float('inf'), None)
 
     # ---------------------------------------------------------------- one step
-    def training_step(self, input_ids: torch.Tensor, labels: torch.Tensor, lr: float) -> torch.Tensor:
+    def training_step(self, input_ids: torch.Tensor, labels: torch.Tensor, lr: float, micro: int = 0, n_micro: int = 1) -> torch.Tensor:
+        """One micro-batch.  With `gradient_accumulation_steps` = k (HF semantics) the gradients of k consecutive micro-batches are
+        summed in the flat buffer (each backward scaled 1/k), the ranks exchange once -- behind the LAST micro-batch's backward --
+        and clip + AdamW run once; `rng_step` advances with every backward so that micro-batches draw their own dropout masks."""
         a = self.args
         self.model.train()
-        self.engine.zero_grad()
+        if micro == 0:
+            self.engine.zero_grad()
+        last = micro == n_micro - 1
         out = self.model(input_ids=input_ids, labels=labels)
-        self.engine.backward(layer_done=self.sync.layer_done)
+        self.engine.backward(grad_scale=1.0 / n_micro, layer_done=self.sync.layer_done if last else None)
+        if not last:
+            self.engine.rng_step += 1
+            return out.loss
         self.sync.finish()
         self.engine.optimizer_step(lr=lr, betas=(a['adam_beta1'], a['adam_beta2']), eps=a['adam_epsilon'],
                                    weight_decay=a['weight_decay'], max_grad_norm=a['max_grad_norm'],
@@ -208,8 +218,10 @@ class MyTrainer:
     def _batches(self, ds, bsz: int, epoch: int, shuffle: bool, pad: bool = False, with_index: bool = False):
         """HF Trainer's loader keeps the last partial batch (`dataloader_drop_last=False`)."""
         if hasattr(ds, 'n_rows'):            # a DeviceBatcher: already sharded, shuffled, augmented, collated, on the device
-            if hasattr(ds.tf, 'sample'):
-                ds.tf.sample()               # ProportionMixingDataset re-draws its sub-sample every epoch (dataset.py:422-431)
+            # ProportionalMixCallback.on_epoch_begin (train_util_wrap.py:307-317) re-draws the TRAIN sub-sample every epoch; the
+            # eval dataset keeps the draw of its construction, so eval_loss compares the same subset from epoch to epoch
+            if shuffle and hasattr(ds.tf, 'sample'):
+                ds.tf.sample(epoch)
             ds.epoch = epoch
             for ids, labels in ds:
                 yield ((ids, labels), None) if with_index else (ids, labels)
@@ -225,22 +237,36 @@ class MyTrainer:
     def train(self, max_steps: Optional[int] = None) -> Dict:
         a = self.args
         bsz = a['per_device_train_batch_size']
+        gas = max(1, int(a.get('gradient_accumulation_steps', 1)))
         n_train = self.train_dataset.n_rows() if hasattr(self.train_dataset, 'n_rows') else len(self.train_dataset)
-        spe = max(1, math.ceil(n_train / (bsz * mdist.world_size())))   # == TrainArgs.steps_per_epoch
+        # optimizer steps per epoch == TrainArgs.steps_per_epoch (train.py:196-199): HF counts micro-batches // accumulation
+        n_micro_epoch = max(1, math.ceil(n_train / (bsz * mdist.world_size())))
+        spe = max(1, math.ceil(n_train / (bsz * gas * mdist.world_size())))
         total = max_steps or spe * int(a['num_train_epochs'])
+        save_steps = int(a['save_steps']) if a.get('save_strategy') == 'steps' and a.get('save_steps') else None
         t0 = time.time()
         done = False
         for epoch in range(int(a['num_train_epochs'])):
+            micro, seen = 0, 0
             for ids in self._batches(self.train_dataset, bsz, epoch, shuffle=True, pad=True):
                 ids, labels = ids if isinstance(ids, tuple) else collate_clm(ids, self.pad_id)
+                seen += 1
+                # the last group of an epoch may hold fewer than `gas` micro-batches (HF steps on the epoch's last batch)
+                group = min(gas, n_micro_epoch - (seen - 1 - micro))
                 lr = lr_at(self.global_step, total, a['learning_rate'], a['lr_scheduler_type'], a['warmup_ratio'])
-                loss = self.training_step(ids, labels, lr)
+                step_before = self.global_step
+                loss = self.training_step(ids, labels, lr, micro=micro, n_micro=group)
+                micro = 0 if self.global_step != step_before else micro + 1
+                if self.global_step == step_before:
+                    continue
                 if self.my_args.get('logging_strategy', 'steps') != 'no' and \
                         self.global_step % self.my_args.get('logging_steps', a['logging_steps']) == 0:
                     d = dict(step=self.global_step, epoch=epoch + self.global_step / spe % 1, learning_rate=lr,
                              loss=loss.item())
                     self.log_history.append(d)
                     self.log_fn(d)
+                if save_steps and a['output_dir'] and self.global_step % save_steps == 0 and mdist.rank() == 0:
+                    self.save_model(os.path.join(a['output_dir'], f'checkpoint-{self.global_step}'))
                 if self.global_step >= total:
                     done = True
                     break
@@ -249,7 +275,10 @@ class MyTrainer:
                 ev.update(step=self.global_step, epoch=epoch + 1)
                 self.log_history.append(ev)
                 self.log_fn(ev)
-                if a['output_dir']:
+                # checkpoint cadence: every epoch (save_strategy='epoch'), or every `save_steps` optimizer steps when
+                # TrainArgs turned `save_epochs` = k into a step count (train.py:213-220: k epochs = k * steps_per_epoch)
+                saves_now = a.get('save_strategy') == 'epoch' or (save_steps and self.global_step % save_steps == 0)
+                if a['output_dir'] and saves_now:
                     # eval_loss is all-reduced and the path is deterministic: every rank tracks the same best checkpoint
                     ck = os.path.join(a['output_dir'], f'checkpoint-{self.global_step}')
                     if mdist.rank() == 0:
@@ -364,9 +393,9 @@ def get_all_setup(model_name: str = None, model_size: str = None, model_config: 
         files = _open_split(dataset_names, split)
         if prop_mix:
             k = prop_mix if isinstance(prop_mix, int) and not isinstance(prop_mix, bool) else 2048
-            tf = MixedTokenFiles(files, k if split == 'train' else max(k // 10, 1))               # :336-343
+            tf = MixedTokenFiles(files, k if split == 'train' else max(k // 10, 1), seed=seed)    # :336-343
         elif len(files) > 1:
-            tf = MixedTokenFiles(files, max(len(f) for f in files))
+            tf = MixedTokenFiles(files, max(len(f) for f in files), seed=seed)
         else:
             tf = files[0]
         aug = None
@@ -392,6 +421,16 @@ def get_all_setup(model_name: str = None, model_size: str = None, model_config: 
     return model, tokenizer, trainer
 
 
+def _save_trained(trainer):
+    """trainer.save_model(<out>/trained) (train.py:489,591) by rank 0 alone: the replicas are identical, and every rank writing
+    the same pytorch_model.bin / trainer_state.json would race"""
+    if trainer.args.get('output_dir'):
+        if mdist.rank() == 0:
+            trainer.save_model(os.path.join(trainer.args['output_dir'], 'trained'))
+        if mdist.is_dist():
+            torch.distributed.barrier()
+
+
 def train_xl(dataset_names, model_size: str = 'base', model_config: Dict = None, train_args: Dict = None,
              my_train_args: Dict = None, dataset_args: Dict = None, device='cuda:0', **train_kwargs):
     """The reference's `train_xl()` (train.py:492-593) with its hard-wired settings as defaults: max_length 1024, mem_len 512,
@@ -412,8 +451,7 @@ def train_xl(dataset_names, model_size: str = 'base', model_config: Dict = None,
                                               my_train_args=mta, trainer_args=dict(disable_train_metrics=True), device=device)
     torch.manual_seed(RANDOM_SEED)
     trainer.train(**train_kwargs)
-    if trainer.args.get('output_dir'):
-        trainer.save_model(os.path.join(trainer.args['output_dir'], 'trained'))
+    _save_trained(trainer)
     return trainer
 
 
@@ -434,6 +472,5 @@ def train_reformer(dataset_names, model_size: str = 'base', model_config: Dict =
                                               dataset_names=dataset_names, dataset_args=dataset_args, train_args=ta,
                                               my_train_args=mta, trainer_args=dict(disable_train_metrics=True), device=device)
     trainer.train(**train_kwargs)
-    if trainer.args.get('output_dir'):
-        trainer.save_model(os.path.join(trainer.args['output_dir'], 'trained'))
+    _save_trained(trainer)
     return trainer
