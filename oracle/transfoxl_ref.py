@@ -313,6 +313,9 @@ class RefTransfoXLModel(nn.Module):
         self.drop = nn.Dropout(c.dropout)
         self.layers = nn.ModuleList([DecoderLayer(c) for _ in range(c.n_layer)])
         self.pos_emb = PositionalEmbedding(c.d_model)
+        # test-infrastructure switch (no upstream counterpart): recompute each layer in the backward instead of keeping its dense
+        # (qlen, klen) score tensors -- same arithmetic, a few GB instead of ~25 GB for the 12-layer / 2048-token autograd
+        self.checkpoint_layers = False
 
     def init_mems(self, bsz):
         p = next(self.parameters())
@@ -350,7 +353,11 @@ class RefTransfoXLModel(nn.Module):
         hids = []
         for i, layer in enumerate(self.layers):
             hids.append(core_out)
-            core_out = layer(core_out, pos_emb, dec_attn_mask, mems[i])
+            if self.checkpoint_layers and torch.is_grad_enabled():
+                from torch.utils.checkpoint import checkpoint
+                core_out = checkpoint(layer, core_out, pos_emb, dec_attn_mask, mems[i], use_reentrant=False)
+            else:
+                core_out = layer(core_out, pos_emb, dec_attn_mask, mems[i])
         core_out = self.drop(core_out)
         new_mems = self._update_mems(hids, mems, mlen, qlen)
         return core_out.transpose(0, 1).contiguous(), new_mems

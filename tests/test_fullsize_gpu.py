@@ -598,3 +598,149 @@ def test_c5_decode_batch64_ring_wrap(dev):
             rl = ref(want[r0:r0 + 1, :t0]).prediction_scores[0, -1]
         margin = (rl.topk(2).values[0] - rl.topk(2).values[1]).item()
         assert margin < 5e-2, f'greedy decode diverges from the oracle at row {r0} position {t0} with margin {margin}'
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 3: the headline config's own backward, sampler and dropout at size
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_c3_train_step_gradients_vs_oracle(dev):
+    """SURVEY C3 at FULL depth: 12L / 768d / H12 / dh64 / F3072, T = M = 2048, V = 1190, B = 1, mode R (fresh zero mems: the
+    reference's training, musicnlp/models/transformer_xl.py:130-221 under HF Trainer), dropout 0, a padded label tail -- loss and
+    EVERY parameter's gradient of the 12-layer backward against the fp32 oracle's autograd.  The oracle recomputes each layer in
+    its backward (`checkpoint_layers`: the same arithmetic; the dense (2048, 4096, 12) score tensors of twelve layers would need
+    ~25 GB otherwise).  Same limits as C2 and as the two-layer C3 test: rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight
+    <= 20 % / >= 0.98 and the last LayerNorm's bias <= 10 % / >= 0.995 (sums with cancellation: see those tests)."""
+    ref, m = _oracle_pair(dev, 'base', 12, T, M, seed=51, wscale=1.0)
+    ref.train(); m.train()
+    ref.transformer.checkpoint_layers = True
+    g = torch.Generator().manual_seed(52)
+    ids = torch.randint(4, V, (1, T), generator=g)
+    lab = ids.clone(); lab[0, T - 100:] = -100
+    ro = ref(ids, labels=lab)
+    ro.loss.backward()
+    m.zero_grad()
+    o = m(input_ids=ids.to(dev), labels=lab.to(dev))
+    m.backward()
+    torch.cuda.synchronize()
+    assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-3
+    last_ln_bias = 'transformer.layers.11.pos_ff.layer_norm.bias'
+    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (0.10, 0.995) if k == last_ln_bias else (0.06, 0.998)
+    named = [(n, p.grad) for n, p in ref.named_parameters()]
+    bad, worst = _grad_table([x for x in named if x[0] != last_ln_bias], m.engine, lim, skip=('crit.out_layers.0.weight',))
+    bad2, w2 = _grad_table([x for x in named if x[0] == last_ln_bias], m.engine, lim)
+    bad.update(bad2)
+    rnet = {n: (round(((m.engine.g32(n).float().cpu().reshape(gr.shape) - gr).norm() / gr.norm()).item(), 4))
+            for n, gr in named if n.endswith('r_net.weight')}
+    print(f'C3 12-layer gradients vs oracle: worst rel {worst[0]:.4f}, worst cosine {worst[1]:.5f}; last LayerNorm bias '
+          f'{w2[0]:.4f} / {w2[1]:.5f}; r_net.weight rel per layer {rnet}')
+    assert not bad, bad
+
+
+def test_c5_topk_sampling_in_graph_at_batch64(dev):
+    """SURVEY C5 as bench.py times it: 12L / 768d, M = 2048, 64 prompts x 256 tokens, `top_k = 8` multinomial sampling
+    (musicnlp/trainer/eval.py:277-326, README top_k 8) inside the hipGraph-captured step, generated to T = 2048.  (i) every
+    sampled id lies in the top-8 of the log-probs of ITS OWN step; (ii) over the 64 x 1792 draws the number of times the k-th
+    most likely token was taken matches its expectation sum p_k under the renormalised top-8 distribution (|z| < 5 per rank:
+    the draws are independent given the log-probs) and the mean log-probability of the taken token matches its expectation;
+    (iii) rows differ from each other and from the greedy continuation (the per-row RNG streams are distinct)."""
+    from symbolic_music_generation_amd.generate import XLDecoder
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    B, Tp, TOT, K = 64, 256, 2048, 8
+    cfg = MyTransfoXLConfig('base', max_length=2048, vocab_size=V, mem_len=2048, cutoffs=[])
+    m = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).eval()
+    with torch.no_grad():        # sharpen the untrained model a little so the top-8 probabilities are not all equal
+        m.engine.P.mul_(2.0)
+        m.engine.sync_weights() if hasattr(m.engine, 'sync_weights') else None
+    g = torch.Generator().manual_seed(32)
+    prompt = torch.randint(4, V, (B, Tp), generator=g)
+    dec = XLDecoder(m.engine, B, TOT, seed=5)
+    dec.trace = torch.zeros(B, TOT, V, device=dev)
+    with torch.no_grad():
+        ids = dec.generate(prompt.to(dev), TOT, do_sample=True, top_k=K, temperature=1.0, use_graph=True)
+    assert ids.shape == (B, TOT) and torch.equal(ids[:, :Tp].cpu(), prompt)
+    tr = dec.trace[:, Tp - 1:TOT - 1].double()                      # log-probs that chose tokens Tp .. TOT-1
+    new = ids[:, Tp:]
+    top = tr.topk(K, -1)
+    hit = top.indices == new.unsqueeze(-1)
+    assert hit.any(-1).all(), 'a sampled id outside the top-8 of its own step'                        # (i)
+    p = torch.softmax(top.values, -1)                                # renormalised top-8 (HF: top-k filter, then renormalise)
+    obs = hit.double().sum((0, 1))
+    exp = p.sum((0, 1))
+    var = (p * (1 - p)).sum((0, 1))
+    z = (obs - exp) / var.sqrt()
+    lp_taken = (torch.log(p) * hit).sum(-1)
+    lp_exp = (p * torch.log(p)).sum(-1)
+    lp_var = (p * torch.log(p) ** 2).sum(-1) - lp_exp ** 2
+    z_lp = ((lp_taken - lp_exp).sum() / lp_var.sum().sqrt()).item()
+    print(f'C5 top-8 sampling, {new.numel()} draws: rank counts {obs.long().tolist()} expected {[round(x) for x in exp.tolist()]} '
+          f'z {[round(x, 2) for x in z.tolist()]}; taken-token log-prob z = {z_lp:.2f}; mean p(top-1) {p[..., 0].mean().item():.3f}')
+    assert z.abs().max().item() < 5.0 and abs(z_lp) < 5.0                                             # (ii)
+    assert p[..., 0].mean().item() < 0.9                             # the test has power: the distributions are not one-hot
+    assert len({tuple(r.tolist()) for r in new[:, :16].cpu()}) > B // 2                               # (iii)
+    assert (new != tr.argmax(-1)).float().mean().item() > 0.2
+
+
+def test_c3_bench_batch_dropout_step_is_a_function_of_seed_and_step(dev):
+    """bench.py's timed workload itself (C3, per-GPU batch 64, dropout 0.1 on): the masks are never stored, the backward
+    REGENERATES them from (seed, step, site, element index).  (a) op level, at the step's own sizes (131072 x 768 and its 64-bit
+    element indices): the mask `mxl_ln_residual_bwd` regenerates equals the one `mxl_ln_residual_fwd` applied, element for
+    element, and another site / seed gives another mask; (b) whole step: run twice from the same parameters and the same
+    rng_step -- same loss to fp32 atomic ordering, every parameter's gradient equal to 1e-4 rel-Frobenius (the weight-gradient /
+    dRd / bias atomics reorder, nothing else may move); a different rng_step moves the loss."""
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    B = 64
+    N = B * T
+    # (a)
+    x = torch.ones(N, D, device=dev, dtype=torch.bfloat16)
+    res = torch.zeros_like(x)
+    gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.ln_residual_fwd(x, res, gam, bet, y, z, mean, rstd, drop_p=0.1, seed=1234567, site=9)
+    keep_f = z != 0
+    frac = keep_f.float().mean().item()
+    assert abs(frac - 0.9) < 1e-3, frac
+    dy = torch.ones_like(x)
+    # a z with row variance (LayerNorm backward of a constant row is zero): the mask does not depend on z
+    torch.manual_seed(0)
+    z2 = torch.randn(N, D, device=dev).to(torch.bfloat16)
+    mean2 = z2.float().mean(-1); rstd2 = (z2.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+    dy2 = torch.randn(N, D, device=dev).to(torch.bfloat16)
+    dres, dx = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ops.ln_residual_bwd(dy2, None, z2, mean2, rstd2, gam, dres, dx, dg, db, drop_p=0.1, seed=1234567, site=9)
+    nz = dres != 0
+    assert torch.equal((dx != 0)[nz], keep_f[nz]) and nz.float().mean().item() > 0.99
+    ops.ln_residual_bwd(dy2, None, z2, mean2, rstd2, gam, dres, dx, dg, db, drop_p=0.1, seed=1234567, site=10)
+    assert ((dx != 0)[nz] != keep_f[nz]).float().mean().item() > 0.1
+    del x, res, y, z, dy, z2, dy2, dres, dx, keep_f, nz
+    torch.cuda.empty_cache()
+    # (b)
+    cfg = MyTransfoXLConfig('base', max_length=T, vocab_size=V, n_layer=12, mem_len=M, cutoffs=[])
+    assert cfg.dropout == 0.1
+    m = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
+    eng = m.engine
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(4, V, (B, T), generator=g).to(dev)
+
+    def step(rng_step):
+        eng.rng_step = rng_step
+        with torch.no_grad():
+            eng.zero_grad()
+            o = m(input_ids=ids, labels=ids)
+            eng.backward()
+        torch.cuda.synchronize()
+        return o.loss.item(), eng.G.clone()
+
+    l0, g0 = step(3)
+    l1, g1 = step(3)
+    l2, _ = step(4)
+    assert abs(l0 - l1) < 1e-5 * abs(l0), (l0, l1)
+    assert abs(l0 - l2) > 1e-6 * abs(l0), 'another rng_step must draw other masks'
+    worst = 0.0
+    for name in eng.layout.real_names():
+        a, b = eng.layout.view(g0, name).double(), eng.layout.view(g1, name).double()
+        worst = max(worst, ((a - b).norm() / (a.norm() + 1e-30)).item())
+    print(f'C3 B=64 dropout step twice: loss {l0:.6f} / {l1:.6f} (other step {l2:.6f}), worst gradient rel difference {worst:.2e}')
+    assert worst < 1e-4
