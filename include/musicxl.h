@@ -192,6 +192,35 @@ int mxl_adaptive_nll_bwd_split(const float* logits, int ldl, const void* labels,
 int mxl_adaptive_logprob(const float* logits, int ldl, float* out, int ldo, int N, int V, int ncl,
                          const int* cutoffs_host, void* stream);
 
+/* ---- the same head for LARGE vocabularies (sub-word tokenizers, musicnlp/trainer/wordpiece_tokenizer.py:349-452: V up to 262144
+ * with cutoffs [20000, 40000, 200000], musicnlp/models/transformer_xl.py:53-66), in upstream's own structure
+ * (ProjectedAdaptiveLogSoftmax.forward with labels): the head softmax (c1 shortlist columns + one column per tail cluster) for
+ * every token, the tail softmax of cluster i only for the tokens whose label lies in it (upstream's `mask_i.nonzero()` /
+ * `index_select`), the caller walking tokens in chunks -- a (tokens x V) tensor never exists.  Token row = b*T + t; the label of
+ * row (b, t) is labels[b][t+1] (shift inside, as above); rows with t = T-1 or an ignored label belong to no cluster. */
+/* perm (ncl+2, B*T) int32: row g lists the token rows of group g in increasing order (g = 0 shortlist, 1..ncl tail clusters,
+ * ncl+1 ignored); counts[g] their number; tgt_head[row] = the row's target column in the packed head logits [0,c1) + [c1, c1+ncl)
+ * (-1: ignored); tgt_tail[row] = label - cutoff_i for a tail token, else -1. */
+int mxl_cluster_bucket(const void* labels, int B, int T, int V, int ncl, const int* cutoffs_host, int* perm, int* counts,
+                       int* tgt_head, int* tgt_tail, void* stream);
+/* dst[j][:] = src[idx[j]][:] (bf16 rows of d elements, d % 8 == 0) and its adjoint dst[idx[j]][:] += src[j][:] (idx unique) */
+int mxl_gather_rows_bf16(const void* src, int ld_src, const int* idx, void* dst, int n, int d, void* stream);
+int mxl_scatter_add_rows_bf16(const void* src, const int* idx, void* dst, int ld_dst, int n, int d, void* stream);
+/* logits (n_rows, ld) f32, row j belongs to token rows_idx[j] (or row0 + j when rows_idx is NULL):
+ * lse_out[token] = logsumexp(logits[j][0:ncols]),  pick_out[token] = logits[j][tgt[token]] (0 when tgt[token] < 0) */
+int mxl_rows_lse_pick(const float* logits, long long ld, int ncols, int n_rows, const int* rows_idx, int row0, const int* tgt,
+                      float* lse_out, float* pick_out, void* stream);
+/* nll[b][t] = nll_tok[b*T+t] = (head_lse - head_pick) + (tail_lse - tail_pick if a tail token), 0 for ignored rows;
+ * acc2[0] += sum, acc2[1] += count(nll != 0) (caller zeroes acc2) -- the reduction of transformer_xl.py:198-200 */
+int mxl_bucket_nll_finish(const float* head_lse, const float* head_pick, const float* tail_lse, const float* tail_pick,
+                          const int* tgt_head, const int* tgt_tail, float* nll, float* nll_tok, float* acc2, int B, int T,
+                          void* stream);
+/* out (n_rows, ldo) bf16 = (softmax(logits[j][0:ncols]) - onehot(tgt[token])) * grad_scale / max(acc2[1], 1), pad columns and
+ * the rows of ignored / zero-loss tokens zeroed; out_lo (optional): the bf16 remainder (see mxl_adaptive_nll_bwd_split) */
+int mxl_rows_softmax_grad(const float* logits, long long ld, int ncols, int n_rows, const int* rows_idx, int row0, const int* tgt,
+                          const float* lse, const float* nll_tok, const float* acc2, float grad_scale, void* out_hi, void* out_lo,
+                          int ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser (K18): torch.optim.AdamW + clip_grad_norm_ as configured at musicnlp/trainer/train.py:165-190.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -240,6 +240,40 @@ def adaptive_logprob(logits, out, N, V, cutoffs=()):
     return out
 
 
+# ---- large-vocabulary (bucketed) adaptive softmax: see csrc/head_large.hip
+def cluster_bucket(labels, V, cutoffs, perm, counts, tgt_head, tgt_tail):
+    B, T = labels.shape
+    n, arr = _cut(cutoffs)
+    check(lib().mxl_cluster_bucket(_p(labels), B, T, V, n, C.cast(arr, C.c_void_p), _p(perm), _p(counts), _p(tgt_head),
+                                   _p(tgt_tail), _stream()), 'mxl_cluster_bucket')
+
+
+def gather_rows(src, idx, dst, n):
+    check(lib().mxl_gather_rows_bf16(_p(src), src.stride(-2), _p(idx), _p(dst), n, src.shape[-1], _stream()), 'mxl_gather_rows_bf16')
+    return dst
+
+
+def scatter_add_rows(src, idx, dst, n):
+    check(lib().mxl_scatter_add_rows_bf16(_p(src), _p(idx), _p(dst), dst.stride(-2), n, src.shape[-1], _stream()),
+          'mxl_scatter_add_rows_bf16')
+
+
+def rows_lse_pick(logits, ncols, n_rows, tgt, lse_out, pick_out, rows_idx=None, row0=0):
+    check(lib().mxl_rows_lse_pick(_p(logits), logits.stride(0), ncols, n_rows, _p(rows_idx), row0, _p(tgt), _p(lse_out),
+                                  _p(pick_out), _stream()), 'mxl_rows_lse_pick')
+
+
+def bucket_nll_finish(hlse, hpick, tlse, tpick, tgt_head, tgt_tail, nll, nll_tok, acc2, B, T):
+    check(lib().mxl_bucket_nll_finish(_p(hlse), _p(hpick), _p(tlse), _p(tpick), _p(tgt_head), _p(tgt_tail), _p(nll), _p(nll_tok),
+                                      _p(acc2), B, T, _stream()), 'mxl_bucket_nll_finish')
+
+
+def rows_softmax_grad(logits, ncols, n_rows, tgt, lse, nll_tok, acc2, grad_scale, out_hi, out_lo=None, rows_idx=None, row0=0):
+    check(lib().mxl_rows_softmax_grad(_p(logits), logits.stride(0), ncols, n_rows, _p(rows_idx), row0, _p(tgt), _p(lse), _p(nll_tok),
+                                      _p(acc2), float(grad_scale), _p(out_hi), _p(out_lo), out_hi.stride(0), _stream()),
+          'mxl_rows_softmax_grad')
+
+
 def sumsq(x: torch.Tensor, out_accum: torch.Tensor):
     check(lib().mxl_sumsq_f32(_p(x), x.numel(), _p(out_accum), _stream()), 'mxl_sumsq_f32')
 

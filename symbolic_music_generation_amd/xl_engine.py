@@ -103,6 +103,10 @@ class XLEngine:
         self.base_seed = seed
         self._ws: Dict[Tuple, _WS] = {}
         self._sumsq = torch.zeros(1, device=self.dev)
+        # large vocabularies (the reference's cutoff policy starts clustering for real at V >= 16384, transformer_xl.py:53-66):
+        # the head runs cluster by cluster over bucketed tokens (csrc/head_large.hip) instead of one (tokens, V + clusters) GEMM
+        self.bucketed_head = len(cfg.cutoffs) > 0 and cfg.vocab_size >= 16384
+        self._hb = None            # bucketed-head scratch (per token count)
         self.init_weights(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -234,9 +238,10 @@ class XLEngine:
             ws.d_rd = torch.empty(M, d, **f32)
             ws.d_rd16 = torch.empty(M, d, **bf)
             ws.phi_c = torch.empty(M, d, **bf)
-            ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
-            ws.dlogits_lo = torch.empty(N, self.layout.head_rows_padded, **bf)
-        ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32)
+            if not self.bucketed_head:
+                ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
+                ws.dlogits_lo = torch.empty(N, self.layout.head_rows_padded, **bf)
+        ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32) if not self.bucketed_head else None
         ws.nll = torch.empty(B, max(T - 1, 1), **f32)
         ws.hlse = torch.empty(N, 2, **f32)
         ws.acc = torch.zeros(2, **f32)
@@ -323,8 +328,21 @@ class XLEngine:
         head_w = self.W[:self.layout.head_rows_padded * d].view(self.layout.head_rows_padded, d)
         boff = self.layout.entries['crit.out_layers.0.bias'][0]
         head_b = self.P[boff:boff + nrow]
-        ops.gemm(hid, head_w, ws.logits, N, nrow, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=head_b)
         out = dict(loss=None, losses=None, logprobs=None, mems=new_mems)
+        if self.bucketed_head:
+            if labels is not None:
+                lab = labels.contiguous().clone()
+                ops.label_guard(lab, c.eos_token_id)       # transformer_xl.py:176-182
+                ws.labels = lab
+                ws.acc.zero_()
+                self._bucketed_nll_fwd(ws, hid, lab, B, T)
+                out['losses'] = ws.nll
+                out['loss'] = ws.acc[0] / ws.acc[1]
+            if want_logprobs and (labels is None or not train):
+                out['logprobs'] = self._chunked_logprobs(hid, N, head_w, head_b).view(B, T, V)
+            self._last = ws
+            return out
+        ops.gemm(hid, head_w, ws.logits, N, nrow, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=head_b)
         if labels is not None:
             lab = labels.contiguous().clone()
             ops.label_guard(lab, c.eos_token_id)       # transformer_xl.py:176-182
@@ -339,6 +357,148 @@ class XLEngine:
             out['logprobs'] = lp.view(B, T, V)
         self._last = ws
         return out
+
+    # ------------------------------------------------------------------ large-vocabulary head (csrc/head_large.hip)
+    HEAD_CHUNK_BYTES = 1 << 30          # fp32 logits of one chunk of tokens
+
+    def _hb_scratch(self, N):
+        """per-token arrays of the bucketed head + the packed head operand [E[:c1] ; cluster_weight ; 0] and its bias"""
+        c, dev = self.cfg, self.dev
+        hb = self._hb
+        ncl, c1, d = len(c.cutoffs), c.cutoffs[0], c.d_model
+        if hb is None or hb.N != N:
+            hb = self._hb = _WS()
+            hb.N = N
+            i32 = dict(device=dev, dtype=torch.int32)
+            f32 = dict(device=dev, dtype=torch.float32)
+            hb.perm = torch.empty(ncl + 2, N, **i32)
+            hb.counts = torch.zeros(ncl + 2, **i32)
+            hb.tgt_head, hb.tgt_tail = torch.empty(N, **i32), torch.empty(N, **i32)
+            hb.hlse, hb.hpick, hb.tlse, hb.tpick = (torch.zeros(N, **f32) for _ in range(4))
+            hb.nll_tok = torch.empty(N, **f32)
+            hb.ldh = _r8(c1 + ncl)
+            hb.wp = torch.zeros(hb.ldh, d, device=dev, dtype=torch.bfloat16)
+            hb.bp = torch.zeros(hb.ldh, **f32)
+        return hb
+
+    def _chunk_rows(self, n, cols):
+        ch = max(256, (self.HEAD_CHUNK_BYTES // (4 * max(cols, 1))) // 256 * 256)
+        return min(n, ch)
+
+    def _pack_head(self, hb):
+        c = self.cfg
+        V, ncl, c1, d = c.vocab_size, len(c.cutoffs), c.cutoffs[0], c.d_model
+        head_w = self.W[:self.layout.head_rows_padded * d].view(self.layout.head_rows_padded, d)
+        boff = self.layout.entries['crit.out_layers.0.bias'][0]
+        hb.wp[:c1].copy_(head_w[:c1]); hb.wp[c1:c1 + ncl].copy_(head_w[V:V + ncl])
+        hb.bp[:c1].copy_(self.P[boff:boff + c1]); hb.bp[c1:c1 + ncl].copy_(self.P[boff + V:boff + V + ncl])
+
+    def _bucketed_nll_fwd(self, ws, hid, lab, B, T):
+        """upstream ProjectedAdaptiveLogSoftmax.forward(hidden, labels): head softmax for every token (chunks of tokens), tail
+        softmax of cluster i for the tokens whose label lies in it (bucketed, gathered, chunked)."""
+        c = self.cfg
+        V, cut, d = c.vocab_size, tuple(c.cutoffs), c.d_model
+        ncl, c1, N = len(cut), cut[0], B * T
+        hb = self._hb_scratch(N)
+        self._pack_head(hb)
+        ops.cluster_bucket(lab, V, cut, hb.perm, hb.counts, hb.tgt_head, hb.tgt_tail)
+        counts = hb.counts.cpu().tolist()          # the one host sync of this path (upstream: mask_i.nonzero())
+        hb.counts_host = counts
+        head_w = self.W[:self.layout.head_rows_padded * d].view(self.layout.head_rows_padded, d)
+        boff = self.layout.entries['crit.out_layers.0.bias'][0]
+        ch = self._chunk_rows(N, hb.ldh)
+        hl = torch.empty(ch, hb.ldh, device=self.dev, dtype=torch.float32)
+        for r0 in range(0, N, ch):
+            n = min(ch, N - r0)
+            ops.gemm(hid[r0:r0 + n], hb.wp, hl, n, c1 + ncl, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=hb.bp)
+            ops.rows_lse_pick(hl, c1 + ncl, n, hb.tgt_head, hb.hlse, hb.hpick, row0=r0)
+        del hl
+        bounds = (0,) + cut + (V,)
+        for i in range(1, ncl + 1):
+            n_i, lo, S = counts[i], bounds[i], bounds[i + 1] - bounds[i]
+            if n_i == 0:
+                continue
+            ldt = _r8(S)
+            ch = self._chunk_rows(n_i, ldt)
+            tl = torch.empty(ch, ldt, device=self.dev, dtype=torch.float32)
+            hc = torch.empty(ch, d, device=self.dev, dtype=torch.bfloat16)
+            for j0 in range(0, n_i, ch):
+                n = min(ch, n_i - j0)
+                idx = hb.perm[i, j0:j0 + n]
+                ops.gather_rows(hid, idx, hc, n)
+                ops.gemm(hc, head_w[lo:lo + S], tl, n, S, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=self.P[boff + lo:boff + lo + S])
+                ops.rows_lse_pick(tl, S, n, hb.tgt_tail, hb.tlse, hb.tpick, rows_idx=idx)
+            del tl, hc
+        ops.bucket_nll_finish(hb.hlse, hb.hpick, hb.tlse, hb.tpick, hb.tgt_head, hb.tgt_tail, ws.nll, hb.nll_tok, ws.acc, B, T)
+
+    def _bucketed_head_bwd(self, ws, dy, B, T, grad_scale):
+        """gradients of the bucketed head: logits are recomputed chunk by chunk (one more GEMM per chunk instead of keeping them);
+        the shortlist / cluster-column gradient travels as a two-term bf16 sum like the small-vocabulary head's"""
+        c = self.cfg
+        V, cut, d = c.vocab_size, tuple(c.cutoffs), c.d_model
+        ncl, c1, N = len(cut), cut[0], B * T
+        hb, G, hid = self._hb, self.G, ws.hid
+        AT = F.GEMM_OUT_F32_ATOMIC
+        nrow_p = self.layout.head_rows_padded
+        head_w = self.W[:nrow_p * d].view(nrow_p, d)
+        g_head_w = G[:nrow_p * d].view(nrow_p, d)
+        boff = self.layout.entries['crit.out_layers.0.bias'][0]
+        ch = self._chunk_rows(N, hb.ldh)
+        hl = torch.empty(ch, hb.ldh, device=self.dev, dtype=torch.float32)
+        dl = torch.empty(ch, hb.ldh, device=self.dev, dtype=torch.bfloat16)
+        dl_lo = torch.empty_like(dl)
+        for r0 in range(0, N, ch):
+            n = min(ch, N - r0)
+            x = hid[r0:r0 + n]
+            ops.gemm(x, hb.wp, hl, n, c1 + ncl, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=hb.bp)
+            ops.rows_softmax_grad(hl, c1 + ncl, n, hb.tgt_head, hb.hlse, hb.nll_tok, ws.acc, grad_scale, dl, dl_lo, row0=r0)
+            for term in (dl_lo, dl):
+                ops.colsum(term, G[boff:boff + c1], n, c1)
+                ops.colsum(term[:, c1:], G[boff + V:boff + V + ncl], n, ncl, ld=hb.ldh)
+                ops.gemm(term, x, g_head_w[:c1], c1, d, n, trans_a=True, trans_b=True, flags=AT, ksplits=self._ks(c1, d, n))
+                ops.gemm(term[:, c1:], x, g_head_w[V:V + ncl], ncl, d, n, trans_a=True, trans_b=True, flags=AT, lda=hb.ldh,
+                         ksplits=self._ks(ncl, d, n))
+            ops.gemm(dl_lo, hb.wp, dy[r0:r0 + n], n, d, hb.ldh, trans_b=True)
+            ops.gemm(dl, hb.wp, dy[r0:r0 + n], n, d, hb.ldh, trans_b=True, flags=F.GEMM_ADD_AUX, aux=dy[r0:r0 + n])
+        del hl, dl, dl_lo
+        bounds = (0,) + cut + (V,)
+        for i in range(1, ncl + 1):
+            n_i, lo, S = hb.counts_host[i], bounds[i], bounds[i + 1] - bounds[i]
+            if n_i == 0:
+                continue
+            ldt = _r8(S)
+            ch = self._chunk_rows(n_i, ldt)
+            tl = torch.empty(ch, ldt, device=self.dev, dtype=torch.float32)
+            dtl = torch.empty(ch, ldt, device=self.dev, dtype=torch.bfloat16)
+            hc = torch.empty(ch, d, device=self.dev, dtype=torch.bfloat16)
+            dhc = torch.empty(ch, d, device=self.dev, dtype=torch.bfloat16)
+            for j0 in range(0, n_i, ch):
+                n = min(ch, n_i - j0)
+                idx = hb.perm[i, j0:j0 + n]
+                ops.gather_rows(hid, idx, hc, n)
+                ops.gemm(hc, head_w[lo:lo + S], tl, n, S, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=self.P[boff + lo:boff + lo + S])
+                ops.rows_softmax_grad(tl, S, n, hb.tgt_tail, hb.tlse, hb.nll_tok, ws.acc, grad_scale, dtl, None, rows_idx=idx)
+                ops.colsum(dtl, G[boff + lo:boff + lo + S], n, S)
+                ops.gemm(dtl, hc, g_head_w[lo:lo + S], S, d, n, trans_a=True, trans_b=True, flags=AT, ksplits=self._ks(S, d, n))
+                # K = the padded row length: the pad columns of dtl are zero and the weight rows they meet are finite
+                ops.gemm(dtl, head_w[lo:lo + ldt], dhc, n, d, ldt, trans_b=True)
+                ops.scatter_add_rows(dhc, idx, dy, n)
+            del tl, dtl, hc, dhc
+
+    def _chunked_logprobs(self, hid, N, head_w, head_b):
+        """labels=None branch at a large vocabulary: the full (N, V) log-probabilities the caller asked for, computed over
+        chunks of tokens so that only one chunk's (rows, V + clusters) logits exist at a time"""
+        c = self.cfg
+        V, cut, d = c.vocab_size, tuple(c.cutoffs), c.d_model
+        nrow, nrow_p = self.layout.n_head_rows, self.layout.head_rows_padded
+        lp = torch.empty(N, V, device=self.dev, dtype=torch.float32)
+        ch = self._chunk_rows(N, nrow_p)
+        lg = torch.empty(ch, nrow_p, device=self.dev, dtype=torch.float32)
+        for r0 in range(0, N, ch):
+            n = min(ch, N - r0)
+            ops.gemm(hid[r0:r0 + n], head_w, lg, n, nrow, d, flags=F.GEMM_OUT_F32 | F.GEMM_BIAS, bias=head_b)
+            ops.adaptive_logprob(lg, lp[r0:r0 + n], n, V, cut)
+        return lp
 
     # ------------------------------------------------------------------ backward
     def zero_grad(self):
@@ -379,20 +539,23 @@ class XLEngine:
             return self._lw(l, suffix, G)
 
         # ---- head
-        # the logit gradient travels as a two-term bf16 sum (mxl_adaptive_nll_bwd_split): every consumer runs once per term and
-        # accumulates -- the small term first where the output is rounded (the input gradient), so that it is rounded once
-        ops.adaptive_nll_bwd(ws.logits, ws.labels, ws.nll, ws.hlse, ws.acc, ws.dlogits, B, T, V, cut, grad_scale,
-                             dlogits_lo=ws.dlogits_lo)
-        head_w = self.W[:nrow_p * d].view(nrow_p, d)
-        g_head_w = G[:nrow_p * d].view(nrow_p, d)
-        boff = self.layout.entries['crit.out_layers.0.bias'][0]
         dy, dy2 = ws.dA, None
-        for term in (ws.dlogits_lo, ws.dlogits):
-            ops.colsum(term, G[boff:boff + nrow], N, nrow)
-            ops.gemm(term, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
-                     ksplits=self._ks(nrow_p, d, N))
-        ops.gemm(ws.dlogits_lo, head_w, dy, N, d, nrow_p, trans_b=True)
-        ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True, flags=F.GEMM_ADD_AUX, aux=dy)
+        if self.bucketed_head:
+            self._bucketed_head_bwd(ws, dy, B, T, grad_scale)
+        else:
+            # the logit gradient travels as a two-term bf16 sum (mxl_adaptive_nll_bwd_split): every consumer runs once per term and
+            # accumulates -- the small term first where the output is rounded (the input gradient), so that it is rounded once
+            ops.adaptive_nll_bwd(ws.logits, ws.labels, ws.nll, ws.hlse, ws.acc, ws.dlogits, B, T, V, cut, grad_scale,
+                                 dlogits_lo=ws.dlogits_lo)
+            head_w = self.W[:nrow_p * d].view(nrow_p, d)
+            g_head_w = G[:nrow_p * d].view(nrow_p, d)
+            boff = self.layout.entries['crit.out_layers.0.bias'][0]
+            for term in (ws.dlogits_lo, ws.dlogits):
+                ops.colsum(term, G[boff:boff + nrow], N, nrow)
+                ops.gemm(term, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
+                         ksplits=self._ks(nrow_p, d, N))
+            ops.gemm(ws.dlogits_lo, head_w, dy, N, d, nrow_p, trans_b=True)
+            ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True, flags=F.GEMM_ADD_AUX, aux=dy)
         if p > 0:
             ops.dropout(dy, dy, p, seed=seed, site=self.SITE_FINAL)
         st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
