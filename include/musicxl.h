@@ -354,6 +354,12 @@ int mxl_argmax_rows(const float* logits, int ld, void* ids_out, int N, int V, vo
 int mxl_eval_counts(const void* preds, int ld_preds, const void* labels, int ld_labels, const signed char* id2pc, int V,
                     int* out14, int B, int T, int clm_pred_shifted, void* stream);
 
+/* the same over a SUB-WORD vocabulary (musicnlp/trainer/wordpiece_tokenizer.py:349-452, pair_merge_tokenizer.py:200-289), whose ids
+ * stand for several base tokens: id2hist uint8 (V, 12) = number of pitches of each class an id expands to (the reference's
+ * per-id `_id2pchs_exc` lists, wordpiece_tokenizer.py:372-379, reduced to pitch classes) */
+int mxl_eval_counts_multi(const void* preds, int ld_preds, const void* labels, int ld_labels, const unsigned char* id2hist, int V,
+                          int* out14, int B, int T, int clm_pred_shifted, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Input pipeline: the pad / truncate / label contract of `tokenizer(toks, padding='max_length',
  * truncation=True)` (musicnlp/preprocess/dataset.py:361) + DataCollatorForLanguageModeling(mlm=False) (train.py:360),

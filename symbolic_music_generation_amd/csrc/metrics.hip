@@ -62,6 +62,39 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const long long* preds
     if (threadIdx.x < 14) out[b * 14 + threadIdx.x] = hist[threadIdx.x];
 }
 
+// the same for SUB-WORD vocabularies (WordPiece / pair-merge ids stand for several base tokens: the reference's
+// `WordPieceMusicTokenizer.ids2pitches` / `PairMergeTokenizer.ids2pitches`, wordpiece_tokenizer.py:450-452, expand every id into the
+// pitches of its base tokens): id2hist[v][pc] = how many pitches of class pc id v stands for
+__global__ __launch_bounds__(256) void eval_counts_multi_kernel(const long long* preds, int ldp, const long long* labels, int ldl,
+                                                                const unsigned char* id2hist, int V, int* out, int T, int shifted) {
+    __shared__ int hist[14];
+    if (threadIdx.x < 14) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const long long* pr = preds + (size_t)b * ldp;
+    const long long* lb = labels + (size_t)b * ldl;
+    int correct = 0, total = 0;
+    const int np = shifted ? T - 1 : T;
+    for (int j = threadIdx.x; j < np; j += 256) {
+        const long long p = pr[j];
+        const long long lk = shifted ? lb[j + 1] : lb[j];
+        if (lk != -100 && p >= 0 && p < V) {
+            const unsigned char* h = id2hist + (size_t)p * 12;
+#pragma unroll
+            for (int pc = 0; pc < 12; pc++) if (h[pc]) atomicAdd(&hist[pc], (int)h[pc]);
+        }
+        if (j < T - 1) {
+            const long long ln = lb[j + 1];
+            if (ln != -100) { total++; correct += (p == ln) ? 1 : 0; }
+        }
+    }
+    correct = (int)wave_sum((float)correct);
+    total = (int)wave_sum((float)total);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&hist[12], correct); atomicAdd(&hist[13], total); }
+    __syncthreads();
+    if (threadIdx.x < 14) out[b * 14 + threadIdx.x] = hist[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" int mxl_argmax_rows(const float* logits, int ld, void* ids_out, int N, int V, void* stream) {
@@ -77,6 +110,16 @@ extern "C" int mxl_eval_counts(const void* preds, int ld_preds, const void* labe
     MXL_CHECK_ARG(ld_labels >= T && ld_preds >= (clm_pred_shifted ? T - 1 : T) && T < (1 << 24));
     hipLaunchKernelGGL(eval_counts_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)preds, ld_preds,
                        (const long long*)labels, ld_labels, id2pc, V, out14, T, clm_pred_shifted);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_eval_counts_multi(const void* preds, int ld_preds, const void* labels, int ld_labels, const unsigned char* id2hist,
+                                     int V, int* out14, int B, int T, int clm_pred_shifted, void* stream) {
+    MXL_CHECK_ARG(preds && labels && id2hist && out14 && B > 0 && T > 1 && V > 0);
+    MXL_CHECK_ARG(ld_labels >= T && ld_preds >= (clm_pred_shifted ? T - 1 : T) && T < (1 << 24));
+    hipLaunchKernelGGL(eval_counts_multi_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)preds, ld_preds,
+                       (const long long*)labels, ld_labels, id2hist, V, out14, T, clm_pred_shifted);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -56,6 +56,19 @@ def pitch_class_table(vocab) -> np.ndarray:
     return tab
 
 
+def pitch_class_hist_table(tokenizer) -> np.ndarray:
+    """uint8 (V, 12) for a sub-word tokenizer (`id2base_ids`): how many pitches of each class one id expands to -- the reference's
+    per-id pitch lists `_id2pchs_exc` (wordpiece_tokenizer.py:372-379, pair_merge_tokenizer.py:214-221) reduced to classes"""
+    base = pitch_class_table(tokenizer.vocab)
+    rows = tokenizer.id2base_ids()
+    tab = np.zeros((len(rows), 12), dtype=np.uint8)
+    for i, ids in enumerate(rows):
+        for b in ids:
+            if 0 <= b < len(base) and base[b] >= 0:
+                tab[i, base[b]] += 1
+    return tab
+
+
 def max_out_logits(logits: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """train.py:362 `preprocess_logits_for_metrics`: (B, T, V) scores -> (B, T) greedy ids without leaving the device"""
     if not logits.is_cuda:
@@ -77,10 +90,15 @@ class ComputeMetrics:
             raise ValueError(f'Training Mode for IKR mismatch: {mode}')
         self.tokenizer, self.vocab = tokenizer, tokenizer.vocab
         self.mode, self.clm_pred_shifted = mode, clm_pred_shifted
-        self._pc_host = pitch_class_table(self.vocab)
+        # a sub-word tokenizer's ids expand to several base tokens: per-id pitch-class counts instead of one class per id
+        self.subword = hasattr(tokenizer, 'id2base_ids')
+        self._pc_host = pitch_class_hist_table(tokenizer) if self.subword else pitch_class_table(self.vocab)
         self._pc_dev: Dict[torch.device, torch.Tensor] = {}
         self._in_key = in_key_table()
         self._key_id = {self.vocab.t2i(f'Key_{k}'): o for o, k in enumerate(KEY_NAMES) if f'Key_{k}' in self.vocab}
+        if self.subword:        # the key token of 'ins-key' labels, as an id of the sub-word vocabulary (ids of one base token)
+            base_key = self._key_id
+            self._key_id = {i: base_key[b[0]] for i, b in enumerate(tokenizer.id2base_ids()) if len(b) == 1 and b[0] in base_key}
 
     def counts(self, preds: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """(B, 14) int32 on the device: pitch-class histogram [12], #correct, #counted"""
@@ -94,9 +112,9 @@ class ComputeMetrics:
         if preds.device not in self._pc_dev:
             self._pc_dev[preds.device] = torch.from_numpy(self._pc_host).to(preds.device)
         out = torch.empty(B, 14, device=preds.device, dtype=torch.int32)
-        check(lib().mxl_eval_counts(preds.data_ptr(), preds.stride(0), labels.data_ptr(), labels.stride(0),
-                                    self._pc_dev[preds.device].data_ptr(), len(self.vocab), out.data_ptr(), B, T,
-                                    int(self.clm_pred_shifted), torch.cuda.current_stream().cuda_stream), 'mxl_eval_counts')
+        fn, what = (lib().mxl_eval_counts_multi, 'mxl_eval_counts_multi') if self.subword else (lib().mxl_eval_counts, 'mxl_eval_counts')
+        check(fn(preds.data_ptr(), preds.stride(0), labels.data_ptr(), labels.stride(0), self._pc_dev[preds.device].data_ptr(),
+                 len(self._pc_host), out.data_ptr(), B, T, int(self.clm_pred_shifted), torch.cuda.current_stream().cuda_stream), what)
         return out
 
     def ikr_from_counts(self, counts: np.ndarray, labels=None, key_scores=None) -> float:
@@ -114,7 +132,7 @@ class ComputeMetrics:
             for b in range(len(ratio)):
                 kid = int(lab[b, pos])
                 if kid not in self._key_id:
-                    raise ValueError(f'Expect key token at 3rd position of label, got {kid}:{self.vocab.i2t(kid) if 0 <= kid < len(self.vocab) else "?"}')
+                    raise ValueError(f'Expect key token at 3rd position of label, got {kid}')
                 per_row[b] = ratio[b, self._key_id[kid]]
         return float(per_row.mean())
 

