@@ -275,6 +275,15 @@ int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, con
                float temperature, float repetition_penalty, float typical_p, float* out_probs, void* stream);
 /* t_dev += 1; rng_ctr += 1 */
 int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream);
+/* Contrastive search (the reference's 'contrastive' strategy, musicnlp/trainer/eval.py:296-302, over the mems patch of
+ * musicnlp/models/transformer_xl.py:229-234; HF 4.25.1 GenerationMixin.contrastive_search with `_ranking_fast`):
+ *   score[b*K + k] = (1 - alpha) * probs[b*K + k] - alpha * max_{s < S} cos(hid[b*K + k], ctx[b][s]);  sel[b] = argmax_k score
+ * ctx (B, ., d) bf16 = last-layer hidden states of the S context positions (batch stride ctx_bs elements), ctx_inv_norm (B, .) f32
+ * their reciprocal norms (mxl_row_inv_norm_bf16; batch stride inv_bs), hid (B*K, d) bf16 the candidates' hidden states,
+ * probs (B*K) f32 their top-k probabilities; sel int64 (B). */
+int mxl_row_inv_norm_bf16(const void* x, long long ld, int n, int d, float* out, void* stream);
+int mxl_contrastive_select(const void* ctx, long long ctx_bs, const float* ctx_inv_norm, int inv_bs, int S, const void* hid,
+                           const float* probs, float alpha, int B, int K, int d, float* score, void* sel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Reformer path (A6-A8): replaces HuggingFace modeling_reformer.py as reached through

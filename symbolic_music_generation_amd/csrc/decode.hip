@@ -528,3 +528,89 @@ extern "C" int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void*
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Contrastive search (HF 4.25.1 GenerationMixin.contrastive_search / _ranking_fast, reached from
+// musicnlp/trainer/eval.py:296-302 with the mems patch of musicnlp/models/transformer_xl.py:229-234): candidate k of sequence b
+// is scored  (1 - alpha) * p[b][k]  -  alpha * max_s cos(h_cand[b*K + k], h_ctx[b][s]),  s over the S context positions.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const bf16_t* x, long long ld, int d, float* out, int n) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const bf16_t* r = x + (size_t)j * ld;
+    float s = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(r + c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float f = bf2f((bf16_t)v[k]); s += f * f; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[j] = rsqrtf(s);
+}
+
+// one workgroup per candidate row: four waves stride over the context positions, 8 bf16 per lane per pass over d
+__global__ __launch_bounds__(256) void contrastive_score_kernel(const bf16_t* ctx, long long ctx_bs, const float* ctx_inv, int inv_bs,
+                                                                int S, const bf16_t* hid, int d, const float* probs, float alpha,
+                                                                int K, float* score) {
+    __shared__ float wmax[4];
+    const int row = blockIdx.x, b = row / K, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bf16_t* h = hid + (size_t)row * d;
+    float hn = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float f = bf2f((bf16_t)v[k]); hn += f * f; }
+    }
+    hn = rsqrtf(wave_sum(hn));
+    float best = -INFINITY;
+    for (int s = wid; s < S; s += 4) {
+        const bf16_t* c_ = ctx + (size_t)b * ctx_bs + (size_t)s * d;
+        float dot = 0.f;
+        for (int c = lane * 8; c < d; c += 512) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + c);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(c_ + c);
+#pragma unroll
+            for (int k = 0; k < 8; k++) dot += bf2f((bf16_t)a[k]) * bf2f((bf16_t)v[k]);
+        }
+        dot = wave_sum(dot) * hn * ctx_inv[(size_t)b * inv_bs + s];
+        best = fmaxf(best, dot);
+    }
+    if (lane == 0) wmax[wid] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float pen = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        score[row] = (1.f - alpha) * probs[row] - alpha * pen;
+    }
+}
+
+__global__ void contrastive_pick_kernel(const float* score, int K, long long* sel, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int bi = 0;
+    float bv = score[(size_t)b * K];
+    for (int k = 1; k < K; k++) {
+        const float v = score[(size_t)b * K + k];
+        if (v > bv) { bv = v; bi = k; }             // first maximum, as torch.max
+    }
+    sel[b] = bi;
+}
+}  // namespace
+
+extern "C" int mxl_row_inv_norm_bf16(const void* x, long long ld, int n, int d, float* out, void* stream) {
+    MXL_CHECK_ARG(x && out && n > 0 && d > 0 && (d % 8) == 0 && (ld % 8) == 0);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, d, out, n);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_contrastive_select(const void* ctx, long long ctx_bs, const float* ctx_inv_norm, int inv_bs, int S, const void* hid,
+                                      const float* probs, float alpha, int B, int K, int d, float* score, void* sel, void* stream) {
+    MXL_CHECK_ARG(ctx && ctx_inv_norm && hid && probs && score && sel && B > 0 && K > 0 && S > 0 && d > 0 && (d % 8) == 0 &&
+                  (ctx_bs % 8) == 0);
+    hipLaunchKernelGGL(contrastive_score_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ctx, ctx_bs,
+                       ctx_inv_norm, inv_bs, S, (const bf16_t*)hid, d, probs, alpha, K, score);
+    hipLaunchKernelGGL(contrastive_pick_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, score, K, (long long*)sel, B);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

@@ -340,6 +340,165 @@ def beam_search(dec, prompt: torch.Tensor, max_length: int, num_beams: int = 3, 
     return (out, torch.tensor(scores)) if return_scores else out
 
 
+def group_beam_search(dec, prompt: torch.Tensor, max_length: int, num_beams: int = 4, num_beam_groups: int = 2,
+                      diversity_penalty: float = 0.0, early_stopping: bool = True, length_penalty: float = 1.0,
+                      num_return_sequences: int = 1, eos_token_id: int = 0, pad_token_id: Optional[int] = None,
+                      return_scores: bool = False):
+    """HF 4.25.1 `group_beam_search` (diverse beam search, Vijayakumar et al.) with `BeamSearchScorer(num_beam_groups=...)` and
+    `HammingDiversityLogitsProcessor`, as `model.generate(num_beams=, num_beam_groups=, diversity_penalty=)` reaches them from
+    the reference's 'beam' strategy (musicnlp/trainer/eval.py:303-317: num_beam_groups set => do_sample False).  One decoder row
+    per beam; per step ONE forward for all beams, then the groups in order: group g's log-probabilities are lowered by
+    diversity_penalty x (how many beams of the EARLIER groups of the same item chose that token at this step), its 2 x group_size
+    best continuations go through the scorer walk (one hypothesis heap and one done flag per item, shared by its groups, as in
+    4.25.1), and its rows follow their beams.  The first beam of every group starts at score 0, the others at -1e9."""
+    e, c = dec.eng, dec.eng.cfg
+    dev, V = e.dev, c.vocab_size
+    nb, ng = num_beams, num_beam_groups
+    if ng < 2 or nb % ng != 0:
+        raise ValueError('`num_beams` should be divisible by `num_beam_groups` for group beam search.')      # HF's message
+    gs = nb // ng
+    pad = eos_token_id if pad_token_id is None else pad_token_id
+    B0, Tp = prompt.shape
+    if num_return_sequences > nb:
+        raise MusicXLError('num_return_sequences has to be smaller or equal to num_beams')
+    rows = B0 * nb
+    if dec.B != rows or max_length > dec.Tmax:
+        raise MusicXLError(f'the decoder was built for {dec.B} rows x {dec.Tmax} positions, group beam search needs {rows} x {max_length}')
+    dec.beam_prefill(prompt.repeat_interleave(nb, 0).to(dev))
+    beam_scores = torch.full((B0, nb), -1e9, device=dev)
+    beam_scores[:, ::gs] = 0
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(nb, length_penalty, early_stopping) for _ in range(B0)]
+    done = [False] * B0
+    cur_len = Tp
+    ident = torch.arange(rows, device=dev)
+    while True:
+        logp = dec.beam_logp()                                   # (rows, V), every beam of every group
+        current = torch.zeros(rows, dtype=torch.int64, device=dev)
+        reorder = ident.clone()
+        new_scores = beam_scores.clone()
+        for g in range(ng):
+            g0 = g * gs
+            gidx = (torch.arange(B0, device=dev)[:, None] * nb + g0 + torch.arange(gs, device=dev)[None, :]).view(-1)
+            sc = logp.index_select(0, gidx)
+            if diversity_penalty and diversity_penalty > 0.0 and g > 0:
+                # HammingDiversityLogitsProcessor: tokens the earlier groups of the same item have just chosen
+                prev = current.view(B0, nb)[:, :g0]
+                freq = torch.zeros(B0, V, device=dev).scatter_add_(1, prev, torch.ones_like(prev, dtype=torch.float32))
+                sc = sc - diversity_penalty * freq.repeat_interleave(gs, 0)
+            sc = sc + beam_scores.index_select(0, gidx)[:, None]
+            top_s, top_i = sc.view(B0, gs * V).topk(2 * gs, dim=1, largest=True, sorted=True)
+            top_b, top_t, top_sl = (top_i // V).tolist(), (top_i % V).tolist(), top_s.tolist()
+            n_s, n_t, n_i = [[0.0] * gs for _ in range(B0)], [[pad] * gs for _ in range(B0)], [[0] * gs for _ in range(B0)]
+            for b in range(B0):
+                if done[b]:
+                    n_i[b] = [b * nb + g0 + j for j in range(gs)]
+                    continue
+                k = 0
+                for rank in range(2 * gs):
+                    tok, s_, src = top_t[b][rank], top_sl[b][rank], b * nb + g0 + top_b[b][rank]
+                    if tok == eos_token_id:
+                        if rank >= gs:
+                            continue
+                        hyps[b].add(dec.ids[src, :cur_len].clone(), s_)
+                    else:
+                        n_s[b][k], n_t[b][k], n_i[b][k] = s_, tok, src
+                        k += 1
+                    if k == gs:
+                        break
+                if k < gs:
+                    raise MusicXLError(f'at most {gs} tokens in the top {2 * gs} can be eos')
+                done[b] = done[b] or hyps[b].is_done(max(top_sl[b]), cur_len)
+            new_scores[gidx] = torch.tensor(n_s, device=dev).view(-1)
+            current[gidx] = torch.tensor(n_t, device=dev).view(-1)
+            reorder[gidx] = torch.tensor(n_i, device=dev).view(-1)
+        beam_scores = new_scores
+        if not torch.equal(reorder, ident):
+            dec.beam_reorder(reorder)
+        dec.ids[:, cur_len] = current
+        cur_len += 1
+        if all(done) or cur_len >= max_length:
+            break
+        dec.beam_advance(cur_len)
+    final = beam_scores.tolist()
+    for b in range(B0):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(dec.ids[b * nb + j, :cur_len].clone(), final[b * nb + j])
+    best, scores = [], []
+    for b in range(B0):
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(num_return_sequences):
+            sc_, h = ranked.pop()
+            best.append(h); scores.append(sc_)
+    L = min(max(len(h) for h in best) + 1, max_length)
+    out = torch.full((len(best), L), pad, dtype=torch.int64, device=dev)
+    for i, h in enumerate(best):
+        out[i, :len(h)] = h
+        if len(h) < L:
+            out[i, len(h)] = eos_token_id
+    return (out, torch.tensor(scores)) if return_scores else out
+
+
+def contrastive_search(dec, prompt: torch.Tensor, max_length: int, top_k: int = 4, penalty_alpha: float = 0.6,
+                       eos_token_id: Optional[int] = 0, pad_token_id: Optional[int] = None) -> torch.Tensor:
+    """HF 4.25.1 `GenerationMixin.contrastive_search` over Transformer-XL mems -- the reference's 'contrastive' strategy
+    (musicnlp/trainer/eval.py:296-302); the reference's `prepare_inputs_for_generation` re-stacks the per-row mems lists that
+    routine builds ("to work with cosine sim generation", musicnlp/models/transformer_xl.py:229-234).  One decoder row per
+    (sequence, candidate): the K = top_k rows of a sequence share its history.  Per step: (1) the top-k tokens of the current
+    log-probabilities and their probabilities renormalised over those k (TopKLogitsWarper, then softmax); (2) all B * K
+    candidates through one cached decode step; (3) mxl_contrastive_select scores each candidate (1 - alpha) * p - alpha * max
+    cosine similarity between its last-layer hidden state and those of every earlier position, and picks the best; (4) the K
+    rows of the sequence take over the picked candidate's rings and history, its log-probabilities open the next step."""
+    e, c = dec.eng, dec.eng.cfg
+    dev, d, L = e.dev, c.d_model, c.n_layer
+    K = int(top_k)
+    if K < 2 or not penalty_alpha or penalty_alpha <= 0:
+        raise ValueError('contrastive search needs top_k > 1 and penalty_alpha > 0')
+    B0, Tp = prompt.shape
+    rows = B0 * K
+    if dec.B != rows or max_length > dec.Tmax:
+        raise MusicXLError(f'the decoder was built for {dec.B} rows x {dec.Tmax} positions, contrastive search needs {rows} x {max_length}')
+    pad = eos_token_id if pad_token_id is None else pad_token_id
+    dec.beam_prefill(prompt.repeat_interleave(K, 0).to(dev))
+    ws = e._last
+    hid0 = (ws.h[L & 1]).view(rows, Tp, d)[::K]                          # last-layer output of every prompt position
+    ctx = torch.empty(B0, max_length, d, device=dev, dtype=torch.bfloat16)
+    inv = torch.empty(B0, max_length, device=dev, dtype=torch.float32)
+    ctx[:, :Tp].copy_(hid0)
+    for b in range(B0):
+        ops.row_inv_norm(ctx[b, :Tp], inv[b, :Tp], Tp)
+    logp = dec.beam_logp()[::K].clone()                                  # (B0, V)
+    score = torch.empty(rows, device=dev, dtype=torch.float32)
+    sel = torch.empty(B0, device=dev, dtype=torch.int64)
+    grp = torch.arange(B0, device=dev) * K
+    unfinished = torch.ones(B0, dtype=torch.bool, device=dev)
+    cur_len = Tp
+    while cur_len < max_length:
+        top_lp, top_ids = logp.topk(K, dim=-1)
+        probs = torch.softmax(top_lp.float(), dim=-1).contiguous()
+        dec.ids[:, cur_len] = top_ids.reshape(-1)
+        dec.beam_advance(cur_len + 1)                                    # every candidate at position cur_len
+        hid = dec.h[L & 1]
+        ops.contrastive_select(ctx, inv, cur_len, hid, probs, penalty_alpha, score, sel)
+        src = grp + sel
+        if eos_token_id is not None:                                     # finished sequences emit pad from now on
+            tok = dec.ids[src, cur_len]
+            tok = torch.where(unfinished, tok, torch.full_like(tok, pad))
+        dec.beam_reorder(src.repeat_interleave(K))
+        if eos_token_id is not None:
+            dec.ids[:, cur_len] = tok.repeat_interleave(K)
+            unfinished = unfinished & (tok != eos_token_id)
+        ctx[:, cur_len].copy_(hid.index_select(0, src))
+        ops.row_inv_norm(ctx[:, cur_len], inv[:, cur_len], B0)
+        logp = dec.beam_logp().index_select(0, src)
+        cur_len += 1
+        if eos_token_id is not None and not bool(unfinished.any()):
+            break
+    return dec.ids[::K, :cur_len].clone()
+
+
 def _warp(scores: torch.Tensor, top_k, top_p, typical_p, temperature, min_keep: int, renormalize: bool = True) -> torch.Tensor:
     """HF 4.25.1 logits warpers in `_get_logits_warper` order (temperature, top-k, top-p, typical-p, then
     LogitNormalization when renormalize_logits is set -- the reference sets it for every sampling call, eval.py:323) on a

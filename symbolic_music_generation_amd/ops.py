@@ -461,6 +461,20 @@ def decode_advance(t_dev, rng_ctr):
     check(lib().mxl_decode_advance(_p(t_dev), _p(rng_ctr), _stream()), 'mxl_decode_advance')
 
 
+def row_inv_norm(x, out, n):
+    """out[j] = 1 / ||x[j]||  (bf16 rows)"""
+    check(lib().mxl_row_inv_norm_bf16(_p(x), x.stride(-2), n, x.shape[-1], _p(out), _stream()), 'mxl_row_inv_norm_bf16')
+    return out
+
+
+def contrastive_select(ctx, ctx_inv, S, hid, probs, alpha, score, sel):
+    """see mxl_contrastive_select: ctx (B, Smax, d) bf16, ctx_inv (B, Smax) f32, hid (B*K, d) bf16, probs (B, K) f32"""
+    B, K = probs.shape
+    check(lib().mxl_contrastive_select(_p(ctx), ctx.stride(0), _p(ctx_inv), ctx_inv.stride(0), S, _p(hid), _p(probs), float(alpha),
+                                       B, K, ctx.shape[-1], _p(score), _p(sel), _stream()), 'mxl_contrastive_select')
+    return sel
+
+
 # ------------------------------------------------------------------ reformer
 def axial_embed_fwd(ids, E, W0, W1, out, A0, A1, drop_p=0.0, seed=0, site_emb=0, site_pos=1):
     B, T = ids.shape

@@ -196,21 +196,31 @@ class MyTransfoXLLMHeadModel(EngineModule):
                  penalty_alpha=None, typical_p=None, repetition_penalty=None, early_stopping=None,
                  renormalize_logits=None, num_return_sequences: int = 1, num_beam_groups: int = 1, length_penalty: float = 1.0,
                  use_graph: bool = True, seed: int = 77, **unused) -> torch.Tensor:
-        """`model.generate(**inputs, **args)` as called at musicnlp/trainer/eval.py:333: the greedy, sample and beam strategies
-        (eval.py:277-321).  `num_return_sequences` expands the prompts as HF does (repeat_interleave).  Contrastive search
-        (`penalty_alpha`) raises as it does in the reference stack: HF 4.25.1 requires `past_key_values` in the model output for
-        it, and TransfoXL returns `mems`.  Diverse (group) beam search is not implemented."""
-        from .generate import XLDecoder, beam_search
+        """`model.generate(**inputs, **args)` as called at musicnlp/trainer/eval.py:333: the greedy, sample, contrastive and beam
+        strategies (eval.py:277-321), beam search in its plain, sampling and diverse-group forms.  `num_return_sequences` expands the
+        prompts as HF does (repeat_interleave).  Mode selection follows HF 4.25.1 `generate`: contrastive search when
+        `penalty_alpha > 0`, `top_k > 1`, `do_sample` false and one beam; group beam search when `num_beam_groups > 1`."""
+        from .generate import XLDecoder, beam_search, contrastive_search, group_beam_search
         # HF 4.25.1 fills unspecified generation arguments from the model config; PretrainedConfig's default top_k is 50, so
         # `generate(do_sample=True)` without top_k samples from the 50 best tokens (the reference relies on these defaults)
         top_k = getattr(self.config, 'top_k', 50) if top_k is None else top_k
-        if penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and not do_sample:
-            raise ValueError(f'{type(self).__name__} does not support caching through `past_key_values` and therefore '
-                             "**can't** be used for contrastive search (the message HF 4.25.1 raises for this model)")
-        if num_beam_groups != 1:
-            raise NotImplementedError('diverse (group) beam search is not implemented on the HIP decode path')
+        diversity_penalty = unused.pop('diversity_penalty', None)
         self._maybe_resync()
         max_length = max_length or self.config.max_length_
+        if penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and not do_sample and num_beams == 1:
+            dec = XLDecoder(self.engine, input_ids.shape[0] * top_k, max_length, seed=seed)
+            return contrastive_search(dec, input_ids, max_length, top_k=top_k, penalty_alpha=penalty_alpha,
+                                      eos_token_id=self.config.eos_token_id, pad_token_id=self.config.pad_token_id)
+        if num_beam_groups != 1:
+            if num_beams <= 1 or num_beam_groups > num_beams:
+                raise ValueError('`num_beam_groups` has to be smaller or equal to `num_beams`')               # HF's message
+            if do_sample:
+                raise ValueError('Diverse beam search cannot be used in sampling mode. Make sure that `do_sample` is set to `False`.')
+            dec = XLDecoder(self.engine, input_ids.shape[0] * num_beams, max_length, seed=seed)
+            return group_beam_search(dec, input_ids, max_length, num_beams=num_beams, num_beam_groups=num_beam_groups,
+                                     diversity_penalty=diversity_penalty or 0.0, early_stopping=bool(early_stopping),
+                                     length_penalty=length_penalty, num_return_sequences=num_return_sequences,
+                                     eos_token_id=self.config.eos_token_id, pad_token_id=self.config.pad_token_id)
         if num_beams > 1:
             rows = input_ids.shape[0] * num_beams * (num_return_sequences if do_sample else 1)
             dec = XLDecoder(self.engine, rows, max_length, seed=seed)

@@ -639,11 +639,12 @@ def test_c3_train_step_gradients_vs_oracle(dev):
     EVERY parameter's gradient of the 12-layer backward against the fp32 oracle's autograd.  The oracle recomputes each layer in
     its backward (`checkpoint_layers`: the same arithmetic; the dense (2048, 4096, 12) score tensors of twelve layers would need
     ~25 GB otherwise).
-    Limits: the last six layers, the head and the embedding as at C2 and the two-layer C3 test (rel-Frobenius <= 6 %, cosine >=
-    0.998; r_net.weight <= 20 % / >= 0.98, the last LayerNorm's bias <= 10 % / >= 0.995).  A gradient that has crossed more than
-    six bf16 layers carries their storage roundings in both directions; it is held against the SAME oracle run with bf16 storage
-    of activations and gradient streams (`_bf16_storage_train_step`): within 2 x that envelope's own deviation from fp32 (and
-    never beyond 15 % / 0.985)."""
+    Limits: the fixed ones of C2 and of the two-layer C3 test (rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight <= 20 % /
+    >= 0.98, the last LayerNorm's bias <= 10 % / >= 0.995) or, where bf16 STORAGE alone costs more than that, 1.5 x the deviation
+    of the same oracle run with bf16 storage of activations and gradient streams and exact arithmetic everywhere else
+    (`_bf16_storage_train_step`), never beyond 15 % / 0.985.  Measured: that envelope is 5.9 % (layer 11) to 8.8 % (layer 0) on
+    the worst tensor of a layer (the first FFN weight: 2048 tokens, one sequence), the HIP path 1.19 x it at every depth --
+    i.e. the 12-layer gradient error is what the storage format costs, not something the kernels add with depth."""
     ref, m = _oracle_pair(dev, 'base', 12, T, M, seed=51, wscale=1.0)
     ref.train(); m.train()
     ref.transformer.checkpoint_layers = True
@@ -674,10 +675,7 @@ def test_c3_train_step_gradients_vs_oracle(dev):
         parts = name.split('.')
         layer = int(parts[2]) if parts[1] == 'layers' else None
         base = (0.20, 0.98) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias else (0.06, 0.998)
-        if layer is not None and layer < 6:
-            lim = (min(0.15, max(base[0], 2.0 * ee)), max(0.985, min(base[1], 1.0 - 2.0 * (1.0 - ecos))))
-        else:
-            lim = base
+        lim = (min(0.15, max(base[0], 1.5 * ee)), max(0.985, min(base[1], 1.0 - 1.5 * (1.0 - ecos))))
         if e > lim[0] or cos < lim[1]:
             bad[name] = (round(e, 4), round(cos, 5), 'envelope', round(ee, 4), round(ecos, 5))
         if layer is not None and not name.endswith('r_net.weight'):
