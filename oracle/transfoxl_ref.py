@@ -552,5 +552,139 @@ def ref_beam_search(model: 'RefTransfoXLLMHeadModel', input_ids, max_length, num
     return (outp, torch.tensor(scores)) if return_scores else outp
 
 
+@torch.no_grad()
+def ref_group_beam_search(model: 'RefTransfoXLLMHeadModel', input_ids, max_length, num_beams=4, num_beam_groups=2,
+                          diversity_penalty=0.0, early_stopping=True, length_penalty=1.0, num_return_sequences=1,
+                          return_scores=False):
+    """HF 4.25.1 `GenerationMixin.group_beam_search` + `BeamSearchScorer(num_beam_groups=)` + `HammingDiversityLogitsProcessor`
+    restated for this model (musicnlp/trainer/eval.py:303-317; test infrastructure).  Every step runs the model on ALL beams with
+    carried mems; group g's log-probabilities lose diversity_penalty x the number of beams of the earlier groups of the same
+    item that have just emitted a token (torch.bincount of `current_tokens`), get the group's running beam scores added, and the
+    2 * group_size best continuations per item go through the scorer (4.25.1: ONE BeamHypotheses of capacity num_beams and one
+    done flag per item, shared by the groups).  `reordering_indices` maps every row to the row whose mems it inherits."""
+    model.eval()
+    eos = model.config.eos_token_id
+    pad = eos
+    B, nb, ng = input_ids.shape[0], num_beams, num_beam_groups
+    assert nb % ng == 0
+    gs = nb // ng
+    ids = input_ids.repeat_interleave(nb, 0)
+    beam_scores = torch.full((B, nb), -1e9)
+    beam_scores[:, ::gs] = 0
+    beam_scores = beam_scores.view(-1)
+    hyps = [_RefBeamHyps(nb, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    past = None
+    while True:
+        inp = model.prepare_inputs_for_generation(ids, past)
+        out = model(inp['input_ids'], mems=inp.get('mems'))
+        logp_all = out.prediction_scores[:, -1, :]
+        V = logp_all.shape[-1]
+        cur_len = ids.shape[-1]
+        current = torch.zeros(B * nb, dtype=torch.long)
+        reorder = torch.zeros(B * nb, dtype=torch.long)
+        new_ids = ids.clone()
+        for g in range(ng):
+            g0, g1 = g * gs, (g + 1) * gs
+            rows = [b * nb + j for b in range(B) for j in range(g0, g1)]
+            sc = logp_all[rows].clone()
+            if diversity_penalty > 0 and g > 0:
+                for b in range(B):
+                    prev = current[b * nb:b * nb + g0]
+                    freq = torch.bincount(prev, minlength=V).to(sc.dtype)
+                    sc[b * gs:(b + 1) * gs] -= diversity_penalty * freq
+            sc = (sc + beam_scores[rows][:, None]).view(B, gs * V)
+            top_s, top_i = sc.topk(2 * gs, dim=1, largest=True, sorted=True)
+            top_b, top_t = top_i // V, top_i % V
+            for b in range(B):
+                if done[b]:
+                    for j in range(gs):
+                        r = b * nb + g0 + j
+                        beam_scores[r], current[r], reorder[r] = 0.0, pad, r
+                    continue
+                k = 0
+                for rank in range(2 * gs):
+                    tok, s_, src = int(top_t[b, rank]), float(top_s[b, rank]), b * nb + g0 + int(top_b[b, rank])
+                    if tok == eos:
+                        if rank >= gs:
+                            continue
+                        hyps[b].add(ids[src].clone(), s_)
+                    else:
+                        r = b * nb + g0 + k
+                        beam_scores[r], current[r], reorder[r] = s_, tok, src
+                        k += 1
+                    if k == gs:
+                        break
+                assert k == gs
+                done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+        ids = torch.cat([ids[reorder], current[:, None]], 1)
+        past = [m.index_select(1, reorder) for m in out.mems]
+        if all(done) or ids.shape[-1] >= max_length:
+            break
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(ids[b * nb + j], float(beam_scores[b * nb + j]))
+    best, scores = [], []
+    for b in range(B):
+        srt = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(num_return_sequences):
+            sc_, h = srt.pop()
+            best.append(h); scores.append(sc_)
+    L = min(max(len(h) for h in best) + 1, max_length)
+    outp = torch.full((len(best), L), pad, dtype=torch.long)
+    for i, h in enumerate(best):
+        outp[i, :len(h)] = h
+        if len(h) < L:
+            outp[i, len(h)] = eos
+    return (outp, torch.tensor(scores)) if return_scores else outp
+
+
+@torch.no_grad()
+def ref_contrastive_search(model: 'RefTransfoXLLMHeadModel', input_ids, max_length, top_k=4, penalty_alpha=0.6, return_trace=False):
+    """HF 4.25.1 `GenerationMixin.contrastive_search` + `_ranking_fast` restated for this model (the reference's 'contrastive'
+    strategy, musicnlp/trainer/eval.py:296-302, with `past` = the mems, musicnlp/models/transformer_xl.py:223-241; test
+    infrastructure).  Prompt pass -> last-layer hidden states of every position + next-token log-probs; then per step: top-k
+    filter (TopKLogitsWarper) and softmax -> k candidates with their probabilities; one forward of the B*k candidates on the
+    k-times replicated mems; score = (1 - alpha) * p - alpha * max cosine(candidate hidden, every context hidden); the winner's
+    token, hidden state, mems and log-probs carry on.  (eos = 0 = [OMIT] practically never fires; it ends a row as in HF.)"""
+    model.eval()
+    eos = model.config.eos_token_id
+    B, K = input_ids.shape[0], top_k
+    hid_full, mems = model.transformer(input_ids, mems=None)                 # (B, T, d): hidden_states[-1] in eval mode
+    logp = model.crit(hid_full[:, -1:], None).view(B, -1)                    # log-probs of the next token
+    ctx = hid_full
+    ids = input_ids.clone()
+    unfinished = torch.ones(B, dtype=torch.bool)
+    trace = []
+    while ids.shape[1] < max_length:
+        filt = logp.masked_fill(logp < logp.topk(K, -1).values[:, -1:], float('-inf'))
+        probs = filt.softmax(-1)
+        top_p, top_i = probs.topk(K, -1)
+        cand = top_i.reshape(-1, 1)
+        mem_k = [m.repeat_interleave(K, dim=1) for m in mems]                # mems are (M, B, d): batch on dim 1
+        h_c, mems_c = model.transformer(cand, mems=mem_k)                    # (B*K, 1, d)
+        logp_c = model.crit(h_c, None).view(B * K, -1)
+        ctx_k = ctx.repeat_interleave(K, 0)
+        a = ctx_k / ctx_k.norm(dim=2, keepdim=True)
+        b_ = h_c / h_c.norm(dim=2, keepdim=True)
+        pen = torch.matmul(a, b_.transpose(1, 2)).squeeze(-1).max(-1).values
+        score = ((1.0 - penalty_alpha) * top_p.reshape(-1) - penalty_alpha * pen).view(B, K)
+        sel = score.argmax(-1)
+        trace.append(dict(score=score.clone(), sel=sel.clone(), cand=top_i.clone()))
+        rows = torch.arange(B) * K + sel
+        tok = top_i[torch.arange(B), sel]
+        tok = torch.where(unfinished, tok, torch.full_like(tok, eos))
+        ids = torch.cat([ids, tok[:, None]], 1)
+        unfinished = unfinished & (tok != eos)
+        ctx = torch.cat([ctx, h_c[rows]], 1)
+        mems = [m.index_select(1, rows) for m in mems_c]
+        logp = logp_c[rows]
+        if not unfinished.any():
+            break
+    return (ids, trace) if return_trace else ids
+
+
 def count_parameters(m: nn.Module) -> int:
     return sum(p.numel() for p in m.parameters())  # shared (tied) tensors counted once
