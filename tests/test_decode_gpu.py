@@ -313,9 +313,33 @@ def test_contrastive_search_matches_oracle(dev):
             t = int(mism[0]) - 24
             sc = trace[t]['score'][b].sort(descending=True).values
             assert (sc[0] - sc[1]).item() < 2e-2, f'row {b} forks at step {t} where the oracle margin is {(sc[0] - sc[1]).item():.4f}'
-    agree = (got == want).float().mean().item()
-    print(f'contrastive search: {agree:.3f} of the tokens identical to the oracle')
-    assert agree > 0.6
+    # after a legitimate fork the two continuations are different sequences: compare up to the first fork of each row
+    prefix = [int((got[b] != want[b]).nonzero().flatten()[0]) - 24 if (got[b] != want[b]).any() else L - 24 for b in range(3)]
+    print(f'contrastive search: generated tokens identical to the oracle before the first near-tie fork: {prefix} of {L - 24}')
+    assert max(prefix) >= 20 and sum(prefix) >= 40
     tiny = m.generate(input_ids=prompt.to(dev), max_length=60, penalty_alpha=1e-9, top_k=4).cpu()
     gr = m.generate(input_ids=prompt.to(dev), max_length=60, do_sample=False).cpu()
     assert torch.equal(tiny, gr)
+
+
+def test_contrastive_select_kernel_matches_formula(dev):
+    """mxl_contrastive_select against HF's `_ranking_fast` formula in fp32 torch on the same bf16 inputs: scores to 1e-3, the
+    same winner wherever the two best scores differ by more than that"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(3)
+    B, K, S, Smax, d = 5, 6, 333, 400, 768
+    ctx = torch.randn(B, Smax, d, device=dev).to(torch.bfloat16)
+    hid = (ctx[:, 17:17 + K].float() * 0.7 + 0.5 * torch.randn(B, K, d, device=dev)).to(torch.bfloat16).reshape(B * K, d).contiguous()
+    probs = torch.softmax(torch.randn(B, K, device=dev), -1).contiguous()
+    inv = torch.empty(B, Smax, device=dev)
+    for b in range(B):
+        ops.row_inv_norm(ctx[b, :S], inv[b, :S], S)
+    score = torch.empty(B * K, device=dev); sel = torch.empty(B, dtype=torch.int64, device=dev)
+    ops.contrastive_select(ctx, inv, S, hid, probs, 0.6, score, sel)
+    c = ctx[:, :S].float(); h = hid.float().view(B, K, d)
+    cos = torch.einsum('bsd,bkd->bks', c / c.norm(dim=-1, keepdim=True), h / h.norm(dim=-1, keepdim=True))
+    want = 0.4 * probs - 0.6 * cos.max(-1).values
+    assert (score.view(B, K) - want).abs().max().item() < 1e-3
+    top2 = want.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-3
+    assert torch.equal(sel[clear], want.argmax(-1)[clear]) and (inv[:, :S] - 1 / c.norm(dim=-1)).abs().max().item() < 1e-4
