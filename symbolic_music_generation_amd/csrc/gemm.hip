@@ -556,6 +556,147 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     }
 }
 
+
+// =====================================================================================================================
+// Large-tile kernel for the weight gradients dW[m][n] += sum_k A[k][m] B[k][n] (A = dY (tokens x out), B = X (tokens x in): both
+// operands K-strided), split-K over workgroups, fp32 atomics.  Same machine as gemm_nt256_kernel -- 256 x 256 tile, 8 waves of
+// 128 x 64, four-stage global_load_lds ring three K-steps ahead, one raw barrier per 32-deep K-step, counted vmcnt -- with the
+// operand images the other way round: a stage holds [32 k][256 m] (512-byte k-rows, the operands' own row order: every DMA
+// instruction moves two whole k-rows), and fragments come out through ds_read_b64_tr_b16 (two per 16 x 32 fragment).  The
+// 32-byte granules of a k-row are XOR-swizzled by (k & 3) | ((k >> 3) & 1) << 2 -- on the SOURCE side of the DMA -- so that the
+// eight k-rows a half-wave's transposed read touches fall into eight different 32-byte bank groups.
+// Why now: at 131072 tokens per launch (per-GPU batch 64) a K-slice is ~18 k tokens long, so the 256 KB of fp32 atomics a
+// workgroup ends with (64 MB per GEMM at ~1.3 TB/s = 50 us) are a few percent of its loop, while the 128 x 128 kernel re-reads
+// the token-long panels twice as often (2.6 GB of HBM traffic per launch against 1 GB of operands, profiles/r02_c3_pmc_traffic).
+// =====================================================================================================================
+__global__ __launch_bounds__(512) void gemm_tt256_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int wr = wid >> 2, wc = wid & 3;                      // 2 x 4 waves of 128 x 64
+    const int ntile = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // launch slots b, b + 8, ... share an XCD: give each XCD a contiguous run of (slice, tile) pairs, i.e. mostly ONE K-slice,
+        // whose workgroups stream the same token rows of dY and X at the same time (L2 hits instead of HBM reads)
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int slice = bid / ntile, tile = bid - slice * ntile;
+    const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * 256;
+    const int kbeg = slice * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
+    const int S = (kend - kbeg) >> 5;                          // K-steps of this workgroup (host: K-slices are multiples of 32)
+    if (S <= 0) return;
+
+    // ---- issue side: DMA instruction i of wave w fills k-rows 2 (8 i + w), 2 (8 i + w) + 1 of an operand image; lane -> k-row
+    // (l >> 5), 16-byte chunk l & 31, which holds source chunk ((c >> 1) ^ swz(krow)) << 1 | (c & 1)
+    unsigned ga[2], gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int krow = 2 * (8 * i + wid) + (l >> 5), c = l & 31;
+        const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+        const int cs = (((c >> 1) ^ sw) << 1) | (c & 1);
+        ga[i] = (unsigned)(kbeg + krow) * (unsigned)p.lda + (unsigned)(m0 + cs * 8);
+        gb[i] = (unsigned)(kbeg + krow) * (unsigned)p.ldb + (unsigned)(n0 + cs * 8);
+    }
+    int gi = 0;
+    const unsigned stepA = 32u * (unsigned)p.lda, stepB = 32u * (unsigned)p.ldb;
+    auto issue_next = [&]() {
+        char* st = smem + (gi & 3) * G2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((g2_gptr)(p.A + ga[i]), (g2_lptr)(st + (8 * i + wid) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g2_gptr)(p.B + gb[i]), (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16, 0, 0);
+            ga[i] += stepA; gb[i] += stepB;
+        }
+        gi++;
+    };
+    // ---- fragment addresses (bytes inside an operand image): lane -> k-row 8 (l >> 4) + ((l & 15) >> 2), columns 4 (l & 3) ..
+    // of the fragment's 16; granule G of the row sits at (G ^ sw) * 32
+    const int fq = (l & 15) >> 2, fg = l >> 4;
+    const int fsw = fq | ((fg & 1) << 2);
+    const int fbase = (8 * fg + fq) * 512 + 8 * (l & 3);
+    int offA[8], offB[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) offA[i] = fbase + (((wr * 8 + i) ^ fsw) << 5);
+#pragma unroll
+    for (int j = 0; j < 4; j++) offB[j] = G2_OP_BYTES + fbase + (((wc * 4 + j) ^ fsw) << 5);
+    // The transposed reads are inline asm: through the builtin hipcc puts s_waitcnt vmcnt(0) in front of the first read of every
+    // step (it cannot tell the read from the LDS-DMA writes in flight), which drains the ring each step (measured: 760 TFLOP/s on
+    // the ffn shapes with the builtin).  A fragment = two 8-byte reads whose results the MFMA takes as one 128-bit operand; the
+    // waits are this kernel's own: lgkmcnt(0) + sched_barrier once per step, before the barrier that precedes the fragments' use.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    auto tr_frag = [&](uint32_t addr) -> bf16x8 {
+        u64x2 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
+                     : "=&v"(v.x), "=&v"(v.y) : "v"(addr) : "memory");
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto frags = [&](int g, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) {
+        const uint32_t st = lds0 + (g & 3) * G2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = tr_frag(st + offB[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fa[i] = tr_frag(st + offA[i]);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_next();
+    if (S > 1) issue_next();
+    if (S > 2) issue_next();
+    if (S > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    frags(0, fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    int g = 0;
+    auto step = [&](bf16x8 (&fa)[8], bf16x8 (&fb)[4], bf16x8 (&na)[8], bf16x8 (&nb)[4]) {
+        const bool issued = gi < S;
+        if (issued) issue_next();
+        if (g + 1 < S) frags(g + 1, na, nb);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)      // (A, B) order: a lane owns one column n and four consecutive rows m (atomics: 4 rows x 64 B)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // the next step's fragments have landed (asm loads: hipcc does not count them) and so has the stage after it
+        if (!issued) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        g++;
+    };
+#pragma unroll 1
+    for (int t = 0; t + 1 < S; t += 2) {
+        step(fa0, fb0, fa1, fb1);
+        step(fa1, fb1, fa0, fb0);
+    }
+    if (S & 1) step(fa0, fb0, fa1, fb1);
+
+    // acc[i][j][r]: m = m0 + wr*128 + i*16 + (l>>4)*4 + r, n = n0 + wc*64 + j*16 + (l&15)
+    float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wc * 64 + j * 16 + (l & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wr * 128 + i * 16 + (l >> 4) * 4 + r;
+                atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+            }
+        }
+}
+
 }  // namespace
 
 static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -650,6 +791,34 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
             MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT);
         else MXL_NT256_LAUNCH(-1);
 #undef MXL_NT256_LAUNCH
+        MXL_LAUNCH_CHECK();
+        return MXL_OK;
+    }
+    // weight gradients at training sizes: the 256 x 256 DMA-fed form (it picks its own K-slicing: one workgroup per CU)
+    if (transA && transB && batch == 1 && p.flags == MXL_GEMM_OUT_F32_ATOMIC && (M % 256) == 0 && (N % 256) == 0 && (K % 32) == 0 &&
+        K >= 8192 && (long long)K * lda < (1ll << 31) && (long long)K * ldb < (1ll << 31) && ((uintptr_t)C % 16) == 0 &&
+        !getenv("MXL_GEMM_NO_TT256")) {
+        static bool attr_tt = false;
+        static int n_cu_tt = 256;
+        if (!attr_tt) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tt256_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+            if (e != hipSuccess) return (int)e;
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu_tt = cus;
+            attr_tt = true;
+        }
+        p.tiles_m = M / 256; p.tiles_n = N / 256;
+        const int ntile = p.tiles_m * p.tiles_n;
+        int ks = n_cu_tt / ntile;
+        if (ks < 1) ks = 1;
+        const int steps = K / 32;
+        if (ks > steps / 64) ks = steps / 64 > 0 ? steps / 64 : 1;          // at least 64 K-steps per slice
+        const int per_steps = (steps + ks - 1) / ks;
+        ks = (steps + per_steps - 1) / per_steps;
+        p.ksplit = per_steps * 32;
+        hipLaunchKernelGGL(gemm_tt256_kernel, dim3(ntile * ks), dim3(512), G2_SMEM, s, p);
         MXL_LAUNCH_CHECK();
         return MXL_OK;
     }
