@@ -318,10 +318,13 @@ def reformer_leg(args, ranks: Ranks, steps: int, warmup: int):
         if br.ev:
             ms_total = br.total_ms()
             ach = br.work / (ms_total * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'weight-gradient GEMM dW = dY^T X (gemm_bf16_kernel<AT,BT>, split-K fp32 atomics): every '
-                                         'such launch of the timed steps', 'bound': 'mfma', 'achieved': ach,
-                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS,
-                               'traffic': None, 'avg_launch_ms': ms_total / len(br.ev), 'launches_timed': len(br.ev),
+            traffic, src = reformer_pmc_traffic(B)
+            out['roofline'] = {'kernel': 'weight-gradient GEMM dW = dY^T X (gemm_tt256_kernel, or gemm_bf16_kernel<AT,BT> for shapes '
+                                         'off the 256 grid; split-K fp32 atomics): every such launch of the timed steps',
+                               'bound': 'mfma', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'HBM bytes per launch (PMC), mean over the weight-gradient launches',
+                               'traffic_source': src, 'avg_launch_ms': ms_total / len(br.ev), 'launches_timed': len(br.ev),
                                'share_of_step': ms_total * 1e-3 / dt}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_reformer(T)
@@ -426,12 +429,30 @@ def pmc_traffic(workload, B):
         return None, None
     k = rec['kernels']
     names = rec.get('attention_backward_group')
-    if names is None:
+    if names is None:       # every launch of the bracketed group: delta, query-owner, key-owner, q + r_r_bias, dRd contraction
         dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
-        names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>']
+        names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']
     if not all(n in k for n in names):
         return None, None
     return sum(k[n]['hbm_bytes_per_launch'] * k[n].get('launches_per_group', 1) for n in names), os.path.basename(path)
+
+
+def reformer_pmc_traffic(B):
+    """HBM bytes per weight-gradient GEMM launch of the C4 leg from the newest committed PMC passes
+    (profiles/r*_c4_pmc_traffic.json: scripts/collect_profiles.sh, separate FETCH_SIZE / WRITE_SIZE runs of
+    `bench.py --mode reformer`), averaged over the launches of the kernels that serve those GEMMs"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_c4_pmc_traffic.json')))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1]))
+    if rec.get('per_gpu_batch') != B:
+        return None, None
+    ks = {n: v for n, v in rec['kernels'].items() if n.startswith('gemm_tt256_kernel') or n.startswith('gemm_bf16_kernel<true, true')}
+    tot = sum(v['launches'] for v in ks.values())
+    if not tot:
+        return None, None
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks.values()) / tot, os.path.basename(files[-1])
 
 
 def decode_pmc_traffic():
