@@ -33,7 +33,6 @@ struct GemmP {
     int flags;
     unsigned long long seed; unsigned site; unsigned thresh; float drop_scale;
     int tiles_m, tiles_n;
-    int noahead;           // A/B switch (MXL_GEMM_NOAHEAD): gemm_nt256_kernel keeps its loads behind the epilogue stores
     // batching: grid.y = batch index by; operand offsets (elements) = (by / bdiv) * s?1 + (by % bdiv) * s?2
     int bdiv;
     long long sA1, sA2, sB1, sB2, sC1, sC2;
@@ -131,9 +130,14 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
             if (flags & MXL_GEMM_DROPOUT) {
                 // 32-bit element index (host check: M * N <= 2^32): the same decisions as dropout_keep's 64-bit form, which the
                 // stand-alone dropout / LayerNorm kernels use when they regenerate a mask
+                // dropout_keep32(seed, site, i0 + r) with the index spread of the quad's four elements formed from ONE multiply:
+                // (i0 + r) * C = i0 * C + r * C (mod 2^32) -- the same masks, 9 quarter-rate integer multiplies per quad instead of 12
                 const uint32_t i0 = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+                const uint32_t mix = mxl_hash32((uint32_t)p.seed ^ (p.site * 0x9E3779B9U)) + (uint32_t)(p.seed >> 32);
+                const uint32_t h0 = i0 * 0x9E3779B1U;
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = dropout_keep32(p.seed, p.site, i0 + r, p.thresh) ? v[r] * p.drop_scale : 0.f;
+                for (int r = 0; r < 4; r++)
+                    v[r] = (mxl_hash32((h0 + (uint32_t)r * 0x9E3779B1U) ^ mix) >= p.thresh) ? v[r] * p.drop_scale : 0.f;
             }
             if ((flags & MXL_GEMM_RELU_BWD) && auxq) {
                 v[0] = bf2f((bf16_t)(auxq[0] & 0xffffu)) > 0.f ? v[0] : 0.f;
@@ -488,15 +492,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): nothing outstanding at loop entry, the loop body needs no wait before its MFMAs
 
     int g = 0;                              // flattened step being computed
-    // `after_epi`: 0 in steady state; 1 / 2 / 3 for the first three steps of a tile that follows a tile whose epilogue ran with the
-    // next tile's first two loads already issued AHEAD of its stores (see the epilogue).  vmcnt counts loads and stores in issue
-    // order, so a wait for a load issued after the stores is a wait for the stores: with two loads ahead of them the first wait
-    // that covers the stores comes four K-steps after they were issued instead of two.
-    constexpr int NS = FM * (FN / 2) + ((FN & 1) ? FM / 2 : 0);      // 16-byte store instructions per wave of a `pairs` epilogue
-    auto step = [&](int after_epi, bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN], bf16x8 (&na)[FM],
+    auto step = [&](bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN], bf16x8 (&na)[FM],
                     bf16x8 (&nb)[FN]) {
-        const bool may_issue = after_epi == 0 || after_epi == 3;      // steps 1 and 2 after such an epilogue: their loads are out
-        const bool issued = may_issue && gi < S;
+        const bool issued = gi < S;
         if (issued) issue_next();
         if (g + 1 < S) frags(g + 1, na, nb);
         __builtin_amdgcn_s_setprio(1);
@@ -509,12 +507,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         // (the fragment reads of step g+1 need not finish before this barrier: their stage is not re-filled before the
         // barrier of step g+1, and the MFMAs of step g+1 wait for them anyway)
-        if (last_of_tile || (may_issue && !issued)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after_epi == 1) { /* step g+2 landed before the epilogue */ }
-        else if (after_epi == 2 || after_epi == 3) {
-            // needed: the load two steps ahead, issued BEFORE the stores; younger than it: one load + the NS stores
-            if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NS) : "memory");
-        } else if (!first_of_later_tile) {
+        if (last_of_tile || !issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!first_of_later_tile) {
             if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -522,37 +516,22 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     };
 
     const int flags = EPI >= 0 ? EPI : p.flags;
-    const bool getenv_noahead = p.noahead != 0;
     if (EPI == 0) p.alpha = 1.f;
-    bool ahead = false;                     // the previous epilogue ran with this tile's loads 3 and 4 already issued
 #pragma unroll 1
     for (int tile = bid; tile < nwg; tile += G) {
 #pragma unroll
         for (int i = 0; i < FM; i++)
 #pragma unroll
             for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool later = tile != bid;
-        const bool ahead_now = ahead;          // (set only when nk >= 4)
 #pragma unroll 1
         for (int t = 0; t < nk; t += 2) {
-            const int ae0 = ahead_now ? (t == 0 ? 1 : (t == 2 ? 3 : 0)) : 0;
-            const int ae1 = (ahead_now && t == 0) ? 2 : 0;
-            step(ae0, t == 0 && later && !ahead_now, false, fa0, fb0, fa1, fb1);
-            step(ae1, false, t + 2 >= nk, fa1, fb1, fa0, fb0);
+            step(t == 0 && tile != bid, false, fa0, fb0, fa1, fb1);
+            step(false, t + 2 >= nk, fa1, fb1, fa0, fb0);
         }
         // epilogue.  acc[i][j][r]: m = m0 + wr*FM*16 + i*16 + (l&15), n = n0 + wc*FN*16 + j*16 + (l>>4)*4 + r
         const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BN;
         const bool pairs = !(flags & MXL_GEMM_OUT_F32) && n0 + BN <= p.N && m0 + 256 <= p.M && (p.ldc & 7) == 0 &&
                            (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;                 // workgroup-uniform: interior tile
-        // Two of the next tile's loads go out AHEAD of this tile's stores (the stage read by the last step, and the stage whose
-        // fragments -- those of the next tile's first step -- are in registers once every wave has passed lgkmcnt(0) + a barrier)
-        ahead = pairs && nk >= 4 && gi + 2 <= S && !getenv_noahead;
-        if (ahead) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue_next();
-            issue_next();
-        }
         if (pairs) {
             // 16-byte stores: column blocks (0,1), (2,3) of a row block pair up; with three column blocks the third one pairs up
             // across row blocks (i, i+1)
@@ -757,7 +736,6 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.alpha = alpha; p.flags = flags;
     p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
     { static const bool nt = getenv("MXL_GEMM_NT") != nullptr; if (nt) p.flags |= (1 << 30); }
-    { static const bool noahead = getenv("MXL_GEMM_NOAHEAD") != nullptr; p.noahead = noahead ? 1 : 0; }
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     if ((flags & MXL_GEMM_DROPOUT) && drop_p <= 0.f) p.flags &= ~MXL_GEMM_DROPOUT;
     // the dropout mask is indexed by the 32-bit element index (kernels that regenerate it use the same index for < 2^32 elements)
