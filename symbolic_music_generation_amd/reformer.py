@@ -161,15 +161,41 @@ class MyReformerModelWithLMHead(EngineModule):
         from . import ops
         top_k = getattr(self.config, 'top_k', 50) if top_k is None else top_k        # HF fills it from the config: default 50
         if unsupported.get('penalty_alpha') and not do_sample and top_k is not None and top_k > 1:
-            raise ValueError(f'{type(self).__name__} does not support caching through `past_key_values` and therefore '
-                             "**can't** be used for contrastive search (the message HF 4.25.1 raises for this model)")
+            # HF 4.25.1 contrastive_search takes `past_buckets_states` as its cache and indexes past[0][0].shape: the bucket entry
+            # of a local layer is None, so the reference stack fails there too; the ValueError is this package's
+            raise ValueError(f"{type(self).__name__} **can't** be used for contrastive search: its cache (past_buckets_states) "
+                             'is not a per-layer tensor cache that HF\'s routine can replicate per candidate')
         if unsupported.get('num_return_sequences', 1) not in (None, 1) and (unsupported.get('num_beams', 1) or 1) == 1:
             if not do_sample:
                 raise ValueError('num_return_sequences has to be 1 when doing greedy search')
             input_ids = input_ids.repeat_interleave(int(unsupported.pop('num_return_sequences')), 0)
         num_beams = unsupported.pop('num_beams', 1) or 1
-        if unsupported.get('num_beam_groups', 1) not in (None, 1):
-            raise NotImplementedError('diverse (group) beam search is not implemented on the HIP decode path')
+        num_beam_groups = unsupported.pop('num_beam_groups', 1) or 1
+        diversity_penalty = unsupported.pop('diversity_penalty', None)
+        if num_beam_groups != 1:
+            # diverse (group) beam search (eval.py:303-317) over the cached decoder's beam hooks
+            if num_beams <= 1 or num_beam_groups > num_beams:
+                raise ValueError('`num_beam_groups` has to be smaller or equal to `num_beams`')
+            if do_sample:
+                raise ValueError('Diverse beam search cannot be used in sampling mode. Make sure that `do_sample` is set to `False`.')
+            from .generate import group_beam_search
+            from .rf_generate import RFDecoder
+            nrs = int(unsupported.pop('num_return_sequences', 1) or 1)
+            self._maybe_resync()
+            was = self.training
+            self.eval()
+            try:
+                max_length = int(max_length or c_max_len(self.config))
+                dec = RFDecoder(self.engine, input_ids.shape[0] * num_beams, max_length, rotations=rotations, seed=seed)
+                return group_beam_search(dec, input_ids, max_length, num_beams=num_beams, num_beam_groups=num_beam_groups,
+                                         diversity_penalty=diversity_penalty or 0.0,
+                                         early_stopping=bool(unsupported.get('early_stopping')),
+                                         length_penalty=float(unsupported.get('length_penalty', 1.0) or 1.0),
+                                         num_return_sequences=nrs, eos_token_id=self.config.eos_token_id,
+                                         pad_token_id=self.config.pad_token_id)
+            finally:
+                if was:
+                    self.train()
         if num_beams > 1:
             # the reference's 'beam' strategy (eval.py:302-321): HF beam_search / beam_sample over the cached decoder
             from .generate import beam_search

@@ -164,3 +164,34 @@ def test_beam_search_over_the_cached_decoder(dev):
                            eos_token_id=m.config.eos_token_id, pad_token_id=m.config.pad_token_id).cpu()
     assert two.shape == want.shape and two.shape[0] == 2 * B and torch.equal(two, want)
     assert torch.equal(two[::2, :Tp], prompt) and torch.equal(two[1::2, :Tp], prompt)
+
+
+def test_group_beam_search_over_the_cached_decoder(dev):
+    """`generate(num_beams=4, num_beam_groups=2, diversity_penalty=...)` on the Reformer (eval.py:303-317): generate.group_beam_search
+    over RFDecoder rows (the routine itself is checked against the oracle on the TransfoXL side).  Here: the returned score is
+    the summed log-probability of the hypothesis under the same cached decoding (teacher-forced through a fresh decoder), prompts
+    are kept, and a diversity penalty makes the two groups open with different tokens."""
+    from symbolic_music_generation_amd.generate import group_beam_search
+    from symbolic_music_generation_amd.rf_generate import RFDecoder
+    blob = _load('gen_padded')
+    m = _model(dev, blob)
+    rot = blob['rotations']
+    prompt = blob['prompt']
+    B, Tp = prompt.shape
+    L = min(Tp + 40, 140)
+    dec = RFDecoder(m.engine, B * 4, L, rotations={l: r.clone() for l, r in rot.items()})
+    with torch.no_grad():
+        out, sc = group_beam_search(dec, prompt.to(dev), L, num_beams=4, num_beam_groups=2, diversity_penalty=0.0,
+                                    early_stopping=True, eos_token_id=-1, pad_token_id=0, return_scores=True)
+    out = out.cpu()
+    assert out.shape == (B, L) and torch.equal(out[:, :Tp], prompt)
+    got, _ = _forced_decode(dev, m, prompt, out, rot)
+    lp = torch.log_softmax(got.float(), -1)
+    s = lp.gather(-1, out[:, Tp:, None]).squeeze(-1).sum(1) / L
+    assert (s - sc).abs().max().item() < 2e-2
+    four = m.generate(input_ids=prompt.to(dev), max_length=L, num_beams=4, num_beam_groups=2, diversity_penalty=10.0,
+                      num_return_sequences=4, early_stopping=True, rotations=rot).cpu()
+    assert four.shape[0] == 4 * B and torch.equal(four[:, :Tp], prompt.repeat_interleave(4, 0))
+    assert len({int(t) for t in four[:4, Tp]}) >= 2
+    with pytest.raises(ValueError, match='contrastive'):
+        m.generate(input_ids=prompt.to(dev), max_length=L, penalty_alpha=0.6, top_k=4)
