@@ -87,13 +87,6 @@ int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd,
                     long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
                     float scale, void* stream);
 
-/* mxl_relattn_fwd that also writes the query operands as its MFMAs take them -- qw_s = bf16((q + r_w_bias) * scale * log2 e),
- * qr_s = bf16((q + r_r_bias) * scale * log2 e), both compact (B, T, H*dh) -- for mxl_relattn_bwd_pre */
-int mxl_relattn_fwd_save(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                         const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
-                         long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                         float scale, void* qw_s, void* qr_s, void* stream);
-
 /* Backward of mxl_relattn_fwd (autograd of the upstream attention core).  out/dout share the (o_bs, o_rs) layout.
  *   delta : (B,H,T) f32 scratch (written);  dq (B,T,H,dh) / dk, dv (B,Kc,H,dh) bf16 with their own strides (written);
  *   dg    : (B,H,T,M) bf16, un-skewed score gradient dG[b,h,i,d] = dSr[i, i-d] (written; may be NULL).  The caller
@@ -105,16 +98,6 @@ int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd,
                     int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                     long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                     float scale, void* stream);
-
-/* mxl_relattn_bwd (skip_phantom_dg = 0) / mxl_relattn_bwd_sparse_dg (= 1, d_r_r_bias NULL) given the forward's saved operands
- * qw_s, qr_s and a scratch do_s (B, T, H*dh) bf16 that the delta pre-pass fills with bf16(dout * scale): the key-owner kernel, which
- * visits every query tile once per key block, then copies its tiles instead of re-scaling them each time.  Same results. */
-int mxl_relattn_bwd_pre(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                        const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta, void* dq,
-                        void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc,
-                        long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs, long long dq_bs,
-                        int dq_rs, long long dkv_bs, int dkv_rs, float scale, int skip_phantom_dg, const void* qw_s,
-                        const void* qr_s, void* do_s, void* stream);
 
 /* The contraction the caller owes after mxl_relattn_bwd, as one HBM-streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0;
  * MXL_EUNSUPPORTED otherwise -- use mxl_gemm_bf16_batched):

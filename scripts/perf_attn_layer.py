@@ -20,18 +20,15 @@ CH = int(os.environ.get('DG_CHUNK', B))
 dg = torch.empty(CH, H, T, M, device=dev, dtype=torch.bfloat16)
 a, c = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
 d_rd = torch.zeros(M, d, device=dev); qr = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
-PRE = os.environ.get('PRE', '1') == '1'      # forward saves its scaled query operands, the key-owner backward copies them
-qw_s = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16); qr_s = torch.empty_like(qw_s); do_s = torch.empty_like(qw_s)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 if os.environ.get('KT'):
     ops.ktime_enable(True)
 for it in range(int(os.environ.get('ITERS', 3))):
     ev[0].record()
-    ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, save=(qw_s, qr_s) if PRE else None, **st)
+    ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, **st)
     ev[1].record()
     fin = ops.relattn_bwd(q, k, v, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc-T:, :d], dqkv[:, :, d:2*d], dqkv[:, :, 2*d:],
-                          dg, a, c, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, d_rd=d_rd, qr_buf=qr, defer_drd=True,
-                          pre=(qw_s, qr_s, do_s) if PRE else None, **st)
+                          dg, a, c, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, d_rd=d_rd, qr_buf=qr, defer_drd=True, **st)
     ev[2].record()
     fin()
     ev[3].record()
@@ -40,4 +37,4 @@ for it in range(int(os.environ.get('ITERS', 3))):
 torch.cuda.synchronize()
 kt = ops.ktime_collect() if os.environ.get('KT') else {}
 print({k: round(v[0] / max(v[1], 1), 3) for k, v in kt.items()} if kt else '')
-print(f'PRE={PRE} B={B} dg chunk {CH}: fwd {ev[0].elapsed_time(ev[1]):.3f} ms, bwd (delta+dq+dkv) {ev[1].elapsed_time(ev[2]):.3f} ms, drd {ev[2].elapsed_time(ev[3]):.3f} ms')
+print(f'B={B} dg chunk {CH}: fwd {ev[0].elapsed_time(ev[1]):.3f} ms, bwd (delta+dq+dkv) {ev[1].elapsed_time(ev[2]):.3f} ms, drd {ev[2].elapsed_time(ev[3]):.3f} ms')

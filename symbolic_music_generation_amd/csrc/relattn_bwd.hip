@@ -40,11 +40,6 @@ struct BwdP {
     // 8-wave query-owner kernel only: do not store dG for 32-distance blocks whose 256-distance block lies entirely on phantom
     // distances of the wave's 32 queries -- mxl_relattn_drd_recompute rebuilds exactly those cells itself
     int dg_skip_phantom;
-    // prescaled operands (compact (B, T, H*dh) bf16; all three or none): qw_s / qr_s as mxl_relattn_fwd_save wrote them, do_s =
-    // bf16(dout * scale) written by the delta pre-pass of this call -- the key-owner kernel then copies its query tiles instead
-    // of re-scaling them once per key block
-    const bf16_t *qw_s, *qr_s;
-    bf16_t* do_s;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -68,12 +63,6 @@ __global__ __launch_bounds__(256) void relattn_bwd_delta_kernel(BwdP p, int dh) 
             const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + c * 8);
 #pragma unroll
             for (int j = 0; j < 8; j++) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)d[j]);
-            if (p.do_s) {
-                bf16x8 ds;
-#pragma unroll
-                for (int j = 0; j < 8; j++) ds[j] = (short)f2bf(bf2f((bf16_t)d[j]) * p.scale);
-                *reinterpret_cast<bf16x8*>(p.do_s + ((size_t)b * p.T + i) * ((size_t)p.H * dh) + c * 8) = ds;
-            }
         }
         // reduce groups of cph consecutive lanes
         for (int off = 1; off < cph; off <<= 1) s += __shfl_xor(s, off, 64);
@@ -1150,7 +1139,7 @@ __device__ __forceinline__ void skew_read16k(uint32_t base, uint32_t (&u)[16]) {
         : "memory");
 }
 
-template <int DH, bool PRE = false>
+template <int DH>
 __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     using G = GeoK<DH>;
     constexpr int KS = G::KS, EB = G::EB;
@@ -1201,29 +1190,15 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     const int it_lo = i_lo / QT, it_hi = i_hi / QT;
 
     // staging: thread t < 32*CH handles one 16-byte chunk of each of the three tiles
-    u32x4 tq, tq2, tdo, rr;
+    u32x4 tq, tdo, rr;
     float tl = 0.f, tdl = 0.f;
-    // PRE: the three images are copies of the prescaled tensors (qw_s, qr_s, do_s: compact (B, T, H*DH)); the tile's rows start at
-    // a wave-uniform base, every thread adds the same row / chunk offset each tile
-    const size_t dmod = (size_t)p.H * DH;
-    const bf16_t* qws_b = PRE ? p.qw_s + (size_t)b * T * dmod + (size_t)h * DH : nullptr;
-    const bf16_t* qrs_b = PRE ? p.qr_s + (size_t)b * T * dmod + (size_t)h * DH : nullptr;
-    const bf16_t* dos_b = PRE ? p.do_s + (size_t)b * T * dmod + (size_t)h * DH : nullptr;
-    const unsigned pre_ofs = (unsigned)(tid / G::CH) * (unsigned)dmod + (unsigned)(tid % G::CH) * 8u;
     auto load_q = [&](int it) {
         const int I = it * QT;
         const int row = tid / G::CH, ch = tid % G::CH;
         u32x4 z = {0u, 0u, 0u, 0u};
         const bool ok = (tid < QT * G::CH) && (I + row < T);
-        if (PRE) {
-            const size_t t0 = (size_t)I * dmod;
-            tq = ok ? *reinterpret_cast<const u32x4*>(qws_b + t0 + pre_ofs) : z;
-            tq2 = ok ? *reinterpret_cast<const u32x4*>(qrs_b + t0 + pre_ofs) : z;
-            tdo = ok ? *reinterpret_cast<const u32x4*>(dos_b + t0 + pre_ofs) : z;
-        } else {
-            tq = ok ? *reinterpret_cast<const u32x4*>(qbase + (size_t)(I + row) * p.q_rs + ch * 8) : z;
-            tdo = ok ? *reinterpret_cast<const u32x4*>(dobase + (size_t)(I + row) * p.o_rs + ch * 8) : z;
-        }
+        tq = ok ? *reinterpret_cast<const u32x4*>(qbase + (size_t)(I + row) * p.q_rs + ch * 8) : z;
+        tdo = ok ? *reinterpret_cast<const u32x4*>(dobase + (size_t)(I + row) * p.o_rs + ch * 8) : z;
         if (tid < QT) {
             const bool ok2 = I + tid < T;
             const size_t sidx = ((size_t)b * p.H + h) * T + (ok2 ? I + tid : 0);
@@ -1239,11 +1214,6 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
         float* sDl = sLse + QT;
         if (tid < QT * G::CH) {
             const int row = tid / G::CH, ch = tid % G::CH;
-            if (PRE) {
-                *reinterpret_cast<u32x4*>(sQw + G::koff(row, ch)) = tq;
-                *reinterpret_cast<u32x4*>(sQr + G::koff(row, ch)) = tq2;
-                *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = tdo;
-            } else {
             u32x4 w, rq, wd;
             const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
             const bf16_t* sdo = reinterpret_cast<const bf16_t*>(&tdo);
@@ -1260,7 +1230,6 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
             *reinterpret_cast<u32x4*>(sQw + G::koff(row, ch)) = w;
             *reinterpret_cast<u32x4*>(sQr + G::koff(row, ch)) = rq;
             *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = wd;
-            }
         }
         if (tid < QT) { sLse[tid] = tl; sDl[tid] = tdl; }
     };
@@ -1719,10 +1688,7 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dq_kernel<DH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GeoQ<DH>::SMEM);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dkv_kernel<DH, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GeoK<DH>::SMEM);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dkv_kernel<DH, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_dkv_kernel<DH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, GeoK<DH>::SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -1747,8 +1713,7 @@ int launch_bwd(const BwdP& p, hipStream_t s) {
     }
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_DKV, s);
-        if (p.qw_s) hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH, true>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
-        else hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH, false>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
+        hipLaunchKernelGGL((relattn_bwd_dkv_kernel<DH>), dim3((p.Kc + KB - 1) / KB, p.H, p.B), dim3(256), GeoK<DH>::SMEM, s, p);
     }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
@@ -1761,10 +1726,8 @@ static int relattn_bwd_impl(const void* q, const void* k, const void* v, const v
                             void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
                             int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                             long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
-                            float scale, int skip_phantom_dg, const void* qw_s, const void* qr_s, void* do_s, void* stream) {
+                            float scale, int skip_phantom_dg, void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv);
-    MXL_CHECK_ARG((qw_s != nullptr) == (qr_s != nullptr) && (qw_s != nullptr) == (do_s != nullptr));
-    MXL_CHECK_ARG(((uintptr_t)qw_s % 16) == 0 && ((uintptr_t)qr_s % 16) == 0 && ((uintptr_t)do_s % 16) == 0);
     // the skipped cells are rebuilt by mxl_relattn_drd_recompute, which tiles 256 distances x 32 queries and needs d r_r_bias
     // left to it (the 8-wave query-owner kernel)
     if (skip_phantom_dg) MXL_CHECK_ARG(dg && d_r_r_bias == nullptr && dh == 64 && (M % 256) == 0 && (T % 32) == 0);
@@ -1783,7 +1746,6 @@ static int relattn_bwd_impl(const void* q, const void* k, const void* v, const v
     p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dq_rs = dq_rs; p.dkv_rs = dkv_rs;
     p.scale = scale; p.scale_log2e = scale * LOG2E;
     p.dg_skip_phantom = skip_phantom_dg ? 1 : 0;
-    p.qw_s = (const bf16_t*)qw_s; p.qr_s = (const bf16_t*)qr_s; p.do_s = (bf16_t*)do_s;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_bwd<16>(p, s);
@@ -1800,7 +1762,7 @@ extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, cons
                                long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
                                float scale, void* stream) {
     return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, d_r_r_bias, B, T, H,
-                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 0, nullptr, nullptr, nullptr, stream);
+                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 0, stream);
 }
 
 extern "C" int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
@@ -1810,19 +1772,7 @@ extern "C" int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const voi
                                          int rd_rs, long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs,
                                          int dkv_rs, float scale, void* stream) {
     return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, nullptr, B, T, H,
-                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 1, nullptr, nullptr, nullptr, stream);
-}
-
-extern "C" int mxl_relattn_bwd_pre(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                                   const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta, void* dq,
-                                   void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T, int H, int dh,
-                                   int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs,
-                                   int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale,
-                                   int skip_phantom_dg, const void* qw_s, const void* qr_s, void* do_s, void* stream) {
-    MXL_CHECK_ARG(qw_s && qr_s && do_s);
-    return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, d_r_r_bias, B, T, H,
-                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale,
-                            skip_phantom_dg, qw_s, qr_s, do_s, stream);
+                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 1, stream);
 }
 
 static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,

@@ -33,9 +33,6 @@ struct RelAttnP {
     long long q_bs, kv_bs, o_bs;
     int q_rs, kv_rs, rd_rs, o_rs;
     float scale_log2e;
-    // optional outputs (B, T, H*dh) bf16, compact: the scaled, bias-added query operands exactly as the MFMAs take them --
-    // (q + r_w_bias) * scale * log2e and (q + r_r_bias) * scale * log2e -- for the key-owner backward (mxl_relattn_bwd_pre)
-    bf16_t *qw_s, *qr_s;
 };
 
 constexpr int QB = 128;      // queries per workgroup
@@ -162,11 +159,6 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 // scale * log2(e) folded into the operands: the MFMA results are already in exp2 units
                 qw[ks][j] = (short)f2bf((qf + p.rwb[h * DH + e0 + j]) * p.scale_log2e);
                 qr[ks][j] = (short)f2bf((qf + p.rrb[h * DH + e0 + j]) * p.scale_log2e);
-            }
-            if (p.qw_s && ok) {
-                const size_t o = ((size_t)b * T + i) * ((size_t)p.H * DH) + (size_t)h * DH + e0;
-                *reinterpret_cast<bf16x8*>(p.qw_s + o) = qw[ks];
-                *reinterpret_cast<bf16x8*>(p.qr_s + o) = qr[ks];
             }
         }
     }
@@ -512,10 +504,10 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
 
 }  // namespace
 
-static int relattn_fwd_impl(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                            const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
-                            long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                            float scale, void* qw_s, void* qr_s, void* stream) {
+extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
+                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                               float scale, void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
@@ -528,8 +520,6 @@ static int relattn_fwd_impl(const void* q, const void* k, const void* v, const v
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs;
     p.scale_log2e = scale * 1.4426950408889634f;
-    MXL_CHECK_ARG((qw_s == nullptr) == (qr_s == nullptr) && ((uintptr_t)qw_s % 16) == 0 && ((uintptr_t)qr_s % 16) == 0);
-    p.qw_s = (bf16_t*)qw_s; p.qr_s = (bf16_t*)qr_s;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_fwd<16>(p, s);
@@ -537,21 +527,4 @@ static int relattn_fwd_impl(const void* q, const void* k, const void* v, const v
         case 64: return launch_fwd<64>(p, s);
         default: return MXL_EUNSUPPORTED;
     }
-}
-
-extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
-                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                               float scale, void* stream) {
-    return relattn_fwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs,
-                            scale, nullptr, nullptr, stream);
-}
-
-extern "C" int mxl_relattn_fwd_save(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                                    const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
-                                    long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                                    float scale, void* qw_s, void* qr_s, void* stream) {
-    MXL_CHECK_ARG(qw_s && qr_s);
-    return relattn_fwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs,
-                            scale, qw_s, qr_s, stream);
 }

@@ -196,15 +196,9 @@ def mem_update(mem, hid, out):
 
 
 def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,
-                o_bs, o_rs, scale=None, save=None):
-    """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements.
-    `save` = (qw_s, qr_s): two compact (B, T, H*dh) bf16 buffers that receive the scaled query operands for `relattn_bwd(pre=...)`."""
+                o_bs, o_rs, scale=None):
+    """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
-    if save is not None:
-        check(lib().mxl_relattn_fwd_save(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), B, T, H, dh,
-                                         M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale), _p(save[0]), _p(save[1]),
-                                         _stream()), 'mxl_relattn_fwd_save')
-        return out
     check(lib().mxl_relattn_fwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), B, T, H, dh,
                                 M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale), _stream()),
           'mxl_relattn_fwd')
@@ -335,7 +329,7 @@ def add_rowbias(x, x_bs, x_rs, bias, out, B, T, n):
 
 def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_rwb, d_rrb, *, B, T, H, dh, M,
                 Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale=None,
-                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None, defer_drd: bool = False, pre=None):
+                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None, defer_drd: bool = False):
     """Backward of relattn_fwd.  If `d_rd` (M, H*dh) f32 is given, also contracts dG with (q + r_r_bias):
     d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf).
     When that contraction runs as the streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0) it also produces d_rrb, and the
@@ -355,14 +349,6 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
 
     def launch(b0, n):
         sl = slice(b0, b0 + n)
-        if pre is not None:        # (qw_s, qr_s, do_s): the forward's saved operands + scratch for the scaled output gradient
-            qw_s, qr_s, do_s = pre
-            check(lib().mxl_relattn_bwd_pre(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]),
-                                            _p(dout[sl]), _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]), _p(dg),
-                                            _p(d_rwb), None if (fused_rrb or sparse) else _p(d_rrb), n, T, H, dh, M, Kc, q_bs, q_rs,
-                                            kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, float(scale), int(sparse),
-                                            _p(qw_s[sl]), _p(qr_s[sl]), _p(do_s[sl]), _stream()), 'mxl_relattn_bwd_pre')
-            return
         if sparse:
             check(lib().mxl_relattn_bwd_sparse_dg(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]),
                                                   _p(dout[sl]), _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]),

@@ -225,10 +225,6 @@ class XLEngine:
             ws.st1 = [torch.empty(2, N, **f32) for _ in range(L)]
             ws.st2 = [torch.empty(2, N, **f32) for _ in range(L)]
             ws.hid_d = torch.empty(N, d, **bf)
-            # the attention forward's scaled query operands, kept for the key-owner backward (+4 B per token and layer)
-            ws.qw_s = [torch.empty(B, T, d, **bf) for _ in range(L)]
-            ws.qr_s = [torch.empty(B, T, d, **bf) for _ in range(L)]
-            ws.do_s = torch.empty(B, T, d, **bf)
             # backward scratch
             ws.dA = torch.empty(N, d, **bf)      # gradient stream a (residual path)
             ws.dB = torch.empty(N, d, **bf)      # gradient stream b (GEMM path)
@@ -306,7 +302,7 @@ class XLEngine:
             ops.gemm(ws.phi, self._lw(l, 'dec_attn.r_net.weight'), ws.rd[s], M, d, d)
             ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[s],
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
-                            ws.av[s], ws.lse[s], save=(ws.qw_s[l], ws.qr_s[l]) if train else None, **st)
+                            ws.av[s], ws.lse[s], **st)
             ops.gemm(ws.av[s], self._lw(l, 'dec_attn.o_net.weight'), ws.tmp, N, d, d)
             ops.ln_residual_fwd(ws.tmp, h_in, self._lw(l, 'dec_attn.layer_norm.weight', self.P),
                                 self._lw(l, 'dec_attn.layer_norm.bias', self.P), ws.h1[s],
@@ -600,8 +596,7 @@ class XLEngine:
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
                             ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
                             ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
-                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr,
-                            pre=(ws.qw_s[l], ws.qr_s[l], ws.do_s), **st)
+                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr, **st)
             # r_net: dW_r = d_rd^T . phi
             ops.cast_bf16(ws.d_rd, ws.d_rd16)
             ops.gemm(ws.d_rd16, ws.phi_c, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
