@@ -25,8 +25,8 @@ B=$(python3 -c "import bench; print(bench.WORKLOADS['c3']['B'])")
 f() { find $1 -name "$2" | head -1; }
 python3 scripts/pmc_traffic.py $(f $OUT/fetch '*counter_collection.csv') $(f $OUT/write '*counter_collection.csv') $OUT/${TAG}_c3_pmc_traffic.json $B
 python3 scripts/pmc_mfma.py $(f $OUT/mfma '*counter_collection.csv') $(f $OUT/mfma '*kernel_trace.csv') $OUT/${TAG}_c3_mfma_util.json $B
-python3 scripts/pmc_traffic.py $(f $OUT/rfetch '*counter_collection.csv') $(f $OUT/rwrite '*counter_collection.csv') $OUT/${TAG}_c4_pmc_traffic.json 16
-python3 scripts/pmc_traffic.py $(f $OUT/dfetch '*counter_collection.csv') $(f $OUT/dwrite '*counter_collection.csv') $OUT/${TAG}_c5_decode_eager_pmc_traffic.json 64
+python3 scripts/pmc_traffic.py $(f $OUT/rfetch '*counter_collection.csv') $(f $OUT/rwrite '*counter_collection.csv') $OUT/${TAG}_c4_pmc_traffic.json 16 reformer
+python3 scripts/pmc_traffic.py $(f $OUT/dfetch '*counter_collection.csv') $(f $OUT/dwrite '*counter_collection.csv') $OUT/${TAG}_c5_decode_eager_pmc_traffic.json 64 decode
 cp $(f $OUT/train '*kernel_stats.csv') $OUT/${TAG}_c3_train_step_kernel_stats.csv
 cp $(f $OUT/decode '*kernel_stats.csv') $OUT/${TAG}_c5_decode_kernel_stats.csv
 cp $(f $OUT/reformer '*kernel_stats.csv') $OUT/${TAG}_c4_reformer_train_kernel_stats.csv

@@ -23,7 +23,7 @@ def per_kernel(path, counter):
     return df.groupby('k').Counter_Value.agg(['count', 'mean'])
 
 
-def main(fetch_csv, write_csv, out_json, batch=32):
+def main(fetch_csv, write_csv, out_json, batch=32, kind='train'):
     f = per_kernel(fetch_csv, 'FETCH_SIZE')
     w = per_kernel(write_csv, 'WRITE_SIZE')
     out = {}
@@ -32,10 +32,26 @@ def main(fetch_csv, write_csv, out_json, batch=32):
         wk = float(w['mean'].get(k, 0.0)) * 1000.0
         out[k] = {'launches': int(f['count'].get(k, w['count'].get(k, 0))), 'fetch_size_bytes_raw': fk,
                   'fetch_bytes_corrected_x2': 2.0 * fk, 'write_bytes': wk, 'hbm_bytes_per_launch': 2.0 * fk + wk}
-    json.dump({'command': 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (SURVEY C3, 1x MI355X)',
-               'per_gpu_batch': int(batch),
-               'units': 'bytes per launch (counter mean over launches x 1000)', 'kernels': out}, open(out_json, 'w'), indent=1)
+    rec = {'command': 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (SURVEY C3, 1x MI355X)',
+           'per_gpu_batch': int(batch), 'units': 'bytes per launch (counter mean over launches x 1000)', 'kernels': out}
+    if kind == 'decode':
+        # eager decode window (bench.py --mode decode --eager --decode-steps 40): bytes of the kernels of the decode loop per step
+        loop = ['advance_kernel', 'decode_attn_kernel<64>', 'decode_bd_kernel', 'decode_embed_kernel', 'gemm_skinny_kernel',
+                'ln_res_fwd_kernel<2>', 'ln_res_partial_fwd_kernel<2>', 'logprob_full_kernel', 'sample_kernel']
+        steps = float(out['advance_kernel']['launches'])
+        d, L, V, B = 768, 12, 1190, int(batch)
+        first = 256 + 1 + 3          # prompt, its sample, warm-up steps (bench.decode_leg): first ring slot count of the window
+        valid = sum(min(first + i, 2048) for i in range(int(steps))) / steps
+        rec.update(command='python3 bench.py --mode decode --eager --decode-steps 40 --no-cpu-baseline (SURVEY C5, eager launches: '
+                           'rocprofv3 cannot collect counters over hipGraph replays)',
+                   decode_loop_kernels=loop, decode_steps_profiled=steps,
+                   positions=f'prompt 256 + warm-up: ring slots ~{first}..{first + int(steps)} written',
+                   hbm_bytes_per_decode_step=sum(out[k]['hbm_bytes_per_launch'] * out[k]['launches'] for k in loop if k in out) / steps,
+                   algorithmic_bytes_per_step_at_these_positions=L * 12 * d * d * 2 + V * d * 2 + B * L * 2 * valid * d * 2)
+    elif kind == 'reformer':
+        rec['command'] = 'python3 bench.py --mode reformer --no-cpu-baseline --steps 2 --warmup 1 (SURVEY C4, 1x MI355X)'
+    json.dump(rec, open(out_json, 'w'), indent=1)
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
