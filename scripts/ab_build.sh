@@ -6,7 +6,6 @@ cd "$(dirname "$0")/../symbolic_music_generation_amd"
 unit=$1; tag=$2; shift 2
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form \
   -mllvm -amdgpu-use-amdgpu-trackers "$@" -c csrc/$unit.hip -o build/${unit}_$tag.o
-objs=$(ls build/*.o | grep -v "_[a-z0-9]*\.o$" | grep -v "build/$unit.o" || true)
-objs=$(for f in api decode elementwise gemm gemm_skinny head metrics optim reformer relattn_bwd relattn_fwd; do [ $f = $unit ] || echo build/$f.o; done)
+objs=$(for s in csrc/*.hip; do f=$(basename $s .hip); [ $f = $unit ] || echo build/$f.o; done)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libmusicxl_$tag.so $objs build/${unit}_$tag.o
 echo build/libmusicxl_$tag.so

@@ -25,6 +25,23 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 
+// In-kernel stamps of the query-owner kernel's tile loop (diagnostic builds only: scripts/ab_build.sh relattn_bwd stamp -DMXL_STAMP;
+// the shipped library contains none of this).  Per wave, shader cycles between consecutive stamps are summed per segment in
+// scalar registers and added to g_dq8_stamps once at the end; read them back with mxl_debug_dq8_stamps.  A stamp waits lgkmcnt(0),
+// so read the SHARES, not the run time (cdna_hip_programming.md, In-kernel stamps).
+#ifdef MXL_STAMP
+__device__ unsigned long long g_dq8_stamps[16];
+#define STAMP_DECL unsigned long long st_last, st_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; \
+    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); st_acc[i] += t_ - st_last; st_last = t_; }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_dq8_stamps[i_], st_acc[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 struct BwdP {
@@ -602,6 +619,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
     _Float16* sG = reinterpret_cast<_Float16*>(sR + G::R_BYTES);                  // [4][32][GS] fp16
     bf16_t* sDG = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sG) + G::G_BYTES);  // [4][32][DGS] bf16
 
+    STAMP_DECL
     const int tid = threadIdx.x;
     // 8 waves: waves w and w + 4 share query group w (32 queries, one LDS skew row per query between them); kbw = 0 takes the
     // first 32 keys of every 64-key tile, kbw = 1 the last 32 -- two waves per SIMD instead of one.
@@ -682,8 +700,21 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
 
     constexpr int NLD8 = (KT * G::CH + 511) / 512;
     u32x4 rk[NLD8], rv[NLD8], rr[NLD8];
+    // DH = 64: every thread owns exactly one 16-byte chunk of a tile.  The loads are then UNCONDITIONAL (row clamped) unless the tile
+    // reaches below the first stored key: with the `ok ? load : zero` form hipcc zero-fills the destination registers first and, to
+    // do that, waits s_waitcnt vmcnt(0) at the top of every tile -- which also waits for the previous tile's dG stores (vmcnt counts
+    // stores): each wave then idles until its stores are acknowledged before it even requests the next tile.  Rows past the last
+    // key (P + row >= T) may hold any finite value: their scores are masked (distance < 0).
+    constexpr bool ONE_CHUNK = (KT * G::CH == 512) && (NLD8 == 1);
     auto load_kv = [&](int kt) {
         const int P = kt * KT;
+        if (ONE_CHUNK) {      // always loaded (row clamped); rows below the first stored key are zeroed when the tile is STORED
+            const int row = tid / G::CH, ch = tid % G::CH;
+            const int srow = max(min(P + row - p0, p.Kc - 1), 0);
+            rk[0] = *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8);
+            rv[0] = *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8);
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < NLD8; n++) {
             const int c = tid + n * 512;
@@ -695,18 +726,28 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
             rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
         }
     };
-    auto store_kv = [&](int buf) {
+    // `P`: first key position of the tile being stored (rows below p0 are the zero memories: k = v = 0)
+    auto store_kv = [&](int buf, int P) {
 #pragma unroll
         for (int n = 0; n < NLD8; n++) {
             const int c = tid + n * 512;
             if (c < KT * G::CH) {
                 const int row = c / G::CH, ch = c % G::CH;
-                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = rk[n];
-                *reinterpret_cast<u32x4*>(sV + buf * G::K_BYTES + G::koff(row, ch)) = rv[n];
+                u32x4 wk = rk[n], wv = rv[n];
+                if (ONE_CHUNK && P + row < p0) { wk = u32x4{0u, 0u, 0u, 0u}; wv = wk; }
+                *reinterpret_cast<u32x4*>(sK + buf * G::K_BYTES + G::koff(row, ch)) = wk;
+                *reinterpret_cast<u32x4*>(sV + buf * G::K_BYTES + G::koff(row, ch)) = wv;
             }
         }
     };
     auto load_r = [&](int dbase) {
+        if (ONE_CHUNK) {
+            const int row = tid / G::CH, ch = tid % G::CH;
+            int d = dbase + row;
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            rr[0] = *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8);
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < NLD8; n++) {
             const int c = tid + n * 512;
@@ -872,10 +913,11 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
         }
     }
 
+    STAMP(10)
     {
         const int P0 = kt_start * KT;
         load_kv(kt_start);
-        store_kv(0);
+        store_kv(0, P0);
 #pragma unroll 1
         for (int q4 = 0; q4 < 3; q4++) {
             const int dbase = i0 - P0 - 64 + 64 * q4;
@@ -937,6 +979,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
     };
     pre_phase(kt_start * KT);
     __syncthreads();
+    STAMP(11)
 
 #pragma unroll 1
     for (int kt = kt_start; kt <= kt_hi; kt++) {
@@ -952,6 +995,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
         const char* cK = sK + cur * G::K_BYTES;
         const char* cV = sV + cur * G::K_BYTES;
         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+        STAMP(0)
         // ---- phase 2: this wave's 32 keys: S / dP chains, skew read, P and dSr, skew write, dQw products
         if (active) {
             const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
@@ -966,8 +1010,10 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av),
                                                              __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp, 0, 0, 0);
             }
+            STAMP(1)
             uint32_t bdu[16];
             skew_read16(gRb - 64 * kb, bdu);
+            STAMP(2)
             if (full) {
 #pragma unroll
                 for (int j = 0; j < 16; j++) s[j] = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j])) * dp[j];
@@ -984,6 +1030,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
 #pragma unroll
             for (int m = 0; m < 8; m++) dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]);
             skew_write16p(dgWb - 64 * kb, dsw);
+            STAMP(3)
 #pragma unroll
             for (int st = 0; st < 2; st++) {
                 const u32x4 pw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
@@ -1008,13 +1055,16 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                 }
             }
         }
+        STAMP(4)
         // the next tile's K/V image and ring rows go to LDS before the barrier: the ring slots they overwrite lie above this tile's
         // window, and the next tile's G blocks (below) need the new rows
         if (more) {
-            store_kv(cur ^ 1);
+            store_kv(cur ^ 1, P + KT);
             store_r(i0 - (P + KT) - 64);
         }
+        STAMP(5)
         __syncthreads();
+        STAMP(6)
         // ---- phase 3: completed distance blocks of the window: wave 0 emits block 2 (d in [dlo+64, dlo+95]), wave 1 block 1
         if (active) {
             const int blk = 2 - kbw;
@@ -1044,11 +1094,15 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
                 }
             }
         }
+        STAMP(7)
         if (more) pre_phase(P + KT);
+        STAMP(8)
         __syncthreads();
+        STAMP(9)
         cur ^= 1;
     }
 
+    STAMP_FLUSH
     // ---- epilogue.  The column sums of the wave's accumulator over its queries are its part of d(r_w_bias) + d(r_r_bias): they
     // go to d_rwb; the dRd kernel moves the r_r_bias part over (colsum(dG) . Rd).  dq = the two waves' accumulators, summed
     // through LDS (the K / V images are dead now).
@@ -1754,6 +1808,16 @@ static int relattn_bwd_impl(const void* q, const void* k, const void* v, const v
         default: return MXL_EUNSUPPORTED;
     }
 }
+
+#ifdef MXL_STAMP
+extern "C" int mxl_debug_dq8_stamps(unsigned long long* host_out16) {
+    hipError_t e = hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(g_dq8_stamps), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_dq8_stamps), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 extern "C" int mxl_relattn_bwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                                const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
