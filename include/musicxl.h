@@ -273,6 +273,14 @@ int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, 
 int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int ld_ids, const int* t_dev,
                unsigned long long* rng_ctr, unsigned long long seed, int B, int do_sample, int top_k, float top_p,
                float temperature, float repetition_penalty, float typical_p, float* out_probs, void* stream);
+/* The same recipe for V > 2048 (the sub-word vocabularies of musicnlp/trainer/wordpiece_tokenizer.py:349-452, whose sizes pick
+ * the cutoff ladder of musicnlp/models/transformer_xl.py:53-66): no sort -- every warper and the multinomial draw are bisections
+ * over a 32-bit order key with integer (fixed-point) conditional sums, so the result is independent of timing.  scratch: B * V * 8
+ * bytes.  Any V >= 1 is accepted (mxl_sample is faster below 2049). */
+int mxl_sample_large(const float* logprobs, int ldl, int V, void* ids, int ld_ids, const int* t_dev,
+                     const unsigned long long* rng_ctr, unsigned long long seed, int B, int do_sample, int top_k, float top_p,
+                     float temperature, float repetition_penalty, float typical_p, float* out_probs, float* scratch,
+                     void* stream);
 /* t_dev += 1; rng_ctr += 1 */
 int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream);
 /* Contrastive search (the reference's 'contrastive' strategy, musicnlp/trainer/eval.py:296-302, over the mems patch of

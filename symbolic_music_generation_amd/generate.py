@@ -90,8 +90,12 @@ class XLDecoder:
         ws = e._last
         N = B * Tp
         # log-probs of the last prompt position only
-        last = ws.logits.view(B, Tp, -1)[:, Tp - 1]
-        ops.adaptive_logprob(last, self.logp, B, c.vocab_size, tuple(c.cutoffs))
+        if ws.logits is None:       # bucketed (large-vocabulary) head: the (N, V) logits were never formed; project B rows here
+            self.tmp.copy_(ws.hid.view(B, Tp, -1)[:, Tp - 1])
+            self._head(self.tmp)
+        else:
+            last = ws.logits.view(B, Tp, -1)[:, Tp - 1]
+            ops.adaptive_logprob(last, self.logp, B, c.vocab_size, tuple(c.cutoffs))
         self.t_dev.fill_(Tp - 1)
         self._trace()
         if sampling is not None:                       # None: the caller picks the token from self.logp (beam search)
@@ -140,13 +144,20 @@ class XLDecoder:
                   bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
                 ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
                                     e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
-        hid = self.h[L & 1]
+        self._head(self.h[L & 1])
+        self._trace()
+
+    def _head(self, hid):
+        """(B, d) hidden states -> self.logp: all head rows (vocabulary + cluster rows) in one weight-streaming GEMM, then the
+        adaptive log-softmax over the row (HF `ProjectedAdaptiveLogSoftmax.log_prob`, the labels=None branch)"""
+        e, c = self.eng, self.eng.cfg
+        B, d = self.B, c.d_model
+        G = ops.gemm_skinny if B <= 64 else ops.gemm
         nrow, nrow_p = e.layout.n_head_rows, e.layout.head_rows_padded
         head_w = e.W[:nrow_p * d].view(nrow_p, d)
         boff = e.layout.entries['crit.out_layers.0.bias'][0]
         G(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
         ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
-        self._trace()
 
     # ---------------------------------------------------------------- beam-search hooks (see beam_search below)
     def beam_prefill(self, prompt: torch.Tensor):

@@ -440,9 +440,24 @@ def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf,
                                    float(scale), _stream()), 'mxl_relattn_decode')
 
 
+_sample_scratch = {}
+
+
 def sample(logprobs, ids, t_dev, rng_ctr, seed, do_sample=False, top_k=0, top_p=1.0, temperature=1.0,
            repetition_penalty=1.0, typical_p=1.0, out_probs=None):
     B, V = logprobs.shape
+    if V > 2048 or os.environ.get('MXL_SAMPLE_LARGE') == '1':      # beyond the LDS sort: the bisection sampler (sample_large.hip)
+        key = (logprobs.device, B, V)
+        scratch = _sample_scratch.get(key)
+        if scratch is None:
+            _sample_scratch.clear()
+            scratch = _sample_scratch[key] = torch.empty(B, 2 * V, device=logprobs.device, dtype=torch.float32)
+        check(lib().mxl_sample_large(_p(logprobs), logprobs.stride(0), V, _p(ids), ids.stride(0), _p(t_dev), _p(rng_ctr), seed, B,
+                                     int(do_sample), int(top_k or 0), float(top_p if top_p is not None else 1.0),
+                                     float(temperature), float(repetition_penalty if repetition_penalty is not None else 1.0),
+                                     float(typical_p if typical_p is not None else 1.0), _p(out_probs), _p(scratch), _stream()),
+              'mxl_sample_large')
+        return
     check(lib().mxl_sample(_p(logprobs), logprobs.stride(0), V, _p(ids), ids.stride(0), _p(t_dev), _p(rng_ctr), seed, B,
                            int(do_sample), int(top_k or 0), float(top_p if top_p is not None else 1.0),
                            float(temperature), float(repetition_penalty if repetition_penalty is not None else 1.0),

@@ -113,3 +113,115 @@ def test_cluster_bucket_lists_are_stable_and_complete(dev):
         else:
             assert (th[w] == cut[0] + i - 1).all() and torch.equal(tt[w], nxt[w] - bounds[i])
     assert (th[want_groups[-1]] == -1).all() and (tt[want_groups[-1]] == -1).all()
+
+
+def _hf_warp(lp_mod, logp, hist, c):
+    s = logp.clone()
+    if c['rp'] != 1.0:
+        s = lp_mod.RepetitionPenaltyLogitsProcessor(c['rp'])(hist, s)
+    if c['temp'] != 1.0:
+        s = lp_mod.TemperatureLogitsWarper(c['temp'])(hist, s)
+    if c['k']:
+        s = lp_mod.TopKLogitsWarper(c['k'])(hist, s)
+    if c['p'] < 1.0:
+        s = lp_mod.TopPLogitsWarper(c['p'])(hist, s)
+    if c['typ'] < 1.0:
+        s = lp_mod.TypicalLogitsWarper(mass=c['typ'])(hist, s)
+    return s.softmax(-1)
+
+
+@pytest.mark.parametrize('V', [1190, 32768, 262144])
+def test_large_vocab_sampler_vs_hf_processors(dev, V, monkeypatch):
+    """mxl_sample_large (no sort: bisections over order keys) against HF's own logits processors chained in GenerationMixin's
+    order, the same check tests/test_decode_gpu.py makes of the LDS-sort sampler; at V = 1190 also against that sampler."""
+    lp_mod = pytest.importorskip('transformers.generation.logits_process')
+    from symbolic_music_generation_amd import ops
+    monkeypatch.setenv('MXL_SAMPLE_LARGE', '1')
+    torch.manual_seed(3)
+    B, Th = 4, 40
+    logp = torch.log_softmax(torch.randn(B, V) * 2.5, -1)
+    logp[1, 7] = logp[1, 9]                                  # an exact tie inside the row
+    lp = logp.to(dev)
+    hist = torch.randint(0, V, (B, Th))
+    hist[:, 5] = hist[:, 6]
+    hist[0, :8] = logp[0].topk(8).indices
+    ids = torch.zeros(B, Th + 8, dtype=torch.int64); ids[:, :Th] = hist
+    ids_d = ids.to(dev)
+    t = torch.full((1,), Th - 1, device=dev, dtype=torch.int32)
+    rng = torch.zeros(1, device=dev, dtype=torch.int64)
+    probs = torch.zeros(B, V, device=dev)
+    cases = [dict(rp=1.0, typ=1.0, k=8, p=1.0, temp=1.0), dict(rp=1.3, typ=1.0, k=0, p=1.0, temp=1.0),
+             dict(rp=1.0, typ=0.6, k=0, p=1.0, temp=1.0), dict(rp=1.2, typ=0.9, k=64, p=0.9, temp=0.8),
+             dict(rp=1.0, typ=0.2, k=16, p=1.0, temp=1.4), dict(rp=1.5, typ=0.95, k=0, p=0.7, temp=1.0),
+             dict(rp=1.0, typ=1.0, k=500, p=0.5, temp=0.9)]
+    for c in cases:
+        ops.sample(lp, ids_d, t, rng, 5, do_sample=True, top_k=c['k'], top_p=c['p'], temperature=c['temp'],
+                   repetition_penalty=c['rp'], typical_p=c['typ'], out_probs=probs)
+        want = _hf_warp(lp_mod, logp, hist, c)
+        got = probs.cpu()
+        # the supports agree except, at most, for boundary tokens whose kept / dropped decision hangs on the last bits of a
+        # float32 cumulative sum over V terms (HF) against an exact integer one (here): such a token carries next to no mass
+        diff = (got > 0) != (want > 0)
+        assert diff.sum().item() <= (0 if V <= 2048 else 2 * B), (c, diff.sum().item())
+        assert (got - want).abs().max().item() < (2e-5 if V <= 2048 else 2e-3), (c, (got - want).abs().max().item())
+        tok = ids_d[:, Th].cpu()
+        assert (got.gather(1, tok[:, None]) > 0).all(), c
+        if V <= 2048:                                         # the sort sampler on the same inputs: same support, same token
+            monkeypatch.setenv('MXL_SAMPLE_LARGE', '0')
+            p2 = torch.zeros_like(probs)
+            ids2 = ids.to(dev)
+            ops.sample(lp, ids2, t, rng, 5, do_sample=True, top_k=c['k'], top_p=c['p'], temperature=c['temp'],
+                       repetition_penalty=c['rp'], typical_p=c['typ'], out_probs=p2)
+            monkeypatch.setenv('MXL_SAMPLE_LARGE', '1')
+            assert ((p2 > 0) == (probs > 0)).all(), c
+            assert (p2 - probs).abs().max().item() < 1e-6, c
+    # greedy = arg-max of the penalised scores (ties -> lowest index)
+    ops.sample(lp, ids_d, t, rng, 5, do_sample=False, repetition_penalty=5.0)
+    want = lp_mod.RepetitionPenaltyLogitsProcessor(5.0)(hist, logp.clone()).argmax(-1)
+    assert torch.equal(ids_d[:, Th].cpu(), want)
+    # the draw follows the distribution: top-k 4, 1500 draws of row 0
+    ops.sample(lp, ids_d, t, rng, 7, do_sample=True, top_k=4, out_probs=probs)
+    want = probs[0].cpu()
+    sel = want > 0
+    assert sel.sum().item() == 4
+    counts = torch.zeros(V)
+    n = 1500
+    for i in range(n):
+        rng.fill_(i)
+        ops.sample(lp, ids_d, t, rng, 7, do_sample=True, top_k=4)
+        counts[ids_d[0, Th].item()] += 1
+    assert counts[~sel].sum().item() == 0
+    assert ((counts[sel] / n) - want[sel]).abs().max().item() < 0.05
+
+
+def test_generate_at_large_vocab_vs_oracle(dev):
+    """model.generate at a sub-word-sized vocabulary (V = 32768, cutoffs [10000]: the bucketed head, no (N, V) logits in the
+    prompt pass, the bisection sampler): greedy tokens against the oracle's HF-style loop; eager == hipGraph replay; a sampled
+    run stays inside the top-k support of the step's own log-probabilities."""
+    V, cut = 32768, (10000,)
+    ref, m = _pair(dev, V, cut, 96, seed=71)
+    assert m.engine.bucketed_head
+    ref.eval(); m.eval()
+    g = torch.Generator().manual_seed(72)
+    prompt = torch.randint(4, V, (3, 20), generator=g)
+    want = ref.greedy_generate(prompt, max_length=80)          # crosses the mem_len = 64 ring boundary
+    got = m.generate(input_ids=prompt.to(dev), max_length=80, do_sample=False, use_graph=False).cpu()
+    got_g = m.generate(input_ids=prompt.to(dev), max_length=80, do_sample=False, use_graph=True).cpu()
+    assert torch.equal(got, got_g)
+    assert got.shape == want.shape and torch.equal(got[:, :20], prompt)
+    mism = (got != want).nonzero()
+    if mism.numel():          # a bf16 near-tie may fork a row: the oracle's margin at the first fork must be tiny
+        b, tpos = mism[0].tolist()
+        with torch.no_grad():
+            lp = ref(want[b:b + 1, :tpos]).prediction_scores[0, -1]
+        top = lp.topk(2).values
+        assert (top[0] - top[1]).item() < 5e-2, f'row {b} forks at {tpos} with oracle margin {(top[0] - top[1]).item():.4f}'
+    agree = (got == want).float().mean().item()
+    print(f'V={V} greedy generation: {agree:.3f} of the tokens identical to the oracle')
+    m._decoder.rng.zero_()                                   # the draw counter runs on across calls; rewind it
+    s1 = m.generate(input_ids=prompt.to(dev), max_length=60, do_sample=True, top_k=8, top_p=0.95, use_graph=True).cpu()
+    m._decoder.rng.zero_()
+    s2 = m.generate(input_ids=prompt.to(dev), max_length=60, do_sample=True, top_k=8, top_p=0.95, use_graph=False).cpu()
+    assert s1.shape == (3, 60) and torch.equal(s1[:, :20], prompt)
+    assert (s1 >= 0).all() and (s1 < V).all()
+    assert torch.equal(s1, s2), 'eager and hipGraph replay draw the same tokens (integer selection, counter-based uniforms)'
