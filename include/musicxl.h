@@ -45,6 +45,13 @@ int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                   const void* aux, int ldaux, int ksplits,
                   float drop_p, unsigned long long seed, unsigned site, void* stream);
 
+/* mxl_gemm_bf16 (bf16 output, no K-split) and, in the same call, colsum[n] += sum_m C[m][n]: the bias gradient of the layer whose
+ * output gradient C is (pos_ff.CoreNet.0.bias: C = the masked dX of CoreNet.3).  With MXL_GEMM_RELU_BWD on the large-tile path (M and
+ * N multiples of 256) the sums are formed from the epilogue's fp32 values inside the GEMM; otherwise by mxl_colsum_bf16 afterwards. */
+int mxl_gemm_bf16_colsum(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         int transA, int transB, int flags, float alpha, const float* bias, const void* aux, int ldaux,
+                         float drop_p, unsigned long long seed, unsigned site, float* colsum, void* stream);
+
 /* same kernel, grid.y = batch: operand element offsets (by / bdiv) * s?1 + (by % bdiv) * s?2 */
 int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           int transA, int transB, int flags, float alpha, int ksplits, int batch, int bdiv,
@@ -150,6 +157,11 @@ int mxl_ln_residual_fwd(const void* x, const void* res, const float* gamma, cons
 int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                         const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
                         float drop_p, unsigned long long seed, unsigned site, void* stream);
+/* same, and dxsum[c] += sum_rows dx[row][c] (the stored bf16 values; d <= 1024): x is the output of a biased linear layer
+ * (pos_ff.CoreNet.3), so this IS that layer's bias gradient -- one pass over dx less than mxl_colsum_bf16 afterwards */
+int mxl_ln_residual_bwd_colsum(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                               const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, int N,
+                               int d, float drop_p, unsigned long long seed, unsigned site, void* stream);
 /* same, with an extra gradient stream added to the residual output: dres = dz + dadd (Reformer's y1 = x1 + f(x2) chains) */
 int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                             const float* gamma, const void* dadd, void* dres, float* dgamma, float* dbeta, int N, int d,

@@ -204,12 +204,12 @@ __global__ __launch_bounds__(256) void ln_res_partial_fwd_kernel(const float* sl
 constexpr int LNB_ROWS = LNB_ROWS_;  // rows per block (8 waves x 8 rows): 2d atomics per block, 4096 waves for the 32768-row C3 matrices
 constexpr int LNB_THREADS = 512;
 
-template <int NCH>
-__global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
+template <int NCH, bool CS = false>
+__global__ __launch_bounds__(LNB_THREADS) __attribute__((amdgpu_waves_per_eu(NCH <= 2 ? 4 : 1, 8))) void ln_res_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* z,
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, int N,
                                                          int d, unsigned thresh, float dscale, unsigned long long seed,
-                                                         unsigned site, const bf16_t* dadd) {
+                                                         unsigned site, const bf16_t* dadd, float* dxsum) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // per-wave slabs [8 waves][2][d] of dgamma / dbeta partials (plain 16-byte writes, then a column-wise sum): LDS atomics from
     // eight waves onto the same 2d addresses cost as much as several rows of work.  (NCH > 2: d up to 2048 would need 128 KB of
@@ -224,10 +224,12 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunks = d >> 3;
     float ag[NCH][8], ab[NCH][8];
+    float ac[CS ? NCH : 1][8];             // column sums of dx as stored (CS: dxsum != null, SLABS form only): the bias gradient of the
+                                           // linear layer whose output gradient dx is -- saves a pass over dx (mxl_colsum_bf16)
 #pragma unroll
     for (int i = 0; i < NCH; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+        for (int j = 0; j < 8; j++) { ag[i][j] = 0.f; ab[i][j] = 0.f; if (CS) ac[i][j] = 0.f; }
     for (int rr = 0; rr < LNB_ROWS / (LNB_THREADS / 64); rr++) {
         const int row = blockIdx.x * LNB_ROWS + rr * (LNB_THREADS / 64) + wid;
         if (row >= N) break;
@@ -278,6 +280,13 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
                 if (dx) {
                     u32x4 ov = {pack2bf(ox[0], ox[1]), pack2bf(ox[2], ox[3]), pack2bf(ox[4], ox[5]), pack2bf(ox[6], ox[7])};
                     *reinterpret_cast<u32x4*>(dx + (size_t)row * d + c * 8) = ov;
+                    if (CS) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {       // the rounded values, as a separate column sum over dx would see them
+                            ac[i][2 * j] += __uint_as_float(ov[j] << 16);
+                            ac[i][2 * j + 1] += __uint_as_float(ov[j] & 0xffff0000u);
+                        }
+                    }
                 }
             }
         }
@@ -300,6 +309,24 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_res_bwd_kernel(const bf16_t* d
 #pragma unroll
             for (int w = 0; w < LNB_THREADS / 64; w++) t += sg[(size_t)w * 2 * d + i];
             atomicAdd((i < d ? dgamma : dbeta - d) + i, t);
+        }
+        if (CS) {              // third accumulator through the same slabs
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int c = lane + i * 64;
+                if (c < chunks) {
+                    *reinterpret_cast<f32x4*>(mg + c * 8) = f32x4{ac[i][0], ac[i][1], ac[i][2], ac[i][3]};
+                    *reinterpret_cast<f32x4*>(mg + c * 8 + 4) = f32x4{ac[i][4], ac[i][5], ac[i][6], ac[i][7]};
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < d; i += LNB_THREADS) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < LNB_THREADS / 64; w++) t += sg[(size_t)w * 2 * d + i];
+                atomicAdd(dxsum + i, t);
+            }
         }
         return;
     }
@@ -534,18 +561,33 @@ extern "C" int mxl_ln_residual_fwd(const void* x, const void* res, const float* 
     return MXL_OK;
 }
 
-extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
-                                   const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
-                                   float drop_p, unsigned long long seed, unsigned site, void* stream) {
+static int ln_residual_bwd_launch(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                  const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
+                                  float drop_p, unsigned long long seed, unsigned site, float* dxsum, void* stream) {
     MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    MXL_CHECK_ARG(!dxsum || (dx && d <= 1024));
     MXL_CHECK_ARG(drop_p <= 0.f || (unsigned long long)N * d <= 0xffffffffull);
-    const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
+    const auto kfn = dxsum ? (d <= 512 ? ln_res_bwd_kernel<1, true> : ln_res_bwd_kernel<2, true>)
+                           : (d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>);
     hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (d <= 1024 ? LNB_THREADS / 64 : 1) * 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p),
-                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr);
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site, (const bf16_t*)nullptr, dxsum);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
+}
+
+extern "C" int mxl_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                   const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, int N, int d,
+                                   float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    return ln_residual_bwd_launch(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, drop_p, seed, site, nullptr, stream);
+}
+
+extern "C" int mxl_ln_residual_bwd_colsum(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                          const float* gamma, void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum,
+                                          int N, int d, float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    MXL_CHECK_ARG(dxsum);
+    return ln_residual_bwd_launch(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, drop_p, seed, site, dxsum, stream);
 }
 
 extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
@@ -555,7 +597,7 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
     const auto kfn = d <= 512 ? ln_res_bwd_kernel<1> : d <= 1024 ? ln_res_bwd_kernel<2> : ln_res_bwd_kernel<LN_MAXCH>;
     hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (d <= 1024 ? LNB_THREADS / 64 : 1) * 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
-                       (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd);
+                       (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd, (float*)nullptr);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

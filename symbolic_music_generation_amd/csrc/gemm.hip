@@ -36,7 +36,9 @@ struct GemmP {
     // batching: grid.y = batch index by; operand offsets (elements) = (by / bdiv) * s?1 + (by % bdiv) * s?2
     int bdiv;
     long long sA1, sA2, sB1, sB2, sC1, sC2;
+    float* colsum;         // [N] f32 or null: += column sums of the epilogue's values (gemm_nt256_kernel, EPI & GEMM_COLSUM_BIT)
 };
+constexpr int GEMM_COLSUM_BIT = 0x80;      // internal epilogue bit (not a public flag): see mxl_gemm_bf16_colsum
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, c
 // made of 64-byte segments, and half as many instructions (scripts/ubench/stores.hip: a 256 x 256 bf16 tile leaves a CU in 8.1 us
 // the first way, 1.4 us the second -- with no other CU active).
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
-                                                   const f32x4 q0, const f32x4 q1) {
+                                                   const f32x4 q0, const f32x4 q1, float* cs0 = nullptr, float* cs1 = nullptr) {
     float v0[4], v1[4];
     if ((flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) {
         // the aux operand the same way round: one 16-byte load per lane at the address the store below uses (8 consecutive
@@ -227,6 +229,10 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int fla
     } else {
         epilogue_vals(p, flags, m, n, q0, v0);
         epilogue_vals(p, flags, m, n + 16, q1, v1);
+    }
+    if (cs0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cs0[r] += v0[r]; cs1[r] += v1[r]; }
     }
     unsigned a0 = pack2bf(v0[0], v0[1]), a1 = pack2bf(v0[2], v0[3]), b0 = pack2bf(v1[0], v1[1]), b1 = pack2bf(v1[2], v1[3]);
     // even 16-lane rows keep block 0 and receive the neighbour's block-0 quad; odd rows keep block 1 and receive the neighbour's
@@ -535,15 +541,43 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         if (pairs) {
             // 16-byte stores: column blocks (0,1), (2,3) of a row block pair up; with three column blocks the third one pairs up
             // across row blocks (i, i+1)
+            constexpr bool CS = EPI >= 0 && (EPI & GEMM_COLSUM_BIT) && !(FN & 1);      // (launched only when every tile is interior)
+            float cs[CS ? FN : 1][4];
+            if (CS) {
+#pragma unroll
+                for (int j = 0; j < FN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) cs[j][r] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < FM; i++) {
                 const int m = m0 + wr * (FM * 16) + i * 16 + (l & 15);
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2)
-                    epilogue_pair_bf16(p, flags, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1]);
+                    epilogue_pair_bf16(p, flags & ~GEMM_COLSUM_BIT, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1],
+                                       CS ? cs[CS ? j : 0] : nullptr, CS ? cs[CS ? j + 1 : 0] : nullptr);
                 if ((FN & 1) && !(i & 1))
                     epilogue_rowpair_bf16(p, flags, m, n0 + wc * (FN * 16) + (FN - 1) * 16 + (l >> 4) * 4, l, acc[i][FN - 1],
                                           acc[(i + 1) % FM][FN - 1]);
+            }
+            if (CS) {
+                // the lane's 4 x FN column sums over its 8 row blocks -> over the 16 lanes (rows) that share the columns -> one
+                // atomic per column from each of the two wave rows
+#pragma unroll
+                for (int j = 0; j < FN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float v = cs[j][r];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                        cs[j][r] = v;
+                    }
+                if ((l & 15) == 0) {
+#pragma unroll
+                    for (int j = 0; j < FN; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) atomicAdd(p.colsum + n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4 + r, cs[j][r]);
+                }
             }
         } else {
 #pragma unroll
@@ -709,7 +743,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
                        const void* aux, int ldaux, int ksplits,
                        float drop_p, unsigned long long seed, unsigned site, void* stream,
                        int batch, int bdiv, long long sA1, long long sA2, long long sB1, long long sB2,
-                       long long sC1, long long sC2) {
+                       long long sC1, long long sC2, float* colsum = nullptr, bool* colsum_fused = nullptr) {
     MXL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
     MXL_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0);
     MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
@@ -734,6 +768,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     ksplits = (ktiles + per - 1) / per;
     p.ksplit = per * BK;
     p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.alpha = alpha; p.flags = flags;
+    p.colsum = colsum;
     p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
     { static const bool nt = getenv("MXL_GEMM_NT") != nullptr; if (nt) p.flags |= (1 << 30); }
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -788,6 +823,12 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         else if (p.flags == MXL_GEMM_BIAS) MXL_NT256_LAUNCH(MXL_GEMM_BIAS);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT);
+        else if (p.flags == MXL_GEMM_RELU_BWD && colsum && !use192 && (M % 256) == 0 && (N % 256) == 0 && (ldc & 7) == 0 &&
+                 ((uintptr_t)C & 15) == 0) {
+            // every tile interior (the paired-store epilogue): the column sums of the output ride along (mxl_gemm_bf16_colsum)
+            MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD | GEMM_COLSUM_BIT);
+            *colsum_fused = true;
+        }
         else if (p.flags == MXL_GEMM_RELU_BWD) MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD);
         else if (p.flags == MXL_GEMM_ADD_AUX) MXL_NT256_LAUNCH(MXL_GEMM_ADD_AUX);                    // Reformer residual epilogues
         else if (p.flags == (MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT);
@@ -853,6 +894,17 @@ extern "C" int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N
                              float drop_p, unsigned long long seed, unsigned site, void* stream) {
     return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, flags, alpha, bias, aux, ldaux, ksplits, drop_p,
                        seed, site, stream, 1, 1, 0, 0, 0, 0, 0, 0);
+}
+
+extern "C" int mxl_gemm_bf16_colsum(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                    int transA, int transB, int flags, float alpha, const float* bias, const void* aux, int ldaux,
+                                    float drop_p, unsigned long long seed, unsigned site, float* colsum, void* stream) {
+    MXL_CHECK_ARG(colsum && !(flags & (MXL_GEMM_OUT_F32 | MXL_GEMM_OUT_F32_ATOMIC)));
+    bool fused = false;
+    const int rc = gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, flags, alpha, bias, aux, ldaux, 1, drop_p, seed, site,
+                               stream, 1, 1, 0, 0, 0, 0, 0, 0, colsum, &fused);
+    if (rc != MXL_OK || fused) return rc;
+    return mxl_colsum_bf16(C, colsum, M, N, ldc, stream);
 }
 
 extern "C" int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,

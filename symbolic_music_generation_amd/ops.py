@@ -73,14 +73,21 @@ def ktime_collect():
 
 def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,
          flags=0, alpha=1.0, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, ksplits=1,
-         lda=None, ldb=None, ldc=None, ldaux=None, drop_p=0.0, seed=0, site=0):
-    """C[M,N] (+)= alpha * op(A) op(B); see mxl_gemm_bf16.  Leading dimensions default to the last-dim stride."""
+         lda=None, ldb=None, ldc=None, ldaux=None, drop_p=0.0, seed=0, site=0, colsum: Optional[torch.Tensor] = None):
+    """C[M,N] (+)= alpha * op(A) op(B); see mxl_gemm_bf16.  Leading dimensions default to the last-dim stride.
+    `colsum` (N,) f32: += the column sums of C in the same call (mxl_gemm_bf16_colsum; bf16 output, ksplits == 1)."""
     _req(a, torch.bfloat16, 'A'); _req(b, torch.bfloat16, 'B')
     lda = lda if lda is not None else a.stride(-2)
     ldb = ldb if ldb is not None else b.stride(-2)
     ldc = ldc if ldc is not None else c.stride(-2)
     if aux is not None and ldaux is None:
         ldaux = aux.stride(-2)
+    if colsum is not None:
+        assert ksplits == 1
+        check(lib().mxl_gemm_bf16_colsum(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,
+                                         float(alpha), _p(bias), _p(aux), ldaux or 0, float(drop_p), seed, site, _p(colsum),
+                                         _stream()), 'mxl_gemm_bf16_colsum')
+        return c
     check(lib().mxl_gemm_bf16(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,
                               float(alpha), _p(bias), _p(aux), ldaux or 0, ksplits, float(drop_p), seed, site,
                               _stream()), 'mxl_gemm_bf16')
@@ -167,12 +174,20 @@ def ln_residual_fwd(x, res, gamma, beta, y, z=None, mean=None, rstd=None, eps=1e
     return y
 
 
-def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, drop_p=0.0, seed=0, site=0):
+def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, dres, dx, dgamma, dbeta, drop_p=0.0, seed=0, site=0, dxsum=None):
+    """`dxsum` (d,) f32: += the column sums of dx (the bias gradient of the linear layer that produced x), d <= 1024"""
     d = z.shape[-1]
     N = z.numel() // d
+    if dxsum is not None and d <= 1024:
+        check(lib().mxl_ln_residual_bwd_colsum(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx),
+                                               _p(dgamma), _p(dbeta), _p(dxsum), N, d, float(drop_p), seed, site, _stream()),
+              'mxl_ln_residual_bwd_colsum')
+        return
     check(lib().mxl_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx),
                                     _p(dgamma), _p(dbeta), N, d, float(drop_p), seed, site, _stream()),
           'mxl_ln_residual_bwd')
+    if dxsum is not None:
+        colsum(dx, dxsum, N, d)
 
 
 def ln_bwd_add(dy, dy2, z, mean, rstd, gamma, dadd, dres, dgamma, dbeta):

@@ -430,8 +430,7 @@ class RFEngine:
             ops.gemm(dff, ws.a[l], gl(l, 'feed_forward.output.dense.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi))
             ops.gemm(dff, self.WT[(l, 'ff2')], ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
-                     aux=ws.a[l], alpha=dscale)
-            ops.colsum(ws.dF, gl(l, 'feed_forward.dense.dense.bias'), N, Fi)
+                     aux=ws.a[l], alpha=dscale, colsum=gl(l, 'feed_forward.dense.dense.bias'))
             ops.gemm(ws.dF, ws.h2[l], gl(l, 'feed_forward.dense.dense.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d))
             ops.gemm(ws.dF, self.WT[(l, 'ff1')], t2, N, d, Fi)

@@ -569,15 +569,13 @@ class XLEngine:
             # LN2 backward: dres -> dC (into h1 via residual), dx -> dD (into f_out)
             ops.ln_residual_bwd(dy, dy2, ws.z2[l], ws.st2[l][0], ws.st2[l][1], self._lw(l, 'pos_ff.layer_norm.weight', self.P),
                                 ws.dC, ws.dD, gw(l, 'pos_ff.layer_norm.weight'), gw(l, 'pos_ff.layer_norm.bias'),
-                                drop_p=p, seed=seed, site=self._site(l, 2))
-            # FFN2
-            ops.colsum(ws.dD, gw(l, 'pos_ff.CoreNet.3.bias'), N, d)
+                                drop_p=p, seed=seed, site=self._site(l, 2), dxsum=gw(l, 'pos_ff.CoreNet.3.bias'))
+            # FFN2 (its bias gradient = the column sums of dD: accumulated by the LayerNorm backward above)
             ops.gemm(ws.dD, ws.a[l], gw(l, 'pos_ff.CoreNet.3.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi, N))
             ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
-                     aux=ws.a[l], alpha=dscale)
-            # FFN1
-            ops.colsum(ws.dF, gw(l, 'pos_ff.CoreNet.0.bias'), N, Fi)
+                     aux=ws.a[l], alpha=dscale, colsum=gw(l, 'pos_ff.CoreNet.0.bias'))
+            # FFN1 (its bias gradient = the column sums of dF: formed in the epilogue of the GEMM above)
             ops.gemm(ws.dF, ws.h1[l], gw(l, 'pos_ff.CoreNet.0.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d, N))
             ops.gemm(ws.dF, self._lwt(l, 'pos_ff.CoreNet.0.weight'), ws.dD, N, d, Fi)

@@ -555,3 +555,56 @@ def test_relattn_bwd_with_a_dg_buffer_of_fewer_sequences(dev, B, T, H, dh, M, Kc
     assert torch.equal(full[0], one[0])
     for nm, a, b_ in zip(('d_rd', 'd_rwb', 'd_rrb'), full[1:], one[1:]):
         assert rel_err(b_.cpu(), a.cpu()) < 1e-4, nm
+
+
+@pytest.mark.parametrize('N,d,p', [(4096, 768, 0.1), (1000, 512, 0.0), (3001, 1024, 0.1)])
+def test_ln_residual_bwd_with_fused_column_sums(dev, N, d, p):
+    """mxl_ln_residual_bwd_colsum: same dres / dx / dgamma / dbeta as mxl_ln_residual_bwd, bit for bit, and dxsum == the column
+    sums of the stored dx (what mxl_colsum_bf16 returns on it; only the summation order differs)"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(20)
+    dy = torch.randn(N, d, device=dev).bfloat16(); dy2 = torch.randn(N, d, device=dev).bfloat16()
+    z = (torch.randn(N, d, device=dev) * 1.5 + 0.2).bfloat16()
+    mean = z.float().mean(-1); rstd = (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+    gamma = torch.rand(d, device=dev) + 0.5
+    outs = []
+    for fused in (False, True):
+        dres = torch.empty_like(z); dx = torch.empty_like(z)
+        dg = torch.full((d,), 0.25, device=dev); db = torch.full((d,), -0.5, device=dev)
+        cs = torch.full((d,), 3.0, device=dev)
+        ops.ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, dres, dx, dg, db, drop_p=p, seed=99, site=7,
+                            dxsum=cs if fused else None)
+        if not fused:
+            ops.colsum(dx, cs, N, d)
+        outs.append((dres, dx, dg, db, cs))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (a[2] - b[2]).abs().max().item() <= 1e-3 * a[2].abs().max().item()       # atomics: order only
+    assert (a[3] - b[3]).abs().max().item() <= 1e-3 * a[3].abs().max().item()
+    want = 3.0 + b[1].float().sum(0)
+    scale = b[1].float().abs().sum(0).max().item()
+    assert (b[4] - want).abs().max().item() <= 1e-5 * scale, (b[4] - want).abs().max().item()
+    assert (a[4] - want).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 3072, 768), (1024, 512, 256), (1000, 3072, 768)])
+def test_gemm_relu_bwd_with_fused_column_sums(dev, M, N, K):
+    """mxl_gemm_bf16_colsum with MXL_GEMM_RELU_BWD (dF = mask(dD W) and, in the same launch, the bias gradient colsum(dF)): the
+    product is bit-identical to mxl_gemm_bf16's; the sums agree with a column sum over the stored bf16 output to within the bf16
+    rounding of its terms (the fused form adds the epilogue's fp32 values).  The third shape has edge tiles (unfused fallback)."""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(21)
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    aux = torch.relu(torch.randn(M, N, device=dev)).bfloat16()
+    c0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); c1 = torch.empty_like(c0)
+    ops.gemm(a, w, c0, M, N, K, flags=ops.GEMM_RELU_BWD, aux=aux, alpha=1.25)
+    cs = torch.full((N,), 2.0, device=dev)
+    ops.gemm(a, w, c1, M, N, K, flags=ops.GEMM_RELU_BWD, aux=aux, alpha=1.25, colsum=cs)
+    assert torch.equal(c0, c1)
+    want = 2.0 + c0.float().sum(0)
+    # each of the M terms of a column carries at most half a bf16 ulp of rounding: |err| <= 2^-9 * sum |term| (far less on average)
+    bound = c0.float().abs().sum(0) * 2.0 ** -9 + 1e-4
+    err = (cs - want).abs()
+    assert (err <= bound).all(), (err / bound).max().item()
+    assert err.max().item() <= 0.05 * bound.max().item() or (M % 256) != 0      # in practice: random-walk, not worst case
