@@ -32,8 +32,11 @@ for name, O, K in (('qkv', 3 * d, d), ('o', d, d), ('ffn1', F, d), ('ffn2', d, F
     t = timeit(lambda i: ops.gemm(X[i % NB], W, Y[i % NB], NT, O, K))
     tt = timeit(lambda i: torch.matmul(X[i % NB], W.t(), out=Y[i % NB]))
     print(f'{name:5s} fwd  Y=X W^T   [{NT}x{O}x{K}]: ours {t*1e3:7.1f} us {fl/t/1e9:6.0f} TF/s | torch {tt*1e3:7.1f} us {fl/tt/1e9:6.0f} TF/s', flush=True)
-    t = timeit(lambda i: ops.gemm(Y[i % NB], W, dX[i % NB], NT, K, O, trans_b=True))
+    Wt = W.t().contiguous()       # the engines keep [in][out] copies of the weights: the input gradient is an NT product too
+    t = timeit(lambda i: ops.gemm(Y[i % NB], Wt, dX[i % NB], NT, K, O))
     tt = timeit(lambda i: torch.matmul(Y[i % NB], W, out=dX[i % NB]))
+    if os.environ.get('SKIP_DW'):
+        print(f'{name:5s} dX   dX=dY W   [{NT}x{K}x{O}]: ours {t*1e3:7.1f} us {fl/t/1e9:6.0f} TF/s', flush=True); continue
     print(f'{name:5s} dX   dX=dY W   [{NT}x{K}x{O}]: ours {t*1e3:7.1f} us {fl/t/1e9:6.0f} TF/s | torch {tt*1e3:7.1f} us {fl/tt/1e9:6.0f} TF/s', flush=True)
     k_ = ks(O, K)
     t = timeit(lambda i: ops.gemm(Y[i % NB], X[i % NB], dW, O, K, NT, trans_a=True, trans_b=True, flags=ops.GEMM_OUT_F32_ATOMIC, ksplits=k_))

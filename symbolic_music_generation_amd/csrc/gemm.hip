@@ -111,12 +111,16 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* base, int rb, int ks) {
 
 // One 1x4 output quad (row m, columns n..n+3, n < N): alpha, bias, relu, dropout, relu-backward mask, aux add ...
 // `auxq`: the aux values of columns n..n+3 (4 bf16 in two dwords) if the caller has loaded them already
+// `biasq`: bias[n..n+3] if the caller holds them in registers
 __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, const int m, const int n, const f32x4 a4_, float (&v)[4],
-                                              const uint32_t* auxq = nullptr) {
+                                              const uint32_t* auxq = nullptr, const float* biasq = nullptr) {
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = a4_[r] * p.alpha;
             const bool full = (n + 3 < p.N);
-            if (flags & MXL_GEMM_BIAS) {
+            if ((flags & MXL_GEMM_BIAS) && biasq) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] += biasq[r];
+            } else if (flags & MXL_GEMM_BIAS) {
                 if (full) {
                     const float b0 = p.bias[n], b1 = p.bias[n + 1], b2 = p.bias[n + 2], b3 = p.bias[n + 3];
                     v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
@@ -213,22 +217,29 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, const int flags, c
 // 16 x 32.  The store path of a CU handles ~30 ns per wave-instruction made of 32-byte row segments but ~11 ns per instruction
 // made of 64-byte segments, and half as many instructions (scripts/ubench/stores.hip: a 256 x 256 bf16 tile leaves a CU in 8.1 us
 // the first way, 1.4 us the second -- with no other CU active).
+// `axv` (have_ax): the lane's 16 bytes of aux at the store address (pair_aux_load below), loaded by the caller ahead of time; `bq0` / `bq1`:
+// the bias quads of the two blocks, in registers
+__device__ __forceinline__ u32x4 pair_aux_load(const GemmP& p, const int m, const int n, const int l) {
+    const int acol = ((l >> 4) & 1) ? n + 16 - 4 : n;
+    return *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.ldaux + acol);
+}
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
-                                                   const f32x4 q0, const f32x4 q1, float* cs0 = nullptr, float* cs1 = nullptr) {
+                                                   const f32x4 q0, const f32x4 q1, float* cs0 = nullptr, float* cs1 = nullptr,
+                                                   const bool have_ax = false, const u32x4 axv = u32x4{0u, 0u, 0u, 0u},
+                                                   const float* bq0 = nullptr, const float* bq1 = nullptr) {
     float v0[4], v1[4];
     if ((flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) {
         // the aux operand the same way round: one 16-byte load per lane at the address the store below uses (8 consecutive
         // columns of one block), then lanes l and l ^ 16 trade halves so that each holds the aux of its own two quads
-        const int acol = ((l >> 4) & 1) ? n + 16 - 4 : n;
-        const u32x4 ax = *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.ldaux + acol);
+        const u32x4 ax = have_ax ? axv : pair_aux_load(p, m, n, l);
         const auto s0 = __builtin_amdgcn_permlane16_swap(ax[0], ax[2], false, false);    // (lo, hi): odd rows' lo <-> even rows' hi
         const auto s1 = __builtin_amdgcn_permlane16_swap(ax[1], ax[3], false, false);
         const uint32_t aq0[2] = {s0[0], s1[0]}, aq1[2] = {s0[1], s1[1]};                  // block 0 quad, block 1 quad of this lane
-        epilogue_vals(p, flags, m, n, q0, v0, aq0);
-        epilogue_vals(p, flags, m, n + 16, q1, v1, aq1);
+        epilogue_vals(p, flags, m, n, q0, v0, aq0, bq0);
+        epilogue_vals(p, flags, m, n + 16, q1, v1, aq1, bq1);
     } else {
-        epilogue_vals(p, flags, m, n, q0, v0);
-        epilogue_vals(p, flags, m, n + 16, q1, v1);
+        epilogue_vals(p, flags, m, n, q0, v0, nullptr, bq0);
+        epilogue_vals(p, flags, m, n + 16, q1, v1, nullptr, bq1);
     }
     if (cs0) {
 #pragma unroll
@@ -421,6 +432,7 @@ typedef __attribute__((address_space(3))) void* g2_lptr;
 template <int NFN, int EPI = -1>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     constexpr int BN = 64 * NFN;
+    constexpr bool PF_ACROSS = !(EPI >= 0 && (EPI & MXL_GEMM_BIAS));     // fragment prefetch across tile boundaries
     constexpr int WN = 4, WM = 2;                           // wave grid: 2 x 4 waves of 128 x BN/4
     constexpr int FM = 16 / WM, FN = BN / 16 / WN;          // 16 x 16 fragments per wave: 8 rows x NFN columns
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -442,6 +454,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     // lane -> row l >> 2, 16-byte slot l & 3); the slot holds k-chunk (l & 3) ^ g2_swz((row >> 2) & 3) = (l & 3) ^ g2_swz(l >> 4).
     // With BN = 192 the B image has 12 row groups: waves 4..7 issue three DMAs per step instead of four, and count their
     // waits accordingly (`per_step`, wave-uniform).
+    // LDS-DMA as buffer_load ... lds, not global_load_lds: hipcc's s_waitcnt pass books a global_load_lds as a FLAT access that
+    // touches both memory and LDS ("pending flat"), and while one is in flight EVERY wait it places for a register loaded from
+    // memory is s_waitcnt vmcnt(0).  The epilogue's bias / aux loads then each drained the whole queue -- the next tile's
+    // prefetched stages and, because stores count in vmcnt, every store issued so far: 258 (bias) / 358 (aux) full drains per tile
+    // in the ISA.  The MUBUF form is booked as an ordinary vector-memory access and those waits come out counted.
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, -1, 0x00020000);
     unsigned ga[2], gb[2];          // element offsets of this lane's source rows (+ k-chunk): 32 bits (host check)
     int gi = 0, i_t = 0, i_tile = bid;
     auto set_ptrs = [&](int tile) {
@@ -460,9 +479,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         const int k0 = i_t << 5;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((g2_gptr)(p.A + (ga[i] + k0)), (g2_lptr)(st + (8 * i + wid) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (g2_lptr)(st + (8 * i + wid) * 1024), 16, (int)((ga[i] + k0) * 2u), 0, 0, 0);
             if (NFN == 4 || i == 0 || wid < 4)
-                __builtin_amdgcn_global_load_lds((g2_gptr)(p.B + (gb[i] + k0)), (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (g2_lptr)(st + G2_OP_BYTES + (8 * i + wid) * 1024), 16,
+                                                         (int)((gb[i] + k0) * 2u), 0, 0, 0);
         }
         gi++;
         if (++i_t == nk) {
@@ -502,7 +522,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
                     bf16x8 (&nb)[FN]) {
         const bool issued = gi < S;
         if (issued) issue_next();
-        if (g + 1 < S) frags(g + 1, na, nb);
+        // (with a bias epilogue not across a tile boundary: the 48 fragment registers are what the preloaded bias values live in;
+        // the next tile's first fragments are then read after the epilogue)
+        if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < FM; i++)
@@ -549,13 +571,42 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) cs[j][r] = 0.f;
             }
+            // the bias quads of the wave's columns once per tile, and the aux rows one row block ahead: loaded where they are used,
+            // every one of them is the youngest memory operation at its wait -- a full drain (vmcnt(0)) of the stores before it
+            constexpr bool HB = EPI >= 0 && (EPI & MXL_GEMM_BIAS) && !(FN & 1);
+            // the aux rows one row block ahead, from the third row block on (the first two are loaded where they are used: with all
+            // 128 accumulators still live there is no room for the 8 extra registers, and the spills' own waits cost more than the
+            // drains they replace: 832 -> 1089 us at the C3 shape)
+            // -- and even so hipcc spills (46-124 scratch operations in the aux instantiations).  Off: the code stays for a compiler that
+            // places it.
+            constexpr bool HA = false && EPI >= 0 && (EPI & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && !(FN & 1);
+            float bq[HB ? FN : 1][4];
+            if (HB) {
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bq[j][r] = b4[r];
+                }
+            }
+            const bool aux_ok = HA && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0;
+            u32x4 axn[HA ? FN / 2 : 1];
 #pragma unroll
             for (int i = 0; i < FM; i++) {
                 const int m = m0 + wr * (FM * 16) + i * 16 + (l & 15);
+                u32x4 axc[HA ? FN / 2 : 1];
+                if (aux_ok) {
+#pragma unroll
+                    for (int j = 0; j + 1 < FN; j += 2) {
+                        axc[j / 2] = i >= 2 ? axn[j / 2] : pair_aux_load(p, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l);
+                        if (i >= 1 && i + 1 < FM) axn[j / 2] = pair_aux_load(p, m + 16, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2)
                     epilogue_pair_bf16(p, flags & ~GEMM_COLSUM_BIT, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1],
-                                       CS ? cs[CS ? j : 0] : nullptr, CS ? cs[CS ? j + 1 : 0] : nullptr);
+                                       CS ? cs[CS ? j : 0] : nullptr, CS ? cs[CS ? j + 1 : 0] : nullptr,
+                                       aux_ok, axc[HA ? j / 2 : 0], HB ? bq[HB ? j : 0] : nullptr, HB ? bq[HB ? j + 1 : 0] : nullptr);
                 if ((FN & 1) && !(i & 1))
                     epilogue_rowpair_bf16(p, flags, m, n0 + wc * (FN * 16) + (FN - 1) * 16 + (l >> 4) * 4, l, acc[i][FN - 1],
                                           acc[(i + 1) % FM][FN - 1]);
@@ -567,9 +618,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
                 for (int j = 0; j < FN; j++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
+                        // all-reduce over the 16-lane row by rotations (v_add_f32 with a DPP row_ror operand: no LDS traffic)
                         float v = cs[j][r];
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
                         cs[j][r] = v;
                     }
                 if ((l & 15) == 0) {
@@ -591,6 +645,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
                     epilogue_quad(p, flags, m, n, acc[i][j]);
                 }
             }
+        }
+        if (!PF_ACROSS && g < S) {          // first fragments of the next tile (their stage landed with the last step's drain)
+            frags(g, fa0, fb0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
         }
     }
 }
@@ -816,7 +874,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
             if (e != hipSuccess) return (int)e;                                                                                  \
             attr_e = true;                                                                                                       \
         }                                                                                                                        \
-        if (use192) hipLaunchKernelGGL((gemm_nt256_kernel<3, EPI_>), grid, dim3(512), G2_SMEM, s, p);                              \
+        if (use192) hipLaunchKernelGGL((gemm_nt256_kernel<3, EPI_>), grid, dim3(512), G2_SMEM, s, p);                       \
         else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
     } while (0)
         if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
