@@ -40,6 +40,14 @@ const char* mxl_error_string(int code);
 #define MXL_GEMM_DROPOUT        0x10  /* inverted dropout with the (seed, site, m*N+n) keep-mask */
 #define MXL_GEMM_RELU_BWD       0x20  /* C = aux[m][n] > 0 ? acc : 0  (backward through relu+dropout) */
 #define MXL_GEMM_ADD_AUX        0x40  /* C = epilogue(acc) + aux[m][n]  (residual add after bias/dropout)  */
+/* The relu (+dropout) mask of C as bits instead of the bf16 activations, for the backward through CoreNet.1 / CoreNet.2:
+ *   MXL_GEMM_SAVE_RELU_MASK  (with BIAS | RELU [| DROPOUT]): also writes, through `aux`, one bit per output element (> 0)
+ *   MXL_GEMM_RELU_BWD_BITS   C = bit ? alpha * acc : 0, bits read through `aux` (the buffer a SAVE call of the same M, N filled)
+ * The bits are in the large-tile kernel's accumulator layout (opaque; mxl_gemm_relu_mask_bytes(M, N) bytes, 0 = these M, N do not
+ * take that kernel: use MXL_GEMM_RELU_BWD with the activations).  Calls that cannot honour the flags return MXL_EUNSUPPORTED. */
+#define MXL_GEMM_SAVE_RELU_MASK 0x100
+#define MXL_GEMM_RELU_BWD_BITS  0x200
+size_t mxl_gemm_relu_mask_bytes(int M, int N);
 int mxl_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                   int transA, int transB, int flags, float alpha, const float* bias,
                   const void* aux, int ldaux, int ksplits,

@@ -37,6 +37,13 @@ if hasattr(ops.lib(), 'mxl_gemm_bf16_colsum'):
     cs = torch.zeros(F, device=dev)
     rows.append(('ffn2 dX mask + colsum   ', t(lambda i: ops.gemm(dy[i % NB], W2t, dF[i % NB], N, F, d, flags=ops.GEMM_RELU_BWD, aux=a[i % NB], alpha=1.1,
                                                                  colsum=cs))))
+if hasattr(ops, 'GEMM_RELU_BWD_BITS') and ops.gemm_relu_mask_bytes(N, F):
+    bits = torch.zeros(ops.gemm_relu_mask_bytes(N, F), device=dev, dtype=torch.uint8)
+    rows.append(('ffn1 fwd b+r+d +savebits', t(lambda i: ops.gemm(x[i % NB], W1, a[i % NB], N, F, d, flags=ops.GEMM_BIAS | ops.GEMM_RELU | ops.GEMM_DROPOUT |
+                                                                 ops.GEMM_SAVE_RELU_MASK, aux=bits, bias=b1, drop_p=0.1, seed=5, site=3))))
+    rows.append(('ffn2 dX mask bits       ', t(lambda i: ops.gemm(dy[i % NB], W2t, dF[i % NB], N, F, d, flags=ops.GEMM_RELU_BWD_BITS, aux=bits, alpha=1.1))))
+    rows.append(('ffn2 dX bits + colsum   ', t(lambda i: ops.gemm(dy[i % NB], W2t, dF[i % NB], N, F, d, flags=ops.GEMM_RELU_BWD_BITS, aux=bits, alpha=1.1,
+                                                                 colsum=cs))))
 rows.append(('ffn2 dX residual add    ', t(lambda i: ops.gemm(dy[i % NB], W2t, dF[i % NB], N, F, d, flags=ops.GEMM_ADD_AUX, aux=a[i % NB]))))
 W2 = (torch.randn(d, F, device=dev) * 0.05).bfloat16(); b2 = torch.randn(d, device=dev)
 y = [torch.empty(N, d, device=dev, dtype=torch.bfloat16) for _ in range(NB)]

@@ -39,6 +39,9 @@ struct GemmP {
     float* colsum;         // [N] f32 or null: += column sums of the epilogue's values (gemm_nt256_kernel, EPI & GEMM_COLSUM_BIT)
 };
 constexpr int GEMM_COLSUM_BIT = 0x80;      // internal epilogue bit (not a public flag): see mxl_gemm_bf16_colsum
+// MXL_GEMM_SAVE_RELU_MASK (0x100) / MXL_GEMM_RELU_BWD_BITS (0x200): the relu(+dropout) mask as 128 bits per lane and tile, in the
+// large-tile kernel's own accumulator layout -- written by the forward epilogue, read back by ONE 16-byte load per lane and tile in
+// the backward one (the bf16 activations as mask cost two dependent loads per row block: 16 serialized round trips per tile).
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -226,8 +229,17 @@ __device__ __forceinline__ u32x4 pair_aux_load(const GemmP& p, const int m, cons
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int flags, const int m, const int n, const int l,
                                                    const f32x4 q0, const f32x4 q1, float* cs0 = nullptr, float* cs1 = nullptr,
                                                    const bool have_ax = false, const u32x4 axv = u32x4{0u, 0u, 0u, 0u},
-                                                   const float* bq0 = nullptr, const float* bq1 = nullptr) {
+                                                   const float* bq0 = nullptr, const float* bq1 = nullptr,
+                                                   const int mask_mode = 0, uint32_t* mbits = nullptr, const int mshift = 0) {
     float v0[4], v1[4];
+    if (mask_mode == 2) {        // relu-backward from the saved bits: bits mshift .. mshift + 7 of *mbits belong to this pair
+        const uint32_t b = *mbits >> mshift;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v0[r] = (b >> r) & 1u ? q0[r] * p.alpha : 0.f;
+            v1[r] = (b >> (4 + r)) & 1u ? q1[r] * p.alpha : 0.f;
+        }
+    } else
     if ((flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) {
         // the aux operand the same way round: one 16-byte load per lane at the address the store below uses (8 consecutive
         // columns of one block), then lanes l and l ^ 16 trade halves so that each holds the aux of its own two quads
@@ -240,6 +252,12 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmP& p, const int fla
     } else {
         epilogue_vals(p, flags, m, n, q0, v0, nullptr, bq0);
         epilogue_vals(p, flags, m, n + 16, q1, v1, nullptr, bq1);
+    }
+    if (mask_mode == 1) {        // save: which of the eight outputs are positive (after relu and dropout)
+        uint32_t b = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) b |= (v0[r] > 0.f ? 1u << r : 0u) | (v1[r] > 0.f ? 16u << r : 0u);
+        *mbits |= b << mshift;
     }
     if (cs0) {
 #pragma unroll
@@ -432,7 +450,7 @@ typedef __attribute__((address_space(3))) void* g2_lptr;
 template <int NFN, int EPI = -1>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     constexpr int BN = 64 * NFN;
-    constexpr bool PF_ACROSS = !(EPI >= 0 && (EPI & MXL_GEMM_BIAS));     // fragment prefetch across tile boundaries
+    constexpr bool PF_ACROSS = !(EPI >= 0 && (EPI & (MXL_GEMM_DROPOUT | 0x100)));     // fragment prefetch across tile boundaries (not beside the register-hungry dropout / mask-saving epilogues)
     constexpr int WN = 4, WM = 2;                           // wave grid: 2 x 4 waves of 128 x BN/4
     constexpr int FM = 16 / WM, FN = BN / 16 / WN;          // 16 x 16 fragments per wave: 8 rows x NFN columns
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -543,14 +561,33 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         g++;
     };
 
-    const int flags = EPI >= 0 ? EPI : p.flags;
-    if (EPI == 0) p.alpha = 1.f;
+    // compile-time BIAS variants (launched with alpha == 1 only): the bias is the accumulators' START VALUE -- its loads have the
+    // whole K loop to arrive and the epilogue carries neither the 16 bias registers nor their waits (loaded in the epilogue, every
+    // bias load was the youngest memory operation at its wait: a drain of all the stores before it, 258 per tile in the ISA)
+    constexpr bool BIAS_INIT = EPI >= 0 && (EPI & MXL_GEMM_BIAS);
+    const int flags = EPI >= 0 ? (BIAS_INIT ? EPI & ~MXL_GEMM_BIAS : EPI) : p.flags;
+    if (EPI == 0 || BIAS_INIT) p.alpha = 1.f;
 #pragma unroll 1
     for (int tile = bid; tile < nwg; tile += G) {
+        if (BIAS_INIT) {
+            const int nb0 = (tile % p.tiles_n) * BN + wc * (FN * 16) + (l >> 4) * 4;
 #pragma unroll
-        for (int i = 0; i < FM; i++)
+            for (int j = 0; j < FN; j++) {
+                f32x4 b4;
+                const int n = nb0 + j * 16;
+                if (n + 3 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else
 #pragma unroll
-            for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int r = 0; r < 4; r++) b4[r] = n + r < p.N ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; i++) acc[i][j] = b4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+                for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll 1
         for (int t = 0; t < nk; t += 2) {
             step(t == 0 && tile != bid, false, fa0, fb0, fa1, fb1);
@@ -571,23 +608,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) cs[j][r] = 0.f;
             }
-            // the bias quads of the wave's columns once per tile, and the aux rows one row block ahead: loaded where they are used,
-            // every one of them is the youngest memory operation at its wait -- a full drain (vmcnt(0)) of the stores before it
-            constexpr bool HB = EPI >= 0 && (EPI & MXL_GEMM_BIAS) && !(FN & 1);
             // the aux rows one row block ahead, from the third row block on (the first two are loaded where they are used: with all
             // 128 accumulators still live there is no room for the 8 extra registers, and the spills' own waits cost more than the
             // drains they replace: 832 -> 1089 us at the C3 shape)
             // -- and even so hipcc spills (46-124 scratch operations in the aux instantiations).  Off: the code stays for a compiler that
             // places it.
             constexpr bool HA = false && EPI >= 0 && (EPI & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) && !(FN & 1);
-            float bq[HB ? FN : 1][4];
-            if (HB) {
-#pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) bq[j][r] = b4[r];
-                }
+            constexpr int MM = (EPI >= 0 && (EPI & 0x100)) ? 1 : (EPI >= 0 && (EPI & 0x200)) ? 2 : 0;      // relu-mask bits: save / use
+            uint32_t mb[4] = {0u, 0u, 0u, 0u};
+            if (MM == 2) {
+                const u32x4 t4 = *(reinterpret_cast<const u32x4*>(p.aux) + ((size_t)tile * 8 + wid) * 64 + l);
+                mb[0] = t4[0]; mb[1] = t4[1]; mb[2] = t4[2]; mb[3] = t4[3];
             }
             const bool aux_ok = HA && (p.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0;
             u32x4 axn[HA ? FN / 2 : 1];
@@ -604,13 +635,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
                 }
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2)
-                    epilogue_pair_bf16(p, flags & ~GEMM_COLSUM_BIT, m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1],
+                    epilogue_pair_bf16(p, flags & ~(GEMM_COLSUM_BIT | 0x300), m, n0 + wc * (FN * 16) + j * 16 + (l >> 4) * 4, l, acc[i][j], acc[i][j + 1],
                                        CS ? cs[CS ? j : 0] : nullptr, CS ? cs[CS ? j + 1 : 0] : nullptr,
-                                       aux_ok, axc[HA ? j / 2 : 0], HB ? bq[HB ? j : 0] : nullptr, HB ? bq[HB ? j + 1 : 0] : nullptr);
+                                       aux_ok, axc[HA ? j / 2 : 0], nullptr, nullptr,
+                                       MM, &mb[(i * FN / 2 + j / 2) / 4], 8 * ((i * FN / 2 + j / 2) & 3));
                 if ((FN & 1) && !(i & 1))
                     epilogue_rowpair_bf16(p, flags, m, n0 + wc * (FN * 16) + (FN - 1) * 16 + (l >> 4) * 4, l, acc[i][FN - 1],
                                           acc[(i + 1) % FM][FN - 1]);
+                if (MM == 1) __builtin_amdgcn_sched_barrier(0);      // row blocks in order: the dropout epilogue is at the register limit
             }
+            if (MM == 1)       // (address formed here, not held across the row blocks: the epilogue is at the register limit)
+                *(reinterpret_cast<u32x4*>(const_cast<bf16_t*>(p.aux)) + ((size_t)tile * 8 + wid) * 64 + l) = u32x4{mb[0], mb[1], mb[2], mb[3]};
             if (CS) {
                 // the lane's 4 x FN column sums over its 8 row blocks -> over the 16 lanes (rows) that share the columns -> one
                 // atomic per column from each of the two wave rows
@@ -796,6 +831,29 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(GemmP p) {
 
 }  // namespace
 
+static int gemm_n_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    return n_cu;
+}
+// BN = 256 or 192 for the large-tile NT kernel: whichever wastes less of the chip (rounds of one tile per CU x tile width)
+static bool nt256_use192(int M, int N) {
+    const int n_cu = gemm_n_cu();
+    const int tm = (M + 255) / 256;
+    const int t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+    const long long c256 = (long long)((t256 + n_cu - 1) / n_cu) * 256, c192 = (long long)((t192 + n_cu - 1) / n_cu) * 192;
+    return c192 < c256;
+}
+
+extern "C" size_t mxl_gemm_relu_mask_bytes(int M, int N) {
+    if (M <= 0 || N <= 0 || (M % 256) != 0 || (N % 256) != 0 || nt256_use192(M, N)) return 0;
+    return (size_t)(M / 256) * (size_t)(N / 256) * 8 * 64 * 16;       // 128 bits per lane, wave and tile = M * N / 8 bytes
+}
+
 static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int transA, int transB, int flags, float alpha, const float* bias,
                        const void* aux, int ldaux, int ksplits,
@@ -811,6 +869,14 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     MXL_CHECK_ARG(transB ? ldb >= ((N + 7) & ~7) : ldb >= K);
     MXL_CHECK_ARG(ldc >= N);
     if (flags & MXL_GEMM_BIAS) MXL_CHECK_ARG(bias != nullptr);
+    if (flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS)) {
+        MXL_CHECK_ARG(aux != nullptr && ((uintptr_t)aux & 15) == 0 && !(flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)));
+        MXL_CHECK_ARG(!((flags & MXL_GEMM_SAVE_RELU_MASK) && (flags & MXL_GEMM_RELU_BWD_BITS)));
+        if (mxl_gemm_relu_mask_bytes(M, N) == 0 || transA || transB || batch != 1 || ksplits > 1 || (K % 64) != 0 || (ldc & 7) != 0 ||
+            ((uintptr_t)C & 15) != 0 || (flags & (MXL_GEMM_OUT_F32 | MXL_GEMM_OUT_F32_ATOMIC)) || getenv("MXL_GEMM_NO256") ||
+            (long long)M * lda >= (1ll << 31) || (long long)N * ldb >= (1ll << 31))
+            return MXL_EUNSUPPORTED;
+    }
     if (flags & (MXL_GEMM_RELU_BWD | MXL_GEMM_ADD_AUX)) MXL_CHECK_ARG(aux != nullptr && ldaux >= N);
     MXL_CHECK_ARG(!((flags & MXL_GEMM_RELU_BWD) && (flags & MXL_GEMM_ADD_AUX)));
     if (ksplits < 1) ksplits = 1;
@@ -845,19 +911,9 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     if (!transA && !transB && batch == 1 && ksplits == 1 && (K % 64) == 0 && M >= 256 && N >= 192 &&
         (long long)M * lda < (1ll << 31) && (long long)N * ldb < (1ll << 31) &&
         !(flags & MXL_GEMM_OUT_F32_ATOMIC) && !getenv("MXL_GEMM_NO256")) {
-        static bool attr_set = false;
-        static int n_cu = 256;
-        if (!attr_set) {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) == hipSuccess &&
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
-            attr_set = true;
-        }
-        // BN = 256 or 192: whichever wastes less of the chip (rounds of one tile per CU x tile width)
+        const int n_cu = gemm_n_cu();
         const int tm = (M + 255) / 256;
-        const int t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
-        const long long c256 = (long long)((t256 + n_cu - 1) / n_cu) * 256, c192 = (long long)((t192 + n_cu - 1) / n_cu) * 192;
-        const bool use192 = c192 < c256;
+        const bool use192 = nt256_use192(M, N);
         p.tiles_m = tm; p.tiles_n = use192 ? (N + 191) / 192 : (N + 255) / 256;
         const int ntile = p.tiles_m * p.tiles_n;
         dim3 grid(ntile < n_cu ? ntile : n_cu);
@@ -878,9 +934,21 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
     } while (0)
         if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
+        else if (p.alpha != 1.f && (p.flags & MXL_GEMM_BIAS) && !(p.flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS))) MXL_NT256_LAUNCH(-1);
+        else if (p.alpha != 1.f && (p.flags & MXL_GEMM_SAVE_RELU_MASK)) return MXL_EUNSUPPORTED;
         else if (p.flags == MXL_GEMM_BIAS) MXL_NT256_LAUNCH(MXL_GEMM_BIAS);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_SAVE_RELU_MASK))
+            MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_SAVE_RELU_MASK);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_SAVE_RELU_MASK))
+            MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_SAVE_RELU_MASK);
+        else if (p.flags == MXL_GEMM_RELU_BWD_BITS && colsum) {
+            MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD_BITS | GEMM_COLSUM_BIT);
+            *colsum_fused = true;
+        }
+        else if (p.flags == MXL_GEMM_RELU_BWD_BITS) MXL_NT256_LAUNCH(MXL_GEMM_RELU_BWD_BITS);
+        else if (p.flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS)) return MXL_EUNSUPPORTED;
         else if (p.flags == MXL_GEMM_RELU_BWD && colsum && !use192 && (M % 256) == 0 && (N % 256) == 0 && (ldc & 7) == 0 &&
                  ((uintptr_t)C & 15) == 0) {
             // every tile interior (the paired-store epilogue): the column sums of the output ride along (mxl_gemm_bf16_colsum)

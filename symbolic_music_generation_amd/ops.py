@@ -19,6 +19,8 @@ GEMM_RELU = 0x08
 GEMM_DROPOUT = 0x10
 GEMM_RELU_BWD = 0x20
 GEMM_ADD_AUX = 0x40
+GEMM_SAVE_RELU_MASK = 0x100
+GEMM_RELU_BWD_BITS = 0x200
 
 
 def mix_seed(base_seed: int, step: int) -> int:
@@ -81,7 +83,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: i
     ldb = ldb if ldb is not None else b.stride(-2)
     ldc = ldc if ldc is not None else c.stride(-2)
     if aux is not None and ldaux is None:
-        ldaux = aux.stride(-2)
+        ldaux = 0 if flags & (GEMM_SAVE_RELU_MASK | GEMM_RELU_BWD_BITS) else aux.stride(-2)
     if colsum is not None:
         assert ksplits == 1
         check(lib().mxl_gemm_bf16_colsum(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), flags,
@@ -92,6 +94,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: i
                               float(alpha), _p(bias), _p(aux), ldaux or 0, ksplits, float(drop_p), seed, site,
                               _stream()), 'mxl_gemm_bf16')
     return c
+
+
+def gemm_relu_mask_bytes(M: int, N: int) -> int:
+    """bytes of the relu-mask bit buffer GEMM_SAVE_RELU_MASK / GEMM_RELU_BWD_BITS use for an (M, N) output; 0 = not available at
+    these sizes (use GEMM_RELU_BWD with the activations)"""
+    if os.environ.get('MXL_NO_RELU_BITS') == '1':
+        return 0
+    return int(lib().mxl_gemm_relu_mask_bytes(int(M), int(N)))
 
 
 def gemm_skinny(a, w, c, M, N, K, *, flags=0, bias=None, lda=None, ldw=None, ldc=None):

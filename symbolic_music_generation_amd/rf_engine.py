@@ -228,6 +228,8 @@ class RFEngine:
         ws.h2 = [torch.empty(N, d, **bf) for _ in range(keep)]
         ws.st2 = [torch.empty(2, N, **f32) for _ in range(keep)]
         ws.a = [torch.empty(N, Fi, **bf) for _ in range(keep)]
+        mb = ops.gemm_relu_mask_bytes(N, Fi) if train else 0      # relu(+dropout) mask bits for the backward GEMM (xl_engine.py)
+        ws.rmask = [torch.empty(mb, device=dev, dtype=torch.uint8) for _ in range(keep)] if mb else None
         ws.cat = torch.empty(N, 2 * d, **bf)
         ws.hcat = torch.empty(N, 2 * d, **bf)
         ws.hcat_d = torch.empty(N, 2 * d, **bf)
@@ -347,7 +349,9 @@ class RFEngine:
                                 self._l(l, 'feed_forward.layer_norm.bias', self.P), ws.h2[s], None, ws.st2[s][0], ws.st2[s][1],
                                 eps=c.layer_norm_eps)
             fl = F.GEMM_BIAS | F.GEMM_RELU | (F.GEMM_DROPOUT if p > 0 else 0)   # relu(drop(x)) == drop(relu(x))
-            ops.gemm(ws.h2[s], self._l(l, 'feed_forward.dense.dense.weight'), ws.a[s], N, Fi, d, flags=fl,
+            save_bits = train and ws.rmask is not None
+            ops.gemm(ws.h2[s], self._l(l, 'feed_forward.dense.dense.weight'), ws.a[s], N, Fi, d,
+                     flags=fl | (F.GEMM_SAVE_RELU_MASK if save_bits else 0), aux=ws.rmask[s] if save_bits else None,
                      bias=self._l(l, 'feed_forward.dense.dense.bias', self.P), drop_p=p, seed=seed, site=self._site(l, 2))
             fl = F.GEMM_BIAS | F.GEMM_ADD_AUX | (F.GEMM_DROPOUT if p > 0 else 0)
             ops.gemm(ws.a[s], self._l(l, 'feed_forward.output.dense.weight'), y2, N, d, Fi, flags=fl,
@@ -429,8 +433,12 @@ class RFEngine:
             ops.colsum(dff, gl(l, 'feed_forward.output.dense.bias'), N, d)
             ops.gemm(dff, ws.a[l], gl(l, 'feed_forward.output.dense.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi))
-            ops.gemm(dff, self.WT[(l, 'ff2')], ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
-                     aux=ws.a[l], alpha=dscale, colsum=gl(l, 'feed_forward.dense.dense.bias'))
+            if ws.rmask is not None:
+                ops.gemm(dff, self.WT[(l, 'ff2')], ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD_BITS,
+                         aux=ws.rmask[l], alpha=dscale, colsum=gl(l, 'feed_forward.dense.dense.bias'))
+            else:
+                ops.gemm(dff, self.WT[(l, 'ff2')], ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
+                         aux=ws.a[l], alpha=dscale, colsum=gl(l, 'feed_forward.dense.dense.bias'))
             ops.gemm(ws.dF, ws.h2[l], gl(l, 'feed_forward.dense.dense.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d))
             ops.gemm(ws.dF, self.WT[(l, 'ff1')], t2, N, d, Fi)

@@ -219,6 +219,11 @@ class XLEngine:
         ws.tmp = torch.empty(N, d, **bf)
         ws.h1 = [torch.empty(N, d, **bf) for _ in range(keep)]
         ws.a = [torch.empty(N, Fi, **bf) for _ in range(keep)]
+        # relu(+dropout) mask of the FFN activations as bits in the GEMM's own tile layout (one 16-byte load per lane and tile in the
+        # backward GEMM's epilogue instead of the bf16 activations row block by row block); None at sizes the large-tile kernel
+        # does not take
+        mb = ops.gemm_relu_mask_bytes(N, Fi) if train else 0
+        ws.rmask = [torch.empty(mb, device=self.dev, dtype=torch.uint8) for _ in range(keep)] if mb else None
         if train:
             ws.z1 = [torch.empty(N, d, **bf) for _ in range(L)]
             ws.z2 = [torch.empty(N, d, **bf) for _ in range(L)]
@@ -310,7 +315,9 @@ class XLEngine:
                                 ws.st1[l][1] if train else None, eps=c.layer_norm_epsilon, drop_p=p, seed=seed,
                                 site=self._site(l, 0))
             fl = F.GEMM_BIAS | F.GEMM_RELU | (F.GEMM_DROPOUT if p > 0 else 0)
-            ops.gemm(ws.h1[s], self._lw(l, 'pos_ff.CoreNet.0.weight'), ws.a[s], N, Fi, d, flags=fl,
+            save_bits = train and ws.rmask is not None
+            ops.gemm(ws.h1[s], self._lw(l, 'pos_ff.CoreNet.0.weight'), ws.a[s], N, Fi, d,
+                     flags=fl | (F.GEMM_SAVE_RELU_MASK if save_bits else 0), aux=ws.rmask[s] if save_bits else None,
                      bias=self._lw(l, 'pos_ff.CoreNet.0.bias', self.P), drop_p=p, seed=seed, site=self._site(l, 1))
             ops.gemm(ws.a[s], self._lw(l, 'pos_ff.CoreNet.3.weight'), ws.tmp, N, d, Fi, flags=F.GEMM_BIAS,
                      bias=self._lw(l, 'pos_ff.CoreNet.3.bias', self.P))
@@ -573,8 +580,12 @@ class XLEngine:
             # FFN2 (its bias gradient = the column sums of dD: accumulated by the LayerNorm backward above)
             ops.gemm(ws.dD, ws.a[l], gw(l, 'pos_ff.CoreNet.3.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi, N))
-            ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
-                     aux=ws.a[l], alpha=dscale, colsum=gw(l, 'pos_ff.CoreNet.0.bias'))
+            if ws.rmask is not None:
+                ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD_BITS,
+                         aux=ws.rmask[l], alpha=dscale, colsum=gw(l, 'pos_ff.CoreNet.0.bias'))
+            else:
+                ops.gemm(ws.dD, self._lwt(l, 'pos_ff.CoreNet.3.weight'), ws.dF, N, Fi, d, flags=F.GEMM_RELU_BWD,
+                         aux=ws.a[l], alpha=dscale, colsum=gw(l, 'pos_ff.CoreNet.0.bias'))
             # FFN1 (its bias gradient = the column sums of dF: formed in the epilogue of the GEMM above)
             ops.gemm(ws.dF, ws.h1[l], gw(l, 'pos_ff.CoreNet.0.weight'), Fi, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(Fi, d, N))

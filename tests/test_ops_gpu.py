@@ -608,3 +608,41 @@ def test_gemm_relu_bwd_with_fused_column_sums(dev, M, N, K):
     err = (cs - want).abs()
     assert (err <= bound).all(), (err / bound).max().item()
     assert err.max().item() <= 0.05 * bound.max().item() or (M % 256) != 0      # in practice: random-walk, not worst case
+
+
+@pytest.mark.parametrize('M,N,K,p', [(16384, 3072, 256, 0.1), (65536, 768, 128, 0.0)])
+def test_gemm_relu_mask_bits_round_trip(dev, M, N, K, p):
+    """MXL_GEMM_SAVE_RELU_MASK / MXL_GEMM_RELU_BWD_BITS: the forward GEMM's bit mask drives the backward GEMM to the same result,
+    bit for bit, as MXL_GEMM_RELU_BWD on the bf16 activations (with and without the fused column sums); sizes outside the
+    large-tile kernel report 0 bytes and the flags are refused"""
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd._lib import MusicXLError
+    torch.manual_seed(22)
+    nbytes = ops.gemm_relu_mask_bytes(M, N)
+    assert nbytes == M * N // 8
+    x = torch.randn(M, K, device=dev).bfloat16()
+    w1 = (torch.randn(N, K, device=dev) * 0.05).bfloat16(); b1 = torch.randn(N, device=dev) * 0.1
+    fl = ops.GEMM_BIAS | ops.GEMM_RELU | (ops.GEMM_DROPOUT if p > 0 else 0)
+    a0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); a1 = torch.empty_like(a0)
+    bits = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+    ops.gemm(x, w1, a0, M, N, K, flags=fl, bias=b1, drop_p=p, seed=9, site=2)
+    ops.gemm(x, w1, a1, M, N, K, flags=fl | ops.GEMM_SAVE_RELU_MASK, aux=bits, bias=b1, drop_p=p, seed=9, site=2)
+    assert torch.equal(a0, a1)
+    # every output element has its bit: population count == number of positive activations
+    pop = sum(int(((bits >> k) & 1).sum().item()) for k in range(8))
+    assert pop == int((a0.float() > 0).sum().item())
+    dy = torch.randn(M, 256, device=dev).bfloat16()
+    w2t = (torch.randn(N, 256, device=dev) * 0.05).bfloat16()
+    d0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); d1 = torch.empty_like(d0); d2 = torch.empty_like(d0)
+    ops.gemm(dy, w2t, d0, M, N, 256, flags=ops.GEMM_RELU_BWD, aux=a0, alpha=1.0 / (1.0 - p))
+    ops.gemm(dy, w2t, d1, M, N, 256, flags=ops.GEMM_RELU_BWD_BITS, aux=bits, alpha=1.0 / (1.0 - p))
+    assert torch.equal(d0, d1)
+    cs0 = torch.zeros(N, device=dev); cs2 = torch.zeros(N, device=dev)
+    ops.colsum(d0, cs0, M, N)
+    ops.gemm(dy, w2t, d2, M, N, 256, flags=ops.GEMM_RELU_BWD_BITS, aux=bits, alpha=1.0 / (1.0 - p), colsum=cs2)
+    assert torch.equal(d0, d2)
+    assert (cs0 - cs2).abs().max().item() <= d0.float().abs().sum(0).max().item() * 2.0 ** -9
+    # sizes the large-tile kernel does not take with 256-wide tiles (ragged, or fewer tiles than one round of the chip at 192)
+    assert ops.gemm_relu_mask_bytes(1000, 3072) == 0 and ops.gemm_relu_mask_bytes(2048, 200) == 0 and ops.gemm_relu_mask_bytes(2048, 3072) == 0
+    with pytest.raises(MusicXLError):
+        ops.gemm(x[:1000], w1, a1[:1000], 1000, N, K, flags=fl | ops.GEMM_SAVE_RELU_MASK, aux=bits, bias=b1, drop_p=p, seed=9, site=2)
