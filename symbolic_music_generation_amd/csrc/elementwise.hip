@@ -82,6 +82,17 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
     const int lane = threadIdx.x & 63;
     const int chunks = d >> 3;
     float v[NCH][8];
+    // gamma / beta requested with the row, not after the two reductions (and after the mean / rstd stores, which the compiler
+    // cannot move them across): at decode sizes (64 rows) the launch is one dependent chain and this removes a round trip from it
+    f32x4 gq[NCH][2], bq[NCH][2];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            gq[i][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8); gq[i][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+            bq[i][0] = *reinterpret_cast<const f32x4*>(beta + c * 8); bq[i][1] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const bf16_t* x, const 
         if (c < chunks) {
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gq[i][j >> 2][j & 3] + bq[i][j >> 2][j & 3];
             u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
             *reinterpret_cast<u32x4*>(y + (size_t)row * d + c * 8) = ov;
             if (z) {
@@ -145,6 +156,15 @@ __global__ __launch_bounds__(256) void ln_res_partial_fwd_kernel(const float* sl
     const int lane = threadIdx.x & 63;
     const int chunks = d >> 3;
     float v[NCH][8];
+    f32x4 gq[NCH][2], bq[NCH][2];          // requested with the row (see ln_res_fwd_kernel)
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            gq[i][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8); gq[i][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+            bq[i][0] = *reinterpret_cast<const f32x4*>(beta + c * 8); bq[i][1] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_res_partial_fwd_kernel(const float* sl
         if (c < chunks) {
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * gq[i][j >> 2][j & 3] + bq[i][j >> 2][j & 3];
             u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
             *reinterpret_cast<u32x4*>(y + (size_t)row * d + c * 8) = ov;
         }
@@ -552,6 +572,7 @@ extern "C" int mxl_ln_residual_fwd(const void* x, const void* res, const float* 
                                    void* z, float* mean, float* rstd, int N, int d, float eps, float drop_p,
                                    unsigned long long seed, unsigned site, void* stream) {
     MXL_CHECK_ARG(x && gamma && beta && y && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
+    MXL_CHECK_ARG(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);      // read as 16-byte vectors
     MXL_CHECK_ARG(drop_p <= 0.f || (unsigned long long)N * d <= 0xffffffffull);      // the dropout mask is indexed in 32 bits
     const auto kfn = d <= 512 ? ln_res_fwd_kernel<1> : d <= 1024 ? ln_res_fwd_kernel<2> : ln_res_fwd_kernel<LN_MAXCH>;
     hipLaunchKernelGGL(kfn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
@@ -606,6 +627,7 @@ extern "C" int mxl_ln_residual_fwd_partial(const float* slabs, int KS, long long
                                            const float* gamma, const float* beta, void* y, int N, int d, float eps, void* stream) {
     MXL_CHECK_ARG(slabs && res && gamma && beta && y && KS >= 1 && N > 0 && d > 0 && (d % 8) == 0 && d <= 64 * 8 * LN_MAXCH);
     MXL_CHECK_ARG(slab_stride >= (long long)N * d && ((uintptr_t)slabs % 16) == 0 && (slab_stride % 4) == 0);
+    MXL_CHECK_ARG(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
     const auto kfn = d <= 512 ? ln_res_partial_fwd_kernel<1> : d <= 1024 ? ln_res_partial_fwd_kernel<2> : ln_res_partial_fwd_kernel<LN_MAXCH>;
     hipLaunchKernelGGL(kfn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, slabs, KS, slab_stride, bias, (const bf16_t*)res,
                        gamma, beta, (bf16_t*)y, N, d, eps);

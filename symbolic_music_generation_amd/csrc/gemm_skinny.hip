@@ -36,6 +36,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int n = n0 + li;
+    // epilogue operands requested up front (a thread's two outputs share one column): loaded after the reduction they would add one
+    // more dependent memory round trip to a launch that is nothing but a dependent chain
+    const int ecol = n0 + (tid & 15);
+    const float ebias = ((p.flags & MXL_GEMM_BIAS) && ecol < p.N) ? p.bias[ecol] : 0.f;
+    const int t_now = p.kc ? *p.t_dev : 0;
+    const float errb = (p.kc && n0 < p.d) ? p.rrb[n0 + (tid & 15)] : 0.f;          // (q third only; its 16 columns are < d)
     const bf16_t* wrow = p.W + (size_t)(n < p.N ? n : 0) * p.ldw;
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 2
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
     if (p.kc) {
         kv_part = n0 / p.d;
         kv_col0 = n0 - kv_part * p.d;
-        const int hh = kv_col0 / p.dh, e0 = kv_col0 - hh * p.dh, slot = (*p.t_dev) % p.Mring;
+        const int hh = kv_col0 / p.dh, e0 = kv_col0 - hh * p.dh, slot = t_now % p.Mring;
         kv_bstride = (size_t)(p.d / p.dh) * p.Mring * p.dh;
         kv_off = ((size_t)hh * p.Mring + slot) * p.dh + e0;
     }
@@ -83,13 +89,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkP p) {
         const int m = i >> 4, nn = n0 + (i & 15);
         if (m < p.M && nn < p.N) {
             float v = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
-            if (p.flags & MXL_GEMM_BIAS) v += p.bias[nn];
+            if (p.flags & MXL_GEMM_BIAS) v += ebias;
             if (p.flags & MXL_GEMM_RELU) v = fmaxf(v, 0.f);
             if (p.flags & MXL_GEMM_OUT_F32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nn] = v;
             else reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(v);
             if (p.kc) {                                        // workgroup-uniform: its 16 columns sit in one third and one head
                 const bf16_t vb = f2bf(v);                     // the rings and qr see the value the qkv buffer holds
-                if (kv_part == 0) p.qr[(size_t)m * p.d + kv_col0 + (i & 15)] = f2bf(bf2f(vb) + p.rrb[kv_col0 + (i & 15)]);
+                if (kv_part == 0) p.qr[(size_t)m * p.d + kv_col0 + (i & 15)] = f2bf(bf2f(vb) + errb);
                 else (kv_part == 1 ? p.kc : p.vc)[(size_t)m * kv_bstride + kv_off + (i & 15)] = vb;
             }
         }
