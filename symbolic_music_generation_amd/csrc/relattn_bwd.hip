@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
     // staging: thread t < 32*CH handles one 16-byte chunk of each of the three tiles
     u32x4 tq, tdo, rr;
     float tl = 0.f, tdl = 0.f;
+    bool tok = false;
     auto load_q = [&](int it) {
         const int I = it * QT;
         const int row = tid / G::CH, ch = tid % G::CH;
@@ -1254,10 +1255,14 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
         tq = ok ? *reinterpret_cast<const u32x4*>(qbase + (size_t)(I + row) * p.q_rs + ch * 8) : z;
         tdo = ok ? *reinterpret_cast<const u32x4*>(dobase + (size_t)(I + row) * p.o_rs + ch * 8) : z;
         if (tid < QT) {
-            const bool ok2 = I + tid < T;
-            const size_t sidx = ((size_t)b * p.H + h) * T + (ok2 ? I + tid : 0);
-            tl = ok2 ? -p.lse[sidx] * LOG2E : 0.f;
-            tdl = ok2 ? -p.scale * p.delta[sidx] : 0.f;
+            // RAW values, from a clamped index; scaled and masked when they are stored (store_q).  Scaling them here puts an
+            // s_waitcnt vmcnt(0) right behind the loads -- at the top of every tile wave 0 then waited for these AND for the
+            // tile's Q / dO rows it had just requested (the wait is a drain), and the other waves waited for wave 0 at the barrier:
+            // the loads' latency was exposed once per tile instead of hidden behind the tile's products
+            const size_t sidx = ((size_t)b * p.H + h) * T + min(I + tid, T - 1);
+            tl = p.lse[sidx];
+            tdl = p.delta[sidx];
+            tok = I + tid < T;
         }
     };
     auto store_q = [&](int buf) {
@@ -1285,7 +1290,7 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_dkv_kernel(BwdP p) {
             *reinterpret_cast<u32x4*>(sQr + G::koff(row, ch)) = rq;
             *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = wd;
         }
-        if (tid < QT) { sLse[tid] = tl; sDl[tid] = tdl; }
+        if (tid < QT) { sLse[tid] = tok ? -tl * LOG2E : 0.f; sDl[tid] = tok ? -p.scale * tdl : 0.f; }
     };
     // 32 Rd rows [dbase, dbase+32)
     auto load_r = [&](int dbase) {
