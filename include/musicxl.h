@@ -137,6 +137,21 @@ int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const void* v, const
                               void* dk, void* dv, void* dg, float* d_r_w_bias, int B, int T, int H, int dh, int M, int Kc,
                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
                               long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream);
+/* The same pair with the forward's help: mxl_relattn_fwd_phantom also writes, for the distance blocks whose score gradient
+ * mxl_relattn_bwd_sparse_dg does not store,  oph[b,i,h,:] = sum_d 2^(G'[i,d] - mph[b,h,i]) * rd[d,h,:]  (G' = the positional score in
+ * log2 units; oph (B,T,H*dh) bf16 with out's strides, mph (B,H,T) f32).  Those blocks' contribution to dq is then the elementwise
+ *   -scale * delta_i * 2^(mph_i - lse_i * log2 e) * oph_i
+ * and mxl_relattn_bwd_sparse_dg_oph does not walk them (M % 256 == 0, T % 32 == 0).  mxl_relattn_drd_recompute is unchanged. */
+int mxl_relattn_fwd_phantom(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                            const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int B, int T, int H,
+                            int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                            long long o_bs, int o_rs, float scale, void* stream);
+int mxl_relattn_bwd_sparse_dg_oph(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                  const float* r_r_bias, const void* out, const void* dout, const float* lse,
+                                  float* delta, void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias,
+                                  const void* oph, const float* mph, int B, int T, int H, int dh, int M, int Kc,
+                                  long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                                  long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream);
 int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs,
                               int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, float* d_r_w_bias_fix,
                               const float* lse, const float* delta, float scale, int Kc, void* stream);

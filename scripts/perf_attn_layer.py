@@ -21,14 +21,17 @@ dg = torch.empty(CH, H, T, M, device=dev, dtype=torch.bfloat16)
 a, c = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
 d_rd = torch.zeros(M, d, device=dev); qr = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+OPH = bool(os.environ.get('OPH'))          # the forward's phantom value-sum for the backward (training path of the engines)
+oph = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16) if OPH else None
+mph = torch.empty(B, H, T, device=dev) if OPH else None
 if os.environ.get('KT'):
     ops.ktime_enable(True)
 for it in range(int(os.environ.get('ITERS', 3))):
     ev[0].record()
-    ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, **st)
+    ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, oph=oph, mph=mph, **st)
     ev[1].record()
     fin = ops.relattn_bwd(q, k, v, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc-T:, :d], dqkv[:, :, d:2*d], dqkv[:, :, 2*d:],
-                          dg, a, c, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, d_rd=d_rd, qr_buf=qr, defer_drd=True, **st)
+                          dg, a, c, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, d_rd=d_rd, qr_buf=qr, defer_drd=True, oph=oph, mph=mph, **st)
     ev[2].record()
     fin()
     ev[3].record()

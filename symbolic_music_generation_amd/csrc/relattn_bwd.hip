@@ -57,6 +57,10 @@ struct BwdP {
     // 8-wave query-owner kernel only: do not store dG for 32-distance blocks whose 256-distance block lies entirely on phantom
     // distances of the wave's 32 queries -- mxl_relattn_drd_recompute rebuilds exactly those cells itself
     int dg_skip_phantom;
+    // with dg_skip_phantom: the forward's phantom value-sum over exactly those blocks (mxl_relattn_fwd_phantom); the query-owner
+    // kernel then does not visit them at all -- their dQr is -scale * delta_i * 2^(mph_i - lse2_i) * oph_i, added in its epilogue
+    const bf16_t* oph;
+    const float* mph;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -790,15 +794,19 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
         kt_start = pz / KT;
         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
         load_r(i0 - pz);
+        // with the forward's phantom value-sum the walk ends with the 256-distance block that holds the last query's first
+        // phantom distance: everything above it is an all-phantom block for every wave of the workgroup
+        const int db_end = p.oph ? min(M - 1, (i0 + QB - 1 - pz) | 255) : M - 1;
 #pragma unroll 1
-        for (int db = i0 - pz; db <= M - 1; db += 64) {
+        for (int db = i0 - pz; db <= db_end; db += 64) {
             store_r(db);
             __syncthreads();
-            if (db + 64 <= M - 1) load_r(db + 64);
+            if (db + 64 <= db_end) load_r(db + 64);
             if (iw0 < T) {
                 for (int gb = kbw; gb == kbw; gb += 2) {                  // each wave of the pair takes one 32-distance block
                     const int dblk = db + 32 * gb;
                     if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform
+                    if (p.oph && (dblk & ~255) > iw0 + 31 - pz) continue;  // all-phantom 256-block: the epilogue's oph term
                     f32x16 g = c_lse;
                     const char* rb = sR + (dblk & 255) * G::ROWB;      // ring rows of this block: (dblk & 255) + 0..31, no wrap inside
 #pragma unroll
@@ -1103,6 +1111,25 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_dq8_kernel(BwdP p) {
     }
 
     STAMP_FLUSH
+    // ---- the skipped all-phantom blocks: dQr_i += -scale * delta_i * 2^(mph_i - lse2_i) * oph_i (one wave of the pair adds it)
+    if (p.oph && kbw == 0 && qok) {
+        const float f = ndlt * __builtin_amdgcn_exp2f(p.mph[sidx] - lse2);
+        const bf16_t* op = p.oph + (size_t)b * p.o_bs + (size_t)qi * p.o_rs + (size_t)h * DH;
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                if (e0 < DH) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(op + e0);
+                    aw[e][4 * grp] += f * bf2f((bf16_t)(w[0] & 0xffffu));
+                    aw[e][4 * grp + 1] += f * bf2f((bf16_t)(w[0] >> 16));
+                    aw[e][4 * grp + 2] += f * bf2f((bf16_t)(w[1] & 0xffffu));
+                    aw[e][4 * grp + 3] += f * bf2f((bf16_t)(w[1] >> 16));
+                }
+            }
+        }
+    }
     // ---- epilogue.  The column sums of the wave's accumulator over its queries are its part of d(r_w_bias) + d(r_r_bias): they
     // go to d_rwb; the dRd kernel moves the r_r_bias part over (colsum(dG) . Rd).  dq = the two waves' accumulators, summed
     // through LDS (the K / V images are dead now).
@@ -1785,8 +1812,9 @@ static int relattn_bwd_impl(const void* q, const void* k, const void* v, const v
                             void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias, float* d_r_r_bias, int B, int T,
                             int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                             long long o_bs, int o_rs, long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs,
-                            float scale, int skip_phantom_dg, void* stream) {
+                            float scale, int skip_phantom_dg, void* stream, const void* oph = nullptr, const float* mph = nullptr) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv);
+    if (oph) MXL_CHECK_ARG(skip_phantom_dg && mph && ((uintptr_t)oph % 8) == 0);
     // the skipped cells are rebuilt by mxl_relattn_drd_recompute, which tiles 256 distances x 32 queries and needs d r_r_bias
     // left to it (the 8-wave query-owner kernel)
     if (skip_phantom_dg) MXL_CHECK_ARG(dg && d_r_r_bias == nullptr && dh == 64 && (M % 256) == 0 && (T % 32) == 0);
@@ -1805,6 +1833,7 @@ static int relattn_bwd_impl(const void* q, const void* k, const void* v, const v
     p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dq_rs = dq_rs; p.dkv_rs = dkv_rs;
     p.scale = scale; p.scale_log2e = scale * LOG2E;
     p.dg_skip_phantom = skip_phantom_dg ? 1 : 0;
+    p.oph = (const bf16_t*)oph; p.mph = mph;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_bwd<16>(p, s);
@@ -1842,6 +1871,18 @@ extern "C" int mxl_relattn_bwd_sparse_dg(const void* q, const void* k, const voi
                                          int dkv_rs, float scale, void* stream) {
     return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, nullptr, B, T, H,
                             dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 1, stream);
+}
+
+extern "C" int mxl_relattn_bwd_sparse_dg_oph(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                             const float* r_r_bias, const void* out, const void* dout, const float* lse,
+                                             float* delta, void* dq, void* dk, void* dv, void* dg, float* d_r_w_bias,
+                                             const void* oph, const float* mph, int B, int T, int H, int dh, int M, int Kc,
+                                             long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                                             long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream) {
+    MXL_CHECK_ARG(oph && mph);
+    return relattn_bwd_impl(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_r_w_bias, nullptr, B, T, H,
+                            dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale, 1, stream,
+                            oph, mph);
 }
 
 static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,

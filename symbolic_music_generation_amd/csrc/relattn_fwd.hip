@@ -33,6 +33,13 @@ struct RelAttnP {
     long long q_bs, kv_bs, o_bs;
     int q_rs, kv_rs, rd_rs, o_rs;
     float scale_log2e;
+    // training with zero memories (mxl_relattn_fwd_phantom): for the distance blocks whose score gradient the backward does not
+    // store (all-phantom 256-distance blocks, see mxl_relattn_bwd_sparse_dg) the forward also accumulates
+    //   oph[b,i,h,:] = sum_d 2^(G'[i,d] - mph[b,h,i]) * Rd[d,h,:]      (G' = the positional score in log2 units)
+    // -- the "output" of those keys if their values were the Rd rows.  Their dQr is then  -scale * delta_i * 2^(mph - lse2) * oph_i,
+    // an elementwise product in the query-owner backward, instead of a second pass over G, exp and an MFMA product there.
+    bf16_t* oph;           // (B, T, H*dh) like out, or null
+    float* mph;            // (B, H, T) like lse
 };
 
 constexpr int QB = 128;      // queries per workgroup
@@ -61,6 +68,7 @@ template <int DH> struct Geo {
         if (DH == 64) return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
         return row * ROWB + (ch << 4);
     }
+    __device__ static __forceinline__ int eoff(int row, int e) { return koff(row, e >> 3) + ((e & 7) << 1); }
     __device__ static __forceinline__ int voff(int row, int byte) {  // V image: [key][VW]
         if (DH == 64) return row * VROWB + (byte ^ (((row >> 1) & 1) << 6));
         return row * VROWB + byte;
@@ -239,6 +247,12 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     // straight from the accumulators, no skew, no K/V traffic.  The tile loop then starts at tile pz.
     const int pz = floordiv(p0, KT) * KT;
     int kt_start = kt_lo;
+    const int tk0 = G::eoff(4 * hh + ((l & 15) >> 2), 16 * ((l >> 4) & 1) + 4 * (l & 3));
+    f32x16 o[EB];          // O^T accumulators; during the phantom loop they hold oph (v = 0 there: O itself stays 0)
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
     if (kt_lo * KT < pz) {
         kt_start = pz / KT;
         const int qi = iw0 + r;
@@ -280,20 +294,81 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
                     if (__any(need)) {
                         const float delta = need ? mx : 0.f;
-                        if (need && !unset) l_run *= __builtin_amdgcn_exp2f(-delta);
+                        const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+                        l_run *= alpha;
                         if (need) m_run = (unset ? 0.f : m_run) + delta;
                         const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
 #pragma unroll
                         for (int j = 0; j < 16; j++) { g[j] -= delta; cinit[j] = neg; }
+                        if (p.oph) {
+#pragma unroll
+                            for (int e = 0; e < EB; e++)
+#pragma unroll
+                                for (int j = 0; j < 16; j++) o[e][j] *= alpha;
+                        }
                     }
                     float rs = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 16; j++) rs += __builtin_amdgcn_exp2f(g[j]);   // exp2(NEG_BIG) = 0 for masked cells
+                    for (int j = 0; j < 16; j++) { g[j] = __builtin_amdgcn_exp2f(g[j]); rs += g[j]; }   // exp2(NEG_BIG) = 0 for masked cells
                     l_run += rs;
+                    // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
+                    if (p.oph && (dblk & ~255) > iw0 + 31 - pz) {
+                        const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
+                        const char* rb = sR + (dblk & 255) * G::ROWB;      // a multiple of 32 rows: + 0..31 does not wrap
+#pragma unroll
+                        for (int st = 0; st < 2; st++) {
+                            const u32x4 pw = {pack2bf(g[8 * st], g[8 * st + 1]), pack2bf(g[8 * st + 2], g[8 * st + 3]),
+                                              pack2bf(g[8 * st + 4], g[8 * st + 5]), pack2bf(g[8 * st + 6], g[8 * st + 7])};
+                            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                            for (int e = 0; e < EB; e++) {
+                                const int dist = dblk + 16 * st + 4 * hh + q4;      // accumulator-permuted k order
+                                const int ecol = 32 * e + 16 * (gq & 1) + 4 * pp;
+                                bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                                if (DH == 64) {
+                                    // one per-lane constant + immediates (relattn_bwd.hip, tk0): the +8 row and the second
+                                    // 32-column half flip swizzle bits that do not depend on the lane for this pattern
+                                    const char* a0 = rb + tk0 + 16 * st * G::ROWB;
+                                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a0 + 64 * e));
+                                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a0 + 8 * G::ROWB + 64 * (1 - e)));
+                                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                } else if (ecol < DH) {
+                                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff(dist & 255, ecol)));
+                                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sR + G::eoff((dist + 8) & 255, ecol)));
+                                    a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                }
+                                o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                                               __builtin_bit_cast(mfma_bf16x8, pf), o[e], 0, 0, 0);
+                            }
+                        }
+                    }
                 }
             }
             __syncthreads();
         }
+    }
+
+    if (p.oph) {           // written for every query (zeros where no block qualified); relative to m_run as it stands now
+        const int qi = iw0 + r;
+        if (qi < T) {
+            bf16_t* op = p.oph + (size_t)b * p.o_bs + (size_t)qi * p.o_rs + (size_t)h * DH;
+#pragma unroll
+            for (int e = 0; e < EB; e++) {
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const int e0 = 32 * e + 8 * grp + 4 * hh;
+                    if (e0 < DH) {
+                        u32x2 w = {pack2bf(o[e][4 * grp], o[e][4 * grp + 1]), pack2bf(o[e][4 * grp + 2], o[e][4 * grp + 3])};
+                        *reinterpret_cast<u32x2*>(op + e0) = w;
+                    }
+                }
+            }
+            if (hh == 0) p.mph[((size_t)b * p.H + h) * T + qi] = (m_run == NEG_BIG) ? 0.f : m_run;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) o[e][j] = 0.f;
     }
 
     // ---- prologue: first tile + its distance window [i0-P0-64, i0-P0+127] (wave w: dlo_w = i0+32w-P0-64, 96 rows)
@@ -310,11 +385,6 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     }
     __syncthreads();
 
-    f32x16 o[EB];
-#pragma unroll
-    for (int e = 0; e < EB; e++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
     bool have_ring = false;
 
 #pragma unroll 1
@@ -504,11 +574,12 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
-                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                               float scale, void* stream) {
+static int relattn_fwd_launch(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                              const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
+                              long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                              float scale, void* oph, float* mph, void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
+    if (oph) MXL_CHECK_ARG(mph && (M % 256) == 0 && (T % 32) == 0 && ((uintptr_t)oph % 8) == 0);
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
     MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 4) == 0);
@@ -520,6 +591,7 @@ extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, cons
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.oph = (bf16_t*)oph; p.mph = mph;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_fwd<16>(p, s);
@@ -527,4 +599,21 @@ extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, cons
         case 64: return launch_fwd<64>(p, s);
         default: return MXL_EUNSUPPORTED;
     }
+}
+
+extern "C" int mxl_relattn_fwd(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
+                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                               float scale, void* stream) {
+    return relattn_fwd_launch(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
+                              o_rs, scale, nullptr, nullptr, stream);
+}
+
+extern "C" int mxl_relattn_fwd_phantom(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                       const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int B, int T, int H,
+                                       int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                                       long long o_bs, int o_rs, float scale, void* stream) {
+    MXL_CHECK_ARG(oph && mph);
+    return relattn_fwd_launch(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
+                              o_rs, scale, oph, mph, stream);
 }

@@ -220,10 +220,23 @@ def mem_update(mem, hid, out):
     return out
 
 
+def phantom_sum_applies(*, T, dh, M, Kc) -> bool:
+    """the shapes at which the forward can hand the backward its phantom value-sum (mxl_relattn_fwd_phantom /
+    mxl_relattn_bwd_sparse_dg_oph): the ones at which relattn_bwd leaves the all-phantom dG blocks unwritten"""
+    return (dh == 64 and T % 32 == 0 and M % 256 == 0 and Kc < M + T and os.environ.get('MXL_NO_DQ8') != '1'
+            and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0' and os.environ.get('MXL_NO_OPH') != '1')
+
+
 def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,
-                o_bs, o_rs, scale=None):
-    """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements."""
+                o_bs, o_rs, scale=None, oph=None, mph=None):
+    """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements.
+    `oph` (like out) / `mph` (B, H, T) f32: also write the phantom value-sum relattn_bwd(..., oph=, mph=) consumes."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    if oph is not None:
+        check(lib().mxl_relattn_fwd_phantom(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), _p(oph),
+                                            _p(mph), B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale),
+                                            _stream()), 'mxl_relattn_fwd_phantom')
+        return out
     check(lib().mxl_relattn_fwd(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), B, T, H, dh,
                                 M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale), _stream()),
           'mxl_relattn_fwd')
@@ -354,7 +367,8 @@ def add_rowbias(x, x_bs, x_rs, bias, out, B, T, n):
 
 def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, dg, d_rwb, d_rrb, *, B, T, H, dh, M,
                 Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs, scale=None,
-                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None, defer_drd: bool = False):
+                d_rd: Optional[torch.Tensor] = None, qr_buf: Optional[torch.Tensor] = None, defer_drd: bool = False,
+                oph: Optional[torch.Tensor] = None, mph: Optional[torch.Tensor] = None):
     """Backward of relattn_fwd.  If `d_rd` (M, H*dh) f32 is given, also contracts dG with (q + r_r_bias):
     d_rd[d, h, :] += sum_{b,i} dG[b,h,i,d] * (q + r_r_bias)[b,i,h,:]   (needs dg and a (B,T,H*dh) bf16 qr_buf).
     When that contraction runs as the streaming kernel (dh = 64, T % 32 == 0, M % 8 == 0) it also produces d_rrb, and the
@@ -371,9 +385,17 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
     # phantom distances (zero memories: k = v = 0) stay out of HBM: the backward leaves their dG blocks unwritten and the dRd
     # contraction rebuilds them from qr, rd, lse and delta (mxl_relattn_bwd_sparse_dg / mxl_relattn_drd_recompute)
     sparse = fused_rrb and M % 256 == 0 and Kc < M + T and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0'
+    assert oph is None or sparse, 'oph / mph are for the shapes phantom_sum_applies() accepts, with d_rd / dg given'
 
     def launch(b0, n):
         sl = slice(b0, b0 + n)
+        if sparse and oph is not None:          # the forward's phantom value-sum: the all-phantom blocks are not walked at all
+            check(lib().mxl_relattn_bwd_sparse_dg_oph(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias),
+                                                      _p(out[sl]), _p(dout[sl]), _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]),
+                                                      _p(dv[sl]), _p(dg), _p(d_rwb), _p(oph[sl]), _p(mph[sl]), n, T, H, dh, M, Kc,
+                                                      q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
+                                                      float(scale), _stream()), 'mxl_relattn_bwd_sparse_dg_oph')
+            return
         if sparse:
             check(lib().mxl_relattn_bwd_sparse_dg(_p(q[sl]), _p(k[sl]), _p(v[sl]), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out[sl]),
                                                   _p(dout[sl]), _p(lse[sl]), _p(delta[sl]), _p(dq[sl]), _p(dk[sl]), _p(dv[sl]),

@@ -216,6 +216,11 @@ class XLEngine:
         ws.rd = [torch.empty(M, d, **bf) for _ in range(keep)]
         ws.av = [torch.empty(N, d, **bf) for _ in range(keep)]
         ws.lse = [torch.empty(B, H, T, **f32) for _ in range(keep)]
+        # zero-memory training: the forward's phantom value-sum per layer (ops.relattn_fwd(..., oph=, mph=)), which spares the
+        # query-owner backward its walk over the all-phantom distance blocks
+        use_oph = train and ops.phantom_sum_applies(T=T, dh=c.d_head, M=M, Kc=Kc)
+        ws.oph = [torch.empty(N, d, **bf) for _ in range(keep)] if use_oph else None
+        ws.mph = [torch.empty(B, H, T, **f32) for _ in range(keep)] if use_oph else None
         ws.tmp = torch.empty(N, d, **bf)
         ws.h1 = [torch.empty(N, d, **bf) for _ in range(keep)]
         ws.a = [torch.empty(N, Fi, **bf) for _ in range(keep)]
@@ -307,7 +312,8 @@ class XLEngine:
             ops.gemm(ws.phi, self._lw(l, 'dec_attn.r_net.weight'), ws.rd[s], M, d, d)
             ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[s],
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
-                            ws.av[s], ws.lse[s], **st)
+                            ws.av[s], ws.lse[s], oph=ws.oph[s].view(B, T, d) if (train and ws.oph is not None) else None,
+                            mph=ws.mph[s] if (train and ws.oph is not None) else None, **st)
             ops.gemm(ws.av[s], self._lw(l, 'dec_attn.o_net.weight'), ws.tmp, N, d, d)
             ops.ln_residual_fwd(ws.tmp, h_in, self._lw(l, 'dec_attn.layer_norm.weight', self.P),
                                 self._lw(l, 'dec_attn.layer_norm.bias', self.P), ws.h1[s],
@@ -605,7 +611,9 @@ class XLEngine:
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
                             ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
                             ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
-                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr, **st)
+                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr,
+                            oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
+                            mph=ws.mph[l] if ws.oph is not None else None, **st)
             # r_net: dW_r = d_rd^T . phi
             ops.cast_bf16(ws.d_rd, ws.d_rd16)
             ops.gemm(ws.d_rd16, ws.phi_c, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,

@@ -646,3 +646,62 @@ def test_gemm_relu_mask_bits_round_trip(dev, M, N, K, p):
     assert ops.gemm_relu_mask_bytes(1000, 3072) == 0 and ops.gemm_relu_mask_bytes(2048, 200) == 0 and ops.gemm_relu_mask_bytes(2048, 3072) == 0
     with pytest.raises(MusicXLError):
         ops.gemm(x[:1000], w1, a1[:1000], 1000, N, K, flags=fl | ops.GEMM_SAVE_RELU_MASK, aux=bits, bias=b1, drop_p=p, seed=9, site=2)
+
+
+@pytest.mark.parametrize('B,T,H,M,Kc,name', [(2, 512, 2, 512, 512, 'nomem'), (3, 768, 1, 1024, 768 + 192, 'partial mem'),
+                                             (1, 1024, 2, 768, 1024 + 64, 'T>M'), (1, 2048, 1, 2048, 2048, 'C3 layer shape')])
+def test_relattn_bwd_with_forward_phantom_sum(dev, B, T, H, M, Kc, name):
+    """mxl_relattn_fwd_phantom + mxl_relattn_bwd_sparse_dg_oph: the all-phantom distance blocks are not walked by the query-owner
+    backward; their dQr comes from the forward's phantom value-sum.  Every gradient against the fp32 dense oracle at the same
+    tolerance as the plain pair, out / lse identical to the plain forward, and dq against the plain backward."""
+    from symbolic_music_generation_amd import ops
+    from oracle.relattn_ref import relattn_dense
+    dh = 64
+    assert ops.phantom_sum_applies(T=T, dh=dh, M=M, Kc=Kc)
+    torch.manual_seed(T * 5 + M)
+    d = H * dh
+    qkv = bf(torch.randn(B, Kc, 3 * d) * 0.8)
+    rd = bf(torch.randn(M, d) * 0.8)
+    rwb, rrb = torch.randn(H, dh) * 0.5, torch.randn(H, dh) * 0.5
+    dout = bf(torch.randn(B, T, d))
+    q = qkv[:, Kc - T:, :d].float().view(B, T, H, dh).clone().requires_grad_(True)
+    k = qkv[:, :, d:2 * d].float().view(B, Kc, H, dh).clone().requires_grad_(True)
+    v = qkv[:, :, 2 * d:].float().view(B, Kc, H, dh).clone().requires_grad_(True)
+    rdr = rd.float().view(M, H, dh).clone().requires_grad_(True)
+    rwbr, rrbr = rwb.clone().requires_grad_(True), rrb.clone().requires_grad_(True)
+    ref_out, _ = relattn_dense(q, k, v, rdr, rwbr, rrbr, M)
+    ref_out.backward(dout.float().view(B, T, H, dh))
+    qkv_d, rd_d, do_d, rwb_d, rrb_d = qkv.to(dev), rd.to(dev), dout.to(dev), rwb.to(dev), rrb.to(dev)
+    st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,
+              o_bs=T * d, o_rs=d)
+    qv, kv, vv = qkv_d[:, Kc - T:, :d], qkv_d[:, :, d:2 * d], qkv_d[:, :, 2 * d:]
+    res = {}
+    for use in (False, True):
+        out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16); lse = torch.zeros(B, H, T, device=dev)
+        oph = torch.full((B, T, d), float('nan'), device=dev, dtype=torch.bfloat16) if use else None
+        mph = torch.full((B, H, T), float('nan'), device=dev) if use else None
+        ops.relattn_fwd(qv, kv, vv, rd_d, rwb_d, rrb_d, out, lse, oph=oph, mph=mph, **st)
+        dqkv = torch.zeros(B, Kc, 3 * d, device=dev, dtype=torch.bfloat16)
+        delta = torch.zeros(B, H, T, device=dev)
+        dg = torch.empty(B, H, T, M, device=dev, dtype=torch.bfloat16)
+        d_rwb, d_rrb = torch.zeros(H, dh, device=dev), torch.zeros(H, dh, device=dev)
+        d_rd = torch.zeros(M, d, device=dev)
+        qr_buf = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
+        ops.relattn_bwd(qv, kv, vv, rd_d, rwb_d, rrb_d, out, do_d, lse, delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d],
+                        dqkv[:, :, 2 * d:], dg, d_rwb, d_rrb, dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
+                        d_rd=d_rd, qr_buf=qr_buf, oph=oph, mph=mph, **st)
+        torch.cuda.synchronize()
+        if use:
+            assert not torch.isnan(oph.float()).any() and not torch.isnan(mph).any(), 'oph / mph written for every query'
+        res[use] = dict(out=out, lse=lse, dq=dqkv[:, Kc - T:, :d].float().cpu().view(B, T, H, dh),
+                        dk=dqkv[:, :, d:2 * d].float().cpu().view(B, Kc, H, dh), dv=dqkv[:, :, 2 * d:].float().cpu().view(B, Kc, H, dh),
+                        d_rd=d_rd.cpu().view(M, H, dh), d_rwb=d_rwb.cpu(), d_rrb=d_rrb.cpu())
+    a, b = res[False], res[True]
+    assert torch.equal(a['out'], b['out']) and torch.equal(a['lse'], b['lse'])
+    assert torch.equal(a['dk'], b['dk']) and torch.equal(a['dv'], b['dv'])
+    errs = {nm: rel_err(b[nm], ref) for nm, ref in [('dq', q.grad), ('dk', k.grad), ('dv', v.grad), ('d_rd', rdr.grad),
+                                                     ('d_rwb', rwbr.grad), ('d_rrb', rrbr.grad)]}
+    base = {nm: rel_err(a[nm], ref) for nm, ref in [('dq', q.grad), ('d_rwb', rwbr.grad), ('d_rrb', rrbr.grad)]}
+    print(f'{name}: with the forward phantom sum {errs}; plain pair {base}; dq vs plain {rel_err(b["dq"], a["dq"]):.2e}')
+    assert all(e < 2e-2 for e in errs.values()), f'{name}: {errs}'
+    assert rel_err(b['dq'], a['dq']) < 1.5e-2
