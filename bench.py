@@ -237,10 +237,20 @@ def train_leg(args, ranks: Ranks):
             nbar = (T + 1) / 2 if T <= M else M
             fwd_alg = B * T * (4 * d * nbar + 2 * d * M)
             alg = 2 * fwd_alg
+            # zero-memory training: the dQr product over the all-phantom 256-distance blocks is formed by the FORWARD kernel (its
+            # phantom value-sum, ops.relattn_fwd(..., oph=)) and enters the query-owner backward as an elementwise term: those
+            # FLOPs are counted where they are executed, not in the backward group
+            moved = 0.0
+            if getattr(eng._last, 'oph', None) is not None:
+                Kc = eng._last.qkv[0].shape[1]
+                pz = -(((Kc - T) + 63) // 64) * 64
+                cells = sum(32 * max(0, M - (((g0 + 31 - pz) | 255) + 1)) for g0 in range(0, T, 32))
+                moved = 2.0 * B * d * cells
+            alg -= moved
             ach = alg / (ms * 1e-3) / 1e12
             traffic, src = pmc_traffic(args.workload, B)
-            kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg), 'delta': ('relattn_bwd_delta_kernel', 0.0),
-                    'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M)),
+            kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('relattn_bwd_delta_kernel', 0.0),
+                    'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M) - moved),
                     'dkv': ('relattn_bwd_dkv_kernel', B * T * 4 * d * nbar), 'rowbias': ('add_rowbias_kernel', 0.0),
                     'drd': ('relattn_drd_kernel', B * T * 2 * d * M)}
             kernels = {}
@@ -256,6 +266,7 @@ def train_leg(args, ranks: Ranks):
                                'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'HBM bytes per launch group (PMC)', 'traffic_source': src,
                                'avg_launch_ms': ms, 'launches_timed': len(br.ev), 'alg_flop_per_launch_group': alg,
+                               'alg_flop_moved_to_forward': moved,
                                'sum_of_kernel_ms': bwd_sum, 'kernels': kernels}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_train(wl, T, M)
