@@ -348,29 +348,50 @@ __device__ __forceinline__ void stage_kv(const ChunkP& p, char* sK, char* sV, in
     using G = GeoC<DH>;
     const int tid = threadIdx.x;
     const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
-    for (int c = tid; c < G::ROWS * G::CH; c += 256) {
-        const int row = c / G::CH, ch = c % G::CH;
+    // three batches -- every sorted position, then every K / V row, then the LDS stores -- instead of one row at a time: a row's
+    // K / V address depends on its sorted position, so row by row the staging was 2 x NIT dependent memory round trips per
+    // workgroup (12 at dh = 64), which is what these gather-bound kernels spent their time on
+    constexpr int NIT = (G::ROWS * G::CH + 255) / 256;
+    int posv[NIT];
+    bool okv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = tid + it * 256;
+        const int row = c / G::CH;
         int chunk = c0 - 1 + (row >> 6);
         if (chunk < 0) chunk += NC;
-        const bool ok = chunk < NC;
+        okv[it] = (c < G::ROWS * G::CH) && chunk < NC;
         const int slot = chunk * 64 + (row & 63);
-        const int pos = ok ? (sp ? sp[slot] : slot) : 0;
-        const bf16_t* kr = p.k + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8;
-        const bf16_t* vr = p.v + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kr) : z;
-        const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vr) : z;
-        *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = kv;
-        *reinterpret_cast<u32x4*>(sV + G::koff(row, ch)) = vv;
-        // per-row key factor: the CH lanes holding one row are consecutive
-        float ss = 0.f;
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&kv);
+        posv[it] = okv[it] ? (sp ? sp[slot] : slot) : 0;
+    }
+    u32x4 kvv[NIT], vvv[NIT];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const float x = bf2f(e[j]); ss += x * x; }
-        for (int o = 1; o < G::CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
-        if (ch == 0) {
-            sPos[row] = ok ? pos : 0x7fffffff;   // invalid rows: position +inf -> masked by causality
-            sFac[row] = p.lsh ? rsqrtf(ss / (float)DH + 1e-6f) * p.scale : p.scale;
+    for (int it = 0; it < NIT; it++) {
+        const int ch = (tid + it * 256) % G::CH;
+        const bf16_t* kr = p.k + (size_t)b * p.bs + (size_t)posv[it] * p.rs + h * DH + ch * 8;
+        const bf16_t* vr = p.v + (size_t)b * p.bs + (size_t)posv[it] * p.rs + h * DH + ch * 8;
+        kvv[it] = *reinterpret_cast<const u32x4*>(kr);          // (row 0 of the sequence for invalid rows: zeroed below)
+        vvv[it] = *reinterpret_cast<const u32x4*>(vr);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = tid + it * 256;
+        if (c < G::ROWS * G::CH) {
+            const int row = c / G::CH, ch = c % G::CH;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const u32x4 kv = okv[it] ? kvv[it] : z, vv = okv[it] ? vvv[it] : z;
+            *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = kv;
+            *reinterpret_cast<u32x4*>(sV + G::koff(row, ch)) = vv;
+            // per-row key factor: the CH lanes holding one row are consecutive
+            float ss = 0.f;
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&kv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float x = bf2f(e[j]); ss += x * x; }
+            for (int o = 1; o < G::CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+            if (ch == 0) {
+                sPos[row] = okv[it] ? posv[it] : 0x7fffffff;   // invalid rows: position +inf -> masked by causality
+                sFac[row] = p.lsh ? rsqrtf(ss / (float)DH + 1e-6f) * p.scale : p.scale;
+            }
         }
     }
 }
@@ -389,12 +410,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
     xcd_block(bx_, h, b);     // the chunk workgroups of one (head, sequence) share an XCD's L2 (neighbours share a K/V chunk)
     const int NC = p.S / 64;
     const int c0 = bx_ * 2;
-    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
-    __syncthreads();
+    // the wave's own query row is requested BEFORE the key / value staging (its sorted position, then the row: two dependent round
+    // trips that used to start only after the staging barrier)
     const int chunk = c0 + (wid >> 1);
-    if (chunk >= NC) return;
-    const int kb0 = 64 * (wid >> 1);                 // first LDS row of this chunk's 128 keys
-    const int qslot = chunk * 64 + 32 * (wid & 1) + r;
+    const int qslot = min(chunk, NC - 1) * 64 + 32 * (wid & 1) + r;
     const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
     const int qpos = sp ? sp[qslot] : qslot;
     const int round = qslot / p.T;
@@ -404,6 +423,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks + 8 * hh);
     }
+    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
+    __syncthreads();
+    if (chunk >= NC) return;
+    const int kb0 = 64 * (wid >> 1);                 // first LDS row of this chunk's 128 keys
     f32x16 s[4];
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
@@ -512,12 +535,9 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
     xcd_block(bx_, h, b);     // the chunk workgroups of one (head, sequence) share an XCD's L2 (neighbours share a K/V chunk)
     const int NC = p.S / 64;
     const int c0 = bx_ * 2;
-    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
-    __syncthreads();
     const int chunk = c0 + (wid >> 1);
-    if (chunk >= NC) return;
     const int kb0 = 64 * (wid >> 1);
-    const int qslot = chunk * 64 + 32 * (wid & 1) + r;
+    const int qslot = min(chunk, NC - 1) * 64 + 32 * (wid & 1) + r;      // (requested before the staging: see the forward kernel)
     const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
     const int qpos = sp ? sp[qslot] : qslot;
     const int round = qslot / p.T;
@@ -542,6 +562,9 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
     const size_t sidx_ = (((size_t)b * p.n_h + round) * p.H + h) * p.T + qpos;
     const float lse = p.lse[sidx_];
     const float dl = p.dlse ? p.dlse[sidx_] : 0.f;
+    stage_kv<DH>(p, sK, sV, sPos, sFac, b, h, c0, NC);
+    __syncthreads();
+    if (chunk >= NC) return;
     f32x16 s[4], dp[4];
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
@@ -657,41 +680,12 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
     const int kc = bx_;
     const int d = p.H * DH;
     const int* sp = p.spos ? p.spos + ((size_t)b * p.H + h) * p.S : nullptr;
-    // stage the 128 queries: rows 0-63 = chunk kc, rows 64-127 = chunk kc+1 (mod NC)
-    for (int c = tid; c < 128 * G::CH; c += 256) {
-        const int row = c / G::CH, ch = c % G::CH;
-        int chunk = kc + (row >> 6);
-        if (chunk >= NC) chunk -= NC;
-        const int slot = chunk * 64 + (row & 63);
-        const int pos = sp ? sp[slot] : slot;
-        const int round = slot / p.T;
-        const size_t orow = ((size_t)b * p.n_h + round) * p.T + pos;
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.bs + (size_t)pos * p.rs + h * DH + ch * 8);
-        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dout + orow * d + h * DH + ch * 8);
-        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.out + orow * d + h * DH + ch * 8);
-        *reinterpret_cast<u32x4*>(sQ + G::koff(row, ch)) = qv;
-        *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = dv;
-        float dl = 0.f;
-        const bf16_t* a = reinterpret_cast<const bf16_t*>(&dv);
-        const bf16_t* o = reinterpret_cast<const bf16_t*>(&ov);
-#pragma unroll
-        for (int j = 0; j < 8; j++) dl += bf2f(a[j]) * bf2f(o[j]);
-        for (int o2 = 1; o2 < G::CH; o2 <<= 1) dl += __shfl_xor(dl, o2, 64);
-        if (ch == 0) {
-            const size_t si = (((size_t)b * p.n_h + round) * p.H + h) * p.T + pos;
-            sQpos[row] = pos;
-            sLse[row] = p.lse[si];
-            sDl[row] = dl;
-            sDlse[row] = p.dlse ? p.dlse[si] : 0.f;
-        }
-    }
-    __syncthreads();
-    // with a single chunk (NC == 1) the "previous" chunk is the chunk itself: HF concatenates it twice; keep both
+    // the wave's own key rows first (sorted position, then K / V), then the 128 queries in three batches -- positions, rows, stores
+    // -- instead of row by row (each row was two to three dependent round trips: see stage_kv)
     const int qsel = wid >> 1;                 // 0: queries of chunk kc (keys are their "current" chunk), 1: chunk kc+1
     const int kslot = kc * 64 + 32 * (wid & 1) + r;
     const int kpos = sp ? sp[kslot] : kslot;
     bf16x8 kf[KS], vf[KS];
-    float ss = 0.f;
     {
         const bf16_t* kp = p.k + (size_t)b * p.bs + (size_t)kpos * p.rs + h * DH;
         const bf16_t* vp = p.v + (size_t)b * p.bs + (size_t)kpos * p.rs + h * DH;
@@ -699,11 +693,67 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
         for (int ks = 0; ks < KS; ks++) {
             kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * hh);
             vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
-#pragma unroll
-            for (int j = 0; j < 8; j++) { const float x = bf2f((bf16_t)kf[ks][j]); ss += x * x; }
         }
-        ss += __shfl_xor(ss, 32, 64);
     }
+    // stage the 128 queries: rows 0-63 = chunk kc, rows 64-127 = chunk kc+1 (mod NC)
+    constexpr int NIT = (128 * G::CH + 255) / 256;
+    int posq[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = min(tid + it * 256, 128 * G::CH - 1);
+        const int row = c / G::CH;
+        int chunk = kc + (row >> 6);
+        if (chunk >= NC) chunk -= NC;
+        const int slot = chunk * 64 + (row & 63);
+        posq[it] = sp ? sp[slot] : slot;
+    }
+    u32x4 qv_[NIT], dv_[NIT], ov_[NIT];
+    float lse_[NIT], dlse_[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = min(tid + it * 256, 128 * G::CH - 1);
+        const int row = c / G::CH, ch = c % G::CH;
+        int chunk = kc + (row >> 6);
+        if (chunk >= NC) chunk -= NC;
+        const int slot = chunk * 64 + (row & 63);
+        const int round = slot / p.T;
+        const size_t orow = ((size_t)b * p.n_h + round) * p.T + posq[it];
+        qv_[it] = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.bs + (size_t)posq[it] * p.rs + h * DH + ch * 8);
+        dv_[it] = *reinterpret_cast<const u32x4*>(p.dout + orow * d + h * DH + ch * 8);
+        ov_[it] = *reinterpret_cast<const u32x4*>(p.out + orow * d + h * DH + ch * 8);
+        const size_t si = (((size_t)b * p.n_h + round) * p.H + h) * p.T + posq[it];
+        lse_[it] = p.lse[si];
+        dlse_[it] = p.dlse ? p.dlse[si] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = tid + it * 256;
+        if (c < 128 * G::CH) {
+            const int row = c / G::CH, ch = c % G::CH;
+            *reinterpret_cast<u32x4*>(sQ + G::koff(row, ch)) = qv_[it];
+            *reinterpret_cast<u32x4*>(sDO + G::koff(row, ch)) = dv_[it];
+            float dl = 0.f;
+            const bf16_t* a = reinterpret_cast<const bf16_t*>(&dv_[it]);
+            const bf16_t* o = reinterpret_cast<const bf16_t*>(&ov_[it]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dl += bf2f(a[j]) * bf2f(o[j]);
+            for (int o2 = 1; o2 < G::CH; o2 <<= 1) dl += __shfl_xor(dl, o2, 64);
+            if (ch == 0) {
+                sQpos[row] = posq[it];
+                sLse[row] = lse_[it];
+                sDl[row] = dl;
+                sDlse[row] = dlse_[it];
+            }
+        }
+    }
+    __syncthreads();
+    // with a single chunk (NC == 1) the "previous" chunk is the chunk itself: HF concatenates it twice; keep both
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x = bf2f((bf16_t)kf[ks][j]); ss += x * x; }
+    ss += __shfl_xor(ss, 32, 64);
     const float fac = p.lsh ? rsqrtf(ss / (float)DH + 1e-6f) * p.scale : p.scale;
     f32x16 ak[EB], av[EB];
 #pragma unroll
