@@ -348,31 +348,28 @@ def decode_leg(args, ranks: Ranks, warmup: int):
     """TransfoXL 12L/768d cached-mem decode, batch 64 prompts x 256 tokens, top-k 8, generate to 2048,
     one hipGraph replay per token.  A 'step' here = one generated token for the whole batch."""
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
-    from symbolic_music_generation_amd.generate import XLDecoder
+    from symbolic_music_generation_amd.generate import XLDecoder, XLDecoderLanes
     dev, rank = ranks.dev, ranks.rank
     B, Tp, M = (args.batch if args.mode == 'decode' and args.batch else 64), 256, 2048
     cfg = MyTransfoXLConfig('base', max_length=2048, vocab_size=V, mem_len=M, cutoffs=[])
     model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).eval()
     # room past T = 2048 so that a full-ring window can be timed after the C5 generation proper
     FULL = 128
-    dec = XLDecoder(model.engine, B, 2048 + FULL + 8, seed=77 + rank)
+    # the decoder model.generate builds for this batch: two free-running half-batch lanes from 32 rows on (generate.XLDecoderLanes;
+    # MXL_DECODE_LANES=1: one decoder).  The eager (PMC) mode keeps one decoder on one stream.
+    lanes = 2 if (B >= 32 and B % 2 == 0 and not args.eager and os.environ.get('MXL_DECODE_LANES', '2') != '1') else 1
+    dec = (XLDecoderLanes(model.engine, B, 2048 + FULL + 8, seed=77 + rank, lanes=lanes) if lanes > 1
+           else XLDecoder(model.engine, B, 2048 + FULL + 8, seed=77 + rank))
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)
     prompt = torch.randint(4, V, (B, Tp), generator=gen).to(dev)
-    samp = dict(do_sample=True, top_k=8, top_p=1.0, temperature=1.0)
+    samp = dict(do_sample=True, top_k=8, top_p=1.0, temperature=1.0, repetition_penalty=1.0, typical_p=1.0)
     warm = max(warmup, 1)
     with torch.no_grad():
-        dec.prefill(prompt, samp)
+        dec.begin(prompt, 2048 + FULL + 8, samp, use_graph=not args.eager)     # prompt pass, first token, graph capture
         for _ in range(warm):
-            dec.step(samp)
-        if args.eager:
-            replay = lambda: dec.step(samp)
-            done = Tp + 1 + warm
-        else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                dec.step(samp)
-            replay = g.replay
-            done = Tp + 1 + warm + 1      # positions filled so far: prompt, its sample, warm-up and capture steps
+            dec.replay_once()
+        replay = dec.replay_once
+        done = Tp + 1 + warm              # positions filled so far: prompt, its sample, warm-up steps
         torch.cuda.synchronize()
         # the whole C5 generation, prompt 256 -> T = 2048 (the first steps are cheaper than the last: ring slots that were never
         # written are HF's zero mems and cost no K/V bytes, so a short window after the prompt would flatter the number)
@@ -405,7 +402,7 @@ def decode_leg(args, ranks: Ranks, warmup: int):
                'value': B * steps / dt, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': steps, 'warmup': warm,
                'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16', 'data': 'synthetic',
                'config': {'workload': 'SURVEY C5 decode: 12L/768d, M=2048, B=64 prompts x 256 tokens generated to T=2048, top_k=8',
-                          'batch': B, 'positions_timed': [done, done + steps], 'hipgraph': not args.eager},
+                          'batch': B, 'positions_timed': [done, done + steps], 'hipgraph': not args.eager, 'lanes': lanes},
                'roofline': {'kernel': 'whole decode step (one hipGraph replay: 12 x [qkv+append, bd, ring attention, o, LN, ffn1, '
                                       'ffn2 slabs, LN] + head + sampler)', 'bound': 'hbm', 'achieved': ach,
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, **decode_pmc_traffic(),

@@ -182,50 +182,106 @@ class XLDecoder:
             self.trace.index_copy_(1, self.t_dev.to(torch.int64), self.logp.unsqueeze(1))
 
     # ---------------------------------------------------------------- loop
+    def begin(self, prompt: torch.Tensor, max_length: int, sampling: dict, use_graph: bool = True) -> int:
+        """prompt pass + first sampled token + (use_graph) capture of one decode step; returns the number of `replay_once()`
+        calls that complete the generation to max_length"""
+        if max_length > self.Tmax:
+            raise MusicXLError(f'max_length {max_length} exceeds the decoder buffer {self.Tmax}')
+        self._sampling = sampling
+        self._use_graph = use_graph
+        self.prefill(prompt, sampling)
+        steps = max_length - prompt.shape[1] - 1
+        if steps > 0 and use_graph:
+            key = tuple(sorted(sampling.items()))
+            if self.graph is None or self._graph_key != key:
+                # warm-up on a side stream (first launches set function attributes), then capture one step
+                state = (self.t_dev.clone(), self.rng.clone(), self.ids.clone(),
+                         [k.clone() for k in self.kc], [v.clone() for v in self.vc])
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self.step(sampling)
+                torch.cuda.current_stream().wait_stream(s)
+                self.graph = torch.cuda.CUDAGraph()       # hipGraph on ROCm
+                with torch.cuda.graph(self.graph):
+                    self.step(sampling)
+                self._graph_key = key
+                # restore the state the two extra steps consumed
+                self.t_dev.copy_(state[0]); self.rng.copy_(state[1]); self.ids.copy_(state[2])
+                for a, b in zip(self.kc, state[3]):
+                    a.copy_(b)
+                for a, b in zip(self.vc, state[4]):
+                    a.copy_(b)
+        return max(steps, 0)
+
+    def replay_once(self):
+        """one more token for every row (on the current stream)"""
+        if self._use_graph:
+            self.graph.replay()
+        else:
+            self.step(self._sampling)
+
     def generate(self, prompt: torch.Tensor, max_length: int, do_sample: bool = False, top_k: Optional[int] = None,
                  top_p: Optional[float] = None, temperature: float = 1.0, repetition_penalty: Optional[float] = None,
                  typical_p: Optional[float] = None, use_graph: bool = True) -> torch.Tensor:
         """Returns (B, max_length) ids = prompt + continuation.  Like the reference (eos_token_id stays HF's default 0 =
         [OMIT]) decoding runs to max_length."""
-        if max_length > self.Tmax:
-            raise MusicXLError(f'max_length {max_length} exceeds the decoder buffer {self.Tmax}')
         sampling = dict(do_sample=do_sample, top_k=top_k or 0, top_p=top_p if top_p is not None else 1.0,
                         temperature=temperature, repetition_penalty=1.0 if repetition_penalty is None else repetition_penalty,
                         typical_p=1.0 if typical_p is None else typical_p)
         Tp = prompt.shape[1]
-        n_new = max_length - Tp
-        if n_new <= 0:
+        if max_length - Tp <= 0:
             return prompt[:, :max_length]
-        self.prefill(prompt, sampling)
-        steps = n_new - 1
-        if steps > 0:
-            if use_graph:
-                key = tuple(sorted(sampling.items()))
-                if self.graph is None or self._graph_key != key:
-                    # warm-up on a side stream (first launches set function attributes), then capture one step
-                    state = (self.t_dev.clone(), self.rng.clone(), self.ids.clone(),
-                             [k.clone() for k in self.kc], [v.clone() for v in self.vc])
-                    s = torch.cuda.Stream()
-                    s.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(s):
-                        self.step(sampling)
-                    torch.cuda.current_stream().wait_stream(s)
-                    self.graph = torch.cuda.CUDAGraph()       # hipGraph on ROCm
-                    with torch.cuda.graph(self.graph):
-                        self.step(sampling)
-                    self._graph_key = key
-                    # restore the state the two extra steps consumed
-                    self.t_dev.copy_(state[0]); self.rng.copy_(state[1]); self.ids.copy_(state[2])
-                    for a, b in zip(self.kc, state[3]):
-                        a.copy_(b)
-                    for a, b in zip(self.vc, state[4]):
-                        a.copy_(b)
-                for _ in range(steps):
-                    self.graph.replay()
-            else:
-                for _ in range(steps):
-                    self.step(sampling)
+        for _ in range(self.begin(prompt, max_length, sampling, use_graph)):
+            self.replay_once()
         return self.ids[:, :max_length].clone()
+
+
+class XLDecoderLanes:
+    """The batch as `lanes` independent XLDecoders of B / lanes sequences, each with its own hipGraph, replayed on its own
+    stream.  A decode step is ~100 small dependent launches around 12 ring-attention launches: alone, the small launches run at
+    launch / latency cost with the chip idle and the ring streaming waits for them; with two lanes one lane's small launches
+    overlap the other's ring streaming (sequences are independent: the lanes never synchronise until the generation ends).
+    Same interface as XLDecoder for `generate` / `begin` / `replay_once`; rows keep their order."""
+
+    def __init__(self, engine, batch: int, max_total_len: int, seed: int = 1234, lanes: int = 2):
+        assert batch % lanes == 0
+        self.B, self.Tmax, self.n = batch, max_total_len, lanes
+        # (the sampler draws per (seed, row, step): a different seed per lane keeps the lanes' draws independent)
+        self.lanes = [XLDecoder(engine, batch // lanes, max_total_len, seed=seed + 7919 * i) for i in range(lanes)]
+        self.streams = [torch.cuda.Stream() for _ in range(lanes)]
+
+    def invalidate_tables(self):
+        for d in self.lanes:
+            d.invalidate_tables()
+
+    def begin(self, prompt, max_length, sampling, use_graph=True) -> int:
+        b = self.B // self.n
+        steps = [d.begin(prompt[i * b:(i + 1) * b], max_length, sampling, use_graph) for i, d in enumerate(self.lanes)]
+        for s in self.streams:                       # the lanes start from the prompt passes and captures issued above
+            s.wait_stream(torch.cuda.current_stream())
+        return steps[0]
+
+    def replay_once(self):
+        for d, s in zip(self.lanes, self.streams):
+            with torch.cuda.stream(s):
+                d.replay_once()
+
+    def join(self):
+        for s in self.streams:
+            torch.cuda.current_stream().wait_stream(s)
+
+    def generate(self, prompt, max_length, do_sample=False, top_k=None, top_p=None, temperature=1.0, repetition_penalty=None,
+                 typical_p=None, use_graph=True) -> torch.Tensor:
+        sampling = dict(do_sample=do_sample, top_k=top_k or 0, top_p=top_p if top_p is not None else 1.0,
+                        temperature=temperature, repetition_penalty=1.0 if repetition_penalty is None else repetition_penalty,
+                        typical_p=1.0 if typical_p is None else typical_p)
+        if max_length - prompt.shape[1] <= 0:
+            return prompt[:, :max_length]
+        for _ in range(self.begin(prompt, max_length, sampling, use_graph)):
+            self.replay_once()
+        self.join()
+        return torch.cat([d.ids[:, :max_length] for d in self.lanes], 0)
 
 
 class _BeamHyps:

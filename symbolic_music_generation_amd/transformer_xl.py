@@ -200,7 +200,7 @@ class MyTransfoXLLMHeadModel(EngineModule):
         strategies (eval.py:277-321), beam search in its plain, sampling and diverse-group forms.  `num_return_sequences` expands the
         prompts as HF does (repeat_interleave).  Mode selection follows HF 4.25.1 `generate`: contrastive search when
         `penalty_alpha > 0`, `top_k > 1`, `do_sample` false and one beam; group beam search when `num_beam_groups > 1`."""
-        from .generate import XLDecoder, beam_search, contrastive_search, group_beam_search
+        from .generate import XLDecoder, XLDecoderLanes, beam_search, contrastive_search, group_beam_search
         # HF 4.25.1 fills unspecified generation arguments from the model config; PretrainedConfig's default top_k is 50, so
         # `generate(do_sample=True)` without top_k samples from the 50 best tokens (the reference relies on these defaults)
         top_k = getattr(self.config, 'top_k', 50) if top_k is None else top_k
@@ -236,8 +236,11 @@ class MyTransfoXLLMHeadModel(EngineModule):
             input_ids = input_ids.repeat_interleave(num_return_sequences, 0)
         B = input_ids.shape[0]
         dec = getattr(self, '_decoder', None)
-        if dec is None or dec.B != B or dec.Tmax < max_length:
-            dec = self._decoder = XLDecoder(self.engine, B, max_length, seed=seed)
+        # two free-running half-batch lanes from 32 rows on (generate.XLDecoderLanes); MXL_DECODE_LANES=1 keeps one decoder
+        lanes = 2 if (B >= 32 and B % 2 == 0 and use_graph and os.environ.get('MXL_DECODE_LANES', '2') != '1') else 1
+        if dec is None or dec.B != B or dec.Tmax < max_length or getattr(dec, 'n', 1) != lanes:
+            dec = self._decoder = (XLDecoderLanes(self.engine, B, max_length, seed=seed, lanes=lanes) if lanes > 1
+                                   else XLDecoder(self.engine, B, max_length, seed=seed))
         dec.invalidate_tables()
         return dec.generate(input_ids.to(self.device), max_length, do_sample=do_sample, top_k=top_k, top_p=top_p,
                             temperature=temperature, repetition_penalty=repetition_penalty, typical_p=typical_p,

@@ -343,3 +343,23 @@ def test_contrastive_select_kernel_matches_formula(dev):
     top2 = want.topk(2, -1).values
     clear = (top2[:, 0] - top2[:, 1]) > 2e-3
     assert torch.equal(sel[clear], want.argmax(-1)[clear]) and (inv[:, :S] - 1 / c.norm(dim=-1)).abs().max().item() < 1e-4
+
+
+def test_two_lane_decoder_equals_single_decoder(dev):
+    """generate.XLDecoderLanes (two free-running half-batch decoders, one hipGraph and one stream each): greedy tokens identical
+    to the single decoder's, row for row; model.generate picks it from 32 rows on; under sampling eager == hipGraph replay"""
+    from symbolic_music_generation_amd.generate import XLDecoder, XLDecoderLanes
+    ref, m = _pair(dev, n_layer=2, mem_len=64, max_length=128, seed=21)
+    m.eval()
+    g = torch.Generator().manual_seed(22)
+    prompt = torch.randint(4, 1190, (32, 16), generator=g).to(dev)
+    one = XLDecoder(m.engine, 32, 128, seed=3).generate(prompt, 100, do_sample=False, use_graph=True)
+    two = XLDecoderLanes(m.engine, 32, 128, seed=3, lanes=2).generate(prompt, 100, do_sample=False, use_graph=True)
+    assert torch.equal(one, two)
+    out = m.generate(input_ids=prompt, max_length=100, do_sample=False)
+    assert type(m._decoder).__name__ == 'XLDecoderLanes' and torch.equal(out, one)
+    kw = dict(max_length=90, do_sample=True, top_k=8, top_p=0.9)
+    a = XLDecoderLanes(m.engine, 32, 128, seed=5, lanes=2).generate(prompt, use_graph=True, **kw)
+    b = XLDecoderLanes(m.engine, 32, 128, seed=5, lanes=2).generate(prompt, use_graph=False, **kw)
+    assert torch.equal(a, b)
+    assert torch.equal(a[:, :16], prompt) and (a >= 0).all() and (a < 1190).all()
