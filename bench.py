@@ -357,7 +357,7 @@ def decode_leg(args, ranks: Ranks, warmup: int):
     FULL = 128
     # the decoder model.generate builds for this batch: two free-running half-batch lanes from 32 rows on (generate.XLDecoderLanes;
     # MXL_DECODE_LANES=1: one decoder).  The eager (PMC) mode keeps one decoder on one stream.
-    lanes = 2 if (B >= 32 and B % 2 == 0 and not args.eager and os.environ.get('MXL_DECODE_LANES', '2') != '1') else 1
+    lanes = int(os.environ.get('MXL_DECODE_LANES', '2')) if (B >= 32 and not args.eager) else 1
     dec = (XLDecoderLanes(model.engine, B, 2048 + FULL + 8, seed=77 + rank, lanes=lanes) if lanes > 1
            else XLDecoder(model.engine, B, 2048 + FULL + 8, seed=77 + rank))
     gen = torch.Generator(device='cpu').manual_seed(77 + rank)

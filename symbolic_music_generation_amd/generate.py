@@ -245,10 +245,12 @@ class XLDecoderLanes:
     Same interface as XLDecoder for `generate` / `begin` / `replay_once`; rows keep their order."""
 
     def __init__(self, engine, batch: int, max_total_len: int, seed: int = 1234, lanes: int = 2):
-        assert batch % lanes == 0
+        assert 1 <= lanes <= batch
         self.B, self.Tmax, self.n = batch, max_total_len, lanes
+        self.sizes = [batch // lanes + (1 if i < batch % lanes else 0) for i in range(lanes)]
+        self.offs = [sum(self.sizes[:i]) for i in range(lanes + 1)]
         # (the sampler draws per (seed, row, step): a different seed per lane keeps the lanes' draws independent)
-        self.lanes = [XLDecoder(engine, batch // lanes, max_total_len, seed=seed + 7919 * i) for i in range(lanes)]
+        self.lanes = [XLDecoder(engine, b, max_total_len, seed=seed + 7919 * i) for i, b in enumerate(self.sizes)]
         self.streams = [torch.cuda.Stream() for _ in range(lanes)]
 
     def invalidate_tables(self):
@@ -256,8 +258,7 @@ class XLDecoderLanes:
             d.invalidate_tables()
 
     def begin(self, prompt, max_length, sampling, use_graph=True) -> int:
-        b = self.B // self.n
-        steps = [d.begin(prompt[i * b:(i + 1) * b], max_length, sampling, use_graph) for i, d in enumerate(self.lanes)]
+        steps = [d.begin(prompt[self.offs[i]:self.offs[i + 1]], max_length, sampling, use_graph) for i, d in enumerate(self.lanes)]
         for s in self.streams:                       # the lanes start from the prompt passes and captures issued above
             s.wait_stream(torch.cuda.current_stream())
         return steps[0]

@@ -237,7 +237,7 @@ class MyTransfoXLLMHeadModel(EngineModule):
         B = input_ids.shape[0]
         dec = getattr(self, '_decoder', None)
         # two free-running half-batch lanes from 32 rows on (generate.XLDecoderLanes); MXL_DECODE_LANES=1 keeps one decoder
-        lanes = 2 if (B >= 32 and B % 2 == 0 and use_graph and os.environ.get('MXL_DECODE_LANES', '2') != '1') else 1
+        lanes = max(1, int(os.environ.get('MXL_DECODE_LANES', '2'))) if (B >= 32 and use_graph) else 1
         if dec is None or dec.B != B or dec.Tmax < max_length or getattr(dec, 'n', 1) != lanes:
             dec = self._decoder = (XLDecoderLanes(self.engine, B, max_length, seed=seed, lanes=lanes) if lanes > 1
                                    else XLDecoder(self.engine, B, max_length, seed=seed))
