@@ -185,3 +185,19 @@ def test_train_and_my_train_args_surface():
     assert all(v is not None for v in args.values())
     with pytest.raises(ValueError):
         get_train_and_my_train_args('reformer', 'tiny', None, dict(logging_strategy='sometimes'), ds)
+
+
+def test_shape_predicates_of_the_round3_paths():
+    """host-side decisions that pick a kernel path (no GPU): where the forward's phantom value-sum applies, and for which output
+    sizes the large-tile GEMM offers its relu-mask bit buffer (M * N / 8 bytes; 0 = the engines fall back to the activations)"""
+    from symbolic_music_generation_amd import ops
+    ok = ops.phantom_sum_applies
+    assert ok(T=2048, dh=64, M=2048, Kc=2048)                  # C3, zero memories
+    assert ok(T=768, dh=64, M=1024, Kc=768 + 192)              # partial memories
+    assert not ok(T=2048, dh=64, M=2048, Kc=4096)              # full real memories: no phantom distance
+    assert not ok(T=2048, dh=32, M=2048, Kc=2048) and not ok(T=2000, dh=64, M=2048, Kc=2000) and not ok(T=512, dh=64, M=384, Kc=512)
+    nbytes = ops.gemm_relu_mask_bytes
+    assert nbytes(131072, 3072) == 131072 * 3072 // 8           # C3 FFN
+    assert nbytes(131072, 2048) == 131072 * 2048 // 8           # C4 FFN
+    assert nbytes(1000, 3072) == 0 and nbytes(2048, 200) == 0   # ragged
+    assert nbytes(2048, 3072) == 0                              # fewer tiles than one round of the chip: 192-wide tiles win
