@@ -194,6 +194,10 @@ int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* b
                          void* stream);
 /* out[n] += sum_m X[m][n]  (bias gradients), X (M,N) bf16 with leading dimension ld */
 int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream);
+/* Y = dropout(X) with the (seed, site) mask over the flat element index (mxl_dropout_bf16) and out[n] += sum_m Y[m][n] in the same
+ * pass (the Reformer's feed_forward.output.dense bias gradient: the regenerated forward mask and the column sums); N % 8 == 0 */
+int mxl_dropout_colsum_bf16(const void* X, void* Y, float* out, int M, int N, float drop_p, unsigned long long seed,
+                            unsigned site, void* stream);
 /* Y[m][n] = X[m][n] - mean_m X[m][n]  (bf16 in / out, fp32 arithmetic; N % 8 == 0).  The positional table enters the r_net
  * weight gradient dW_r = sum_d dRd[d]^T phi[d] centred over the distance axis: sum_d dRd[d] = 0 exactly (every softmax row's
  * score gradients sum to zero and every query sees exactly mem_len distances), so the constant part of phi multiplies nothing

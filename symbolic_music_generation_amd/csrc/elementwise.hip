@@ -367,7 +367,11 @@ __global__ __launch_bounds__(LNB_THREADS) __attribute__((amdgpu_waves_per_eu(NCH
 
 // out[n] += sum_m X[m][n]   (bias gradients: CoreNet.0/3 bias, crit bias).  bf16 in, fp32 atomic out.
 // block = 32 column-threads (8 columns each, 16-byte loads) x 8 row-lanes; rows_per_block rows per block.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out, int M, int N, int ld, int rows_per_block) {
+// DROP: X is first passed through the dropout mask of (seed, site) (element index r * N + c: ld == N) and written to Y; the sums
+// are over the stored Y (mxl_dropout_colsum_bf16: the Reformer's FFN-output bias gradient, one pass instead of two)
+template <bool DROP>
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out, int M, int N, int ld, int rows_per_block,
+                                                     bf16_t* Y, unsigned thresh, float dscale, unsigned long long seed, unsigned site) {
     __shared__ float red[8][256];
     const int ct = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int col = blockIdx.x * 256 + ct * 8;
@@ -378,17 +382,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* X, float* out
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
     if (col + 7 < N && (ld & 7) == 0) {
         int r = r0 + rl;
+        auto drop_store = [&](bf16x8 v, int row) -> bf16x8 {     // DROP: mask, scale, store; returns the stored values
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                o[j] = dropout_keep32(seed, site, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j), thresh) ? bf2f((bf16_t)v[j]) * dscale : 0.f;
+            const u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(Y + (size_t)row * ld + col) = w;
+            return __builtin_bit_cast(bf16x8, w);
+        };
         for (; r + 24 < r1; r += 32) {            // four independent 16-byte loads in flight per thread
-            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 8) * ld + col);
-            const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 16) * ld + col);
-            const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 24) * ld + col);
+            bf16x8 v0 = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
+            bf16x8 v1 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 8) * ld + col);
+            bf16x8 v2 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 16) * ld + col);
+            bf16x8 v3 = *reinterpret_cast<const bf16x8*>(X + (size_t)(r + 24) * ld + col);
+            if (DROP) { v0 = drop_store(v0, r); v1 = drop_store(v1, r + 8); v2 = drop_store(v2, r + 16); v3 = drop_store(v3, r + 24); }
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 acc[j] += (bf2f((bf16_t)v0[j]) + bf2f((bf16_t)v1[j])) + (bf2f((bf16_t)v2[j]) + bf2f((bf16_t)v3[j]));
         }
         for (; r < r1; r += 8) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ld + col);
+            if (DROP) v = drop_store(v, r);
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)v[j]);
         }
@@ -638,8 +653,19 @@ extern "C" int mxl_ln_residual_fwd_partial(const float* slabs, int KS, long long
 extern "C" int mxl_colsum_bf16(const void* X, float* out, int M, int N, int ld, void* stream) {
     MXL_CHECK_ARG(X && out && M > 0 && N > 0 && ld >= N);
     const int rpb = 128;      // 768 blocks for a 32768 x 768 matrix: three per CU, four loads in flight per thread
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)X, out, M, N, ld, rpb);
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X, out, M, N, ld, rpb, (bf16_t*)nullptr, 0u, 1.f, 0ull, 0u);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_dropout_colsum_bf16(const void* X, void* Y, float* out, int M, int N, float drop_p, unsigned long long seed,
+                                       unsigned site, void* stream) {
+    MXL_CHECK_ARG(X && Y && out && M > 0 && N > 0 && (N % 8) == 0 && drop_p > 0.f && drop_p < 1.f);
+    MXL_CHECK_ARG((unsigned long long)M * N <= 0xffffffffull && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0);
+    const int rpb = 128;
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X, out, M, N, N, rpb, (bf16_t*)Y, dropout_thresh(drop_p), 1.f / (1.f - drop_p), seed, site);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

@@ -208,6 +208,11 @@ def ln_bwd_add(dy, dy2, z, mean, rstd, gamma, dadd, dres, dgamma, dbeta):
                                         _p(dbeta), N, d, _stream()), 'mxl_ln_residual_bwd_add')
 
 
+def dropout_colsum(x: torch.Tensor, y: torch.Tensor, out: torch.Tensor, M: int, N: int, p: float, seed: int, site: int):
+    """y = dropout(x) (the mask of mxl_dropout_bf16) and out[n] += column sums of y, one pass"""
+    check(lib().mxl_dropout_colsum_bf16(_p(x), _p(y), _p(out), M, N, float(p), seed, site, _stream()), 'mxl_dropout_colsum_bf16')
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int] = None):
     check(lib().mxl_colsum_bf16(_p(x), _p(out), M, N, ld if ld is not None else x.stride(-2), _stream()), 'mxl_colsum_bf16')
     return out

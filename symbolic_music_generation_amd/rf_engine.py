@@ -425,12 +425,12 @@ class RFEngine:
             kind = c.attn_layers[l]
             x1, x2, y1 = ws.x1[l], ws.x2[l], ws.x1[l + 1]
             # ---- y2 = x2 + drop(a W2^T + b2)
-            if p > 0:
-                ops.dropout(g2, t1, p, seed=seed, site=self._site(l, 3))
+            if p > 0:       # the forward's mask regenerated and the bias gradient (column sums of the masked gradient) in one pass
+                ops.dropout_colsum(g2, t1, gl(l, 'feed_forward.output.dense.bias'), N, d, p, seed, self._site(l, 3))
                 dff = t1
             else:
                 dff = g2
-            ops.colsum(dff, gl(l, 'feed_forward.output.dense.bias'), N, d)
+                ops.colsum(dff, gl(l, 'feed_forward.output.dense.bias'), N, d)
             ops.gemm(dff, ws.a[l], gl(l, 'feed_forward.output.dense.weight'), d, Fi, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, Fi))
             if ws.rmask is not None:
