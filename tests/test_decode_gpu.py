@@ -356,6 +356,8 @@ def test_two_lane_decoder_equals_single_decoder(dev):
     one = XLDecoder(m.engine, 32, 128, seed=3).generate(prompt, 100, do_sample=False, use_graph=True)
     two = XLDecoderLanes(m.engine, 32, 128, seed=3, lanes=2).generate(prompt, 100, do_sample=False, use_graph=True)
     assert torch.equal(one, two)
+    three = XLDecoderLanes(m.engine, 32, 128, seed=3, lanes=3)          # uneven lanes: 11 + 11 + 10 rows
+    assert three.sizes == [11, 11, 10] and torch.equal(three.generate(prompt, 100, do_sample=False, use_graph=True), one)
     out = m.generate(input_ids=prompt, max_length=100, do_sample=False)
     assert type(m._decoder).__name__ == 'XLDecoderLanes' and torch.equal(out, one)
     kw = dict(max_length=90, do_sample=True, top_k=8, top_p=0.9)
