@@ -157,6 +157,39 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
                               const float* lse, const float* delta, float scale, int Kc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Round 4: the attention backward as ONE pass over the score cells (dh = 64, T % 32 == 0, M % 256 == 0, Kc % 32 == 0;
+ * MXL_EUNSUPPORTED otherwise -- use mxl_relattn_bwd + mxl_relattn_drd).  Same gradients as that pair, no dg tensor:
+ *   a workgroup owns 256 keys of one (sequence, head): dk, dv written once; d_rd accumulated on chip per 32-distance block and
+ *   added with float atomics (d_rd (M, drd_ld) f32, +=); the partial dq of every (query tile, key block) pair goes to an fp32
+ *   slab in `ws` (mxl_relattn_bwd_fused_ws_bytes) and a finishing kernel sums a query's slabs and rounds dq to bf16 once.
+ *   d_r_w_bias, d_r_r_bias (H, 64) f32 are accumulated (+=), each with its own gradient (no fix-up pass).
+ * Zero memories (Kc < M + T; musicnlp/models/transformer_xl.py:163-171 calls the model without mems, so upstream init_mems
+ * supplies zeros): the key positions below the first stored one have k = v = 0 and exist only as distances.  Their part of dq
+ * is  -scale * delta_i * 2^(mph_i - lse_i * log2 e) * oph_i  with oph / mph from mxl_relattn_fwd_phantom2(..., oph_all = 1)
+ * (required then), and their part of d_rd is owed by the caller: mxl_relattn_drd_phantom.  With Kc == M + T oph / mph are unused.
+ * `delta` (B,H,T) f32 scratch is written.  dq_rs, dq_bs multiples of 8. */
+size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M);
+int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                          const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                          void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
+                          const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
+                          long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                          long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream);
+/* mxl_relattn_fwd_phantom with a choice of which phantom cells enter oph: oph_all = 0 is mxl_relattn_fwd_phantom (the
+ * all-phantom 256-distance blocks, for mxl_relattn_bwd_sparse_dg_oph); oph_all = 1 sums over EVERY key position below the first
+ * stored key tile (for mxl_relattn_bwd_fused; needs (T - Kc) % 64 == 0). */
+int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                             const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, int B, int T, int H,
+                             int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                             long long o_bs, int o_rs, float scale, void* stream);
+/* d_rd[delta, h*64 + e] += sum over the PHANTOM cells (key position i - delta below T - Kc) of dG[b,h,i,delta] * qr[b,i,h,e],
+ * with dG rebuilt on MFMA from qr = (q + r_r_bias) (bf16), rd, lse, delta as in mxl_relattn_drd_recompute -- cell by cell, so
+ * that together with mxl_relattn_bwd_fused every (query, distance) pair is counted once.  (T - Kc) % 64 == 0. */
+int mxl_relattn_drd_phantom(const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs, int qr_rs,
+                            int drd_ld, const void* rd, int rd_rs, const float* lse, const float* delta, float scale, int Kc,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.
  * ---------------------------------------------------------------------------------------------------------- */
 /* upstream PositionalEmbedding + drop(pos_emb): out[dist][0:d/2]=sin, [d/2:d]=cos of min(dist,clamp)*inv_freq; (M,d) bf16 */
@@ -448,7 +481,9 @@ int mxl_find_token(const void* ids, int ld_ids, int B, int T, long long token, i
 #define MXL_KT_RELATTN_DKV   3   /* relattn_bwd_dkv_kernel                              */
 #define MXL_KT_RELATTN_DRD   4   /* relattn_drd_kernel                                  */
 #define MXL_KT_ROWBIAS       5   /* add_rowbias (the q + r_r_bias operand of the dRd contraction) */
-#define MXL_KT_COUNT         6
+#define MXL_KT_RELATTN_FUSED 6   /* relattn_bwd_fused_kernel (mxl_relattn_bwd_fused)    */
+#define MXL_KT_RELATTN_DQFIN 7   /* relattn_dq_finish_kernel (mxl_relattn_bwd_fused)    */
+#define MXL_KT_COUNT         8
 int mxl_ktime_enable(int on);
 /* waits for every recorded event, adds each kernel's elapsed milliseconds into ms_sum[id] and its launch count into
  * launches[id] (HOST arrays of n >= MXL_KT_COUNT entries, overwritten), and forgets the recorded events */

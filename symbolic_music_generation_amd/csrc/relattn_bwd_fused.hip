@@ -1,0 +1,697 @@
+// K4 backward, fused key-owner form (round 4): ONE pass over the score cells for every gradient of the banded relative-position
+// attention (forward statement: relattn_fwd.hip; the three-kernel form this replaces at dh = 64: relattn_bwd.hip).
+//
+// With raw = AC + BD, P = exp(raw * scale - lse), dP[i,p] = dO_i . v_p, delta_i = dO_i . O_i, dS = scale * P * (dP - delta):
+//     dv_p = sum_i P[i,p] dO_i            dk_p = sum_i dS[i,p] (q_i + r_w_bias)
+//     dq_i = sum_p dS[i,p] k_p + sum_d dG[i,d] Rd[d]            dG[i,d] = dS[i, i-d]   (the un-skewed score gradient)
+//     dRd[d] = sum_{b,i} dG[i,d] (q_i + r_r_bias)               d r_w_bias = sum_i dQw_i,  d r_r_bias = sum_i dQr_i
+//
+// The three-kernel form computes the scores twice (query-owner for dq and dG, key-owner for dk and dv: 10 score-sized MFMA
+// products per cell for 6 algorithmic ones) and sends dG (B,H,T,M) through HBM to a third, streaming kernel for dRd: 3.8 GB
+// written + 3.2 GB read per layer at the bench shape.  Here a workgroup owns 256 keys of one (sequence, head) and sweeps the
+// 32-query tiles that see them (exactly M keys per query):
+//   * S and dP once, key on the lane (wave w = keys 32w .. 32w+31): their accumulators ARE the B operands of dV^T += dO^T P and
+//     dK^T += Qw^T dS, which stay in registers for the whole sweep -- dk, dv are written once, no atomics.
+//   * dS crosses LDS once, in two images: X[key][query] (straight, 8-byte writes) and Y[query][distance - dlo] (un-skewed, 16-bit
+//     writes at lane-constant + immediate addresses: the rel-shift).  After the barrier every wave forms one 16 x 16 piece of
+//     dq[32 queries][64] = X^T K + Y Rd over the whole contraction (256 keys + 288 distances, v_mfma_f32_16x16x32_bf16), so the
+//     8 waves' pieces need no sum: the tile's partial dq goes out with plain stores into a per-key-block fp32 slab, and
+//     relattn_dq_finish_kernel adds the (at most M/256 + 1) slabs of a query, the forward's phantom value-sum term, rounds to
+//     bf16 once.  Plain stores run 4-5x the float-atomic rate (MI355X_MICROARCH.md, Global float atomics) and the sum is
+//     reproducible.
+//   * dG never leaves the chip.  The 32-distance blocks of the tile's window slide down by one block per query tile; wave w
+//     keeps the fp32 accumulator of "its" block -- the one whose index is w mod 8 -- for the nine tiles the block stays in the
+//     window (dRd_blk += Y_blk^T Qr, 4 MFMAs per tile), then adds it to d_rd with 32 float atomic instructions (two 128-byte
+//     segments each) and takes the next block of its residue class: 8 KB of atomics per workgroup and tile, 1.8 GB per layer
+//     at the bench shape instead of the 7 GB round trip of dG, and no third kernel.
+//   * the positional term G = Qr Rd^T of the NEXT query tile is formed (nine 32 x 32 blocks over the eight waves) while this
+//     tile's dq / dRd products run, into an fp16 skew buffer that the score phase reads at column (query - key) with sixteen
+//     immediate-offset 16-bit reads.
+// Score-sized MFMA products per cell: S, dP, G, dV, dK, dQw, dQr, dRd = 8 for 8 algorithmic ones (the old form: 10 + the
+// streaming contraction).
+//
+// Zero memories (the reference's training, mode R): key positions below the first stored one exist only as distances.  Their
+// part of dq comes from the forward's value-sum over ALL such cells (mxl_relattn_fwd_phantom2, oph_all = 1), added by the
+// finishing kernel; their part of d_rd is rebuilt on MFMA from q, rd, lse, delta by mxl_relattn_drd_phantom (relattn_bwd.hip).
+#include <type_traits>
+#include "common.h"
+#include "musicxl_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KBLK = 256;                       // keys per workgroup
+constexpr int QT = 32;                          // queries per tile
+constexpr int ROWB = 128;                       // bytes per 64-element bf16 row
+constexpr int K_BYTES = KBLK * ROWB;            // K image                      32 KB
+constexpr int RING_BLKS = 10;                   // Rd ring: ten 32-row blocks   40 KB (nine of a window + the next tile's new one)
+constexpr int RBLK_BYTES = 32 * ROWB;
+constexpr int RING_BYTES = RING_BLKS * RBLK_BYTES;
+constexpr int QIMG = QT * ROWB;
+constexpr int QSET = 3 * QIMG + 2 * QT * 4;     // Qw, Qr, dO images + -lse (log2) + -scale*delta          12.25 KB, two sets
+constexpr int GP = 584;                         // fp16 skew buffer pitch (bytes): 288 columns + pad; 146 dwords = 2 mod 16
+constexpr int G_BYTES = QT * GP;
+constexpr int X_BYTES = KBLK * 64;              // X[key][32 queries] bf16
+constexpr int YP = 592;                         // Y[query][288 columns + pad] bf16: 148 dwords = 20 mod 64 (16-byte row reads conflict-free)
+constexpr int Y_BYTES = QT * YP;
+constexpr int BIAS_BYTES = 2 * 64 * 4;
+constexpr int SMEM = K_BYTES + RING_BYTES + 2 * QSET + G_BYTES + X_BYTES + Y_BYTES + BIAS_BYTES;   // 153 344 B: one workgroup per CU
+constexpr int RING_OFF = 10240;                 // multiple of RING_BLKS added to (possibly negative) block indices before the modulo
+
+struct FusedP {
+    const bf16_t *q, *k, *v, *rd, *dout;
+    const float *rwb, *rrb, *lse, *delta;
+    bf16_t *dk, *dv;
+    float* slab;          // [nslot][B][T][H*64] fp32 partial dq, slot = key block - first key block that sees the query tile
+    float* drd;           // (M, drd_ld) fp32, +=
+    float *d_rwb, *d_rrb; // (H, 64) fp32, +=  (the stored keys' part)
+    int B, T, H, M, Kc;
+    long long q_bs, kv_bs, o_bs, dkv_bs, slab_stride;
+    int q_rs, kv_rs, rd_rs, o_rs, dkv_rs, drd_ld;
+    float scale, scale_log2e;
+};
+
+// Q-set images: [32][64] bf16, 16-byte chunk c of row at (c ^ ((row >> 1) & 7)) -- the layout of relattn_bwd.hip's key-owner kernel
+__device__ __forceinline__ int qoff(int row, int ch) { return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int qeoff(int row, int e) { return qoff(row, e >> 3) + ((e & 7) << 1); }
+// K image and Rd ring: chunk c of a row at c ^ s(row), s = (bit 3, bit 1, bit 2) of the row index.  A bijection of bits 1..3, so
+// 16-byte row reads by 16 different rows hit 64 different banks; and for the transposed 8-byte reads of a 16x16x32 B fragment
+// (rows 8g + q (+4), 4 columns per lane) the two bits that separate the four row pairs of a half-wave land in chunk bits 1, 2.
+__device__ __forceinline__ int sswz(int row) { return (((row >> 3) & 1) << 2) | (((row >> 1) & 1) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int soff(int row, int ch) { return row * ROWB + ((ch ^ sswz(row)) << 4); }
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+
+// sixteen genuine 16-bit LDS reads: register j belongs to query ii = pat(j) + 4 hh, pat(j) = (j & 3) + 8 (j >> 2), and needs
+// column ii + 256 - kloc of row ii of the skew buffer: lane base + pat(j) * (GP + 2)
+__device__ __forceinline__ void gskew_read16(uint32_t base, uint32_t (&u)[16]) {
+    static_assert(GP == 584, "offsets below are pat(j) * (GP + 2)");
+    asm volatile(
+        "ds_read_u16 %0, %16\n\t"               "ds_read_u16 %1, %16 offset:586\n\t"    "ds_read_u16 %2, %16 offset:1172\n\t"
+        "ds_read_u16 %3, %16 offset:1758\n\t"   "ds_read_u16 %4, %16 offset:4688\n\t"   "ds_read_u16 %5, %16 offset:5274\n\t"
+        "ds_read_u16 %6, %16 offset:5860\n\t"   "ds_read_u16 %7, %16 offset:6446\n\t"   "ds_read_u16 %8, %16 offset:9376\n\t"
+        "ds_read_u16 %9, %16 offset:9962\n\t"   "ds_read_u16 %10, %16 offset:10548\n\t" "ds_read_u16 %11, %16 offset:11134\n\t"
+        "ds_read_u16 %12, %16 offset:14064\n\t" "ds_read_u16 %13, %16 offset:14650\n\t" "ds_read_u16 %14, %16 offset:15236\n\t"
+        "ds_read_u16 %15, %16 offset:15822\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
+          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
+        : "v"(base)
+        : "memory");
+}
+// the mirror image for dS into Y: w[m] holds (value 2m, value 2m + 1) as a bf16 pair; lane base + pat(j) * (YP + 2)
+__device__ __forceinline__ void yskew_write16(uint32_t base, const uint32_t (&w)[8]) {
+    static_assert(YP == 592, "offsets below are pat(j) * (YP + 2)");
+    asm volatile(
+        "ds_write_b16 %8, %0\n\t"               "ds_write_b16_d16_hi %8, %0 offset:594\n\t"
+        "ds_write_b16 %8, %1 offset:1188\n\t"   "ds_write_b16_d16_hi %8, %1 offset:1782\n\t"
+        "ds_write_b16 %8, %2 offset:4752\n\t"   "ds_write_b16_d16_hi %8, %2 offset:5346\n\t"
+        "ds_write_b16 %8, %3 offset:5940\n\t"   "ds_write_b16_d16_hi %8, %3 offset:6534\n\t"
+        "ds_write_b16 %8, %4 offset:9504\n\t"   "ds_write_b16_d16_hi %8, %4 offset:10098\n\t"
+        "ds_write_b16 %8, %5 offset:10692\n\t"  "ds_write_b16_d16_hi %8, %5 offset:11286\n\t"
+        "ds_write_b16 %8, %6 offset:14256\n\t"  "ds_write_b16_d16_hi %8, %6 offset:14850\n\t"
+        "ds_write_b16 %8, %7 offset:15444\n\t"  "ds_write_b16_d16_hi %8, %7 offset:16038"
+        :
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(base)
+        : "memory");
+}
+__device__ __forceinline__ float add_f16(float s, uint32_t h16) {     // s + (float)h in ONE VALU issue
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(h16));
+    return r;
+}
+__device__ __forceinline__ bf16x8 tr_pair(const char* lo_p, const char* hi_p) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)lo_p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)hi_p);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+// delta[b,h,i] = sum_e dO[b,i,h,e] * O[b,i,h,e]   (dh = 64: 8 lanes per head, one wave per token row per sweep of 8 heads)
+__global__ __launch_bounds__(256) void fused_delta_kernel(const bf16_t* o, const bf16_t* dout, float* delta, int B, int T, int H,
+                                                          long long o_bs, int o_rs) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / T, i = row % T;
+    const bf16_t* op = o + (size_t)b * o_bs + (size_t)i * o_rs;
+    const bf16_t* dp = dout + (size_t)b * o_bs + (size_t)i * o_rs;
+    const int chunks = H * 8;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        float s = 0.f;
+        if (c < chunks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(op + c * 8);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)d[j]);
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (c < chunks && (lane & 7) == 0) delta[((size_t)b * H + (c >> 3)) * T + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sR = sK + K_BYTES;
+    char* sQ = sR + RING_BYTES;
+    char* sG = sQ + 2 * QSET;
+    char* sX = sG + G_BYTES;
+    char* sY = sX + X_BYTES;
+    float* sBias = reinterpret_cast<float*>(sY + Y_BYTES);       // r_w_bias[64], r_r_bias[64] of this head
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, r = l & 31, hh = l >> 5;
+    int bx_, h, b;
+    xcd_block(bx_, h, b);
+    const int T = p.T, M = p.M;
+    const int p0 = T - p.Kc;                    // lowest stored key position (a multiple of 32)
+    const int P0 = p0 + KBLK * bx_;             // first key position of the workgroup
+    const int Pw = P0 + 32 * w;
+    const int kloc = 32 * w + r;
+    const int pk = Pw + r;                      // this lane's key position
+    const bool kok = pk < T;
+    const int MB = M >> 5;
+
+    const bf16_t* qbase = p.q + (size_t)b * p.q_bs + (size_t)h * 64;
+    const bf16_t* dobase = p.dout + (size_t)b * p.o_bs + (size_t)h * 64;
+    const bf16_t* rbase = p.rd + (size_t)h * 64;
+    const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * 64;
+    const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * 64;
+
+    // ---- lane constants.  gq / q4 / pp: the decomposition the transposed 8-byte reads use (16 lanes read 4 rows x 16 columns)
+    const int gq = l >> 4, q4 = (l & 15) >> 2, pp = l & 3;
+    const int rowq = qoff(r, hh);                                  // Q-set row fragment, k-step ks: rowq ^ (ks << 5)
+    const int rows = r * ROWB + ((hh ^ sswz(r)) << 4);             // ring row fragment,   k-step ks: rows ^ (ks << 5)
+    const int tk0 = qeoff(4 * hh + q4, 16 * (gq & 1) + 4 * pp);    // Q-set transposed pattern (relattn_bwd.hip, tk0)
+    const uint32_t gRb = lds_addr(sG) + 4 * hh * (GP + 2) + (256 - kloc) * 2;
+    const uint32_t yWb = lds_addr(sY) + 4 * hh * (YP + 2) + (256 - kloc) * 2;
+    // X[key][query]: 8-byte granule g of row p at g ^ ((p >> 1) & 7): this lane's group `grp` (queries 8 grp + 4 hh ..) at xw ^ (grp << 4)
+    const int xf = (kloc >> 1) & 7;
+    const int xw = kloc * 64 + ((((hh ^ (xf & 1)) | (xf & 6))) << 3);
+    const int ya0 = (4 * hh + q4) * YP + (16 * (gq & 1) + 4 * pp) * 2;          // Y transposed pattern (32x32x16 A fragment of dRd)
+    // 16 x 16 piece of dq this wave forms: queries 16 ih .., elements 16 eq ..
+    const int ih = w & 1, eq = w >> 1;
+    const int g16 = l >> 4, q16 = (l & 15) >> 2;                   // 16x16x32 transposed pattern: rows 8 g16 + q16 (+4), 4 columns at 4 pp
+    const int xa0 = (8 * g16 + q16) * 64 + (((4 * ih + pp) ^ ((4 * g16 + (q16 >> 1)) & 7)) << 3);
+    const int xa1 = (8 * g16 + q16 + 4) * 64 + (((4 * ih + pp) ^ ((4 * g16 + 2 + (q16 >> 1)) & 7)) << 3);
+    const int kch = 2 * eq + (pp >> 1);
+    const int ksw = ((g16 & 1) << 2) | (((q16 >> 1) & 1) << 1);
+    const int ka0 = (8 * g16 + q16) * ROWB + ((kch ^ ksw) << 4) + ((pp & 1) << 3);
+    const int ka1 = (8 * g16 + q16 + 4) * ROWB + ((kch ^ (ksw | 1)) << 4) + ((pp & 1) << 3);
+    const int yq0 = (16 * ih + (l & 15)) * YP + 16 * g16;          // Y row fragment (16x16x32 A): row = query, 8 columns at 8 g16
+
+    // ---- prologue: biases, K image, Y zeroed, K / V fragments (B operands: lane = key, k = 16 ks + 8 hh + j)
+    if (tid < 128) sBias[tid] = (tid < 64) ? p.rwb[h * 64 + tid] : p.rrb[h * 64 + tid - 64];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int c = tid + n * 512;
+        const int row = c >> 3, ch = c & 7;
+        const int srow = KBLK * bx_ + row;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (srow < p.Kc) val = *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8);
+        *reinterpret_cast<u32x4*>(sK + soff(row, ch)) = val;
+    }
+    for (int i = tid; i < Y_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(sY)[i] = u32x4{0u, 0u, 0u, 0u};
+    bf16x8 kf[4], vf[4];
+    {
+        const size_t srow = (size_t)(kok ? pk - p0 : 0);
+        const bf16_t* kp = kbase + srow * p.kv_rs;
+        const bf16_t* vp = vbase + srow * p.kv_rs;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * hh);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { kf[ks][j] = kok ? kv[j] : (short)0; vf[ks][j] = kok ? vv[j] : (short)0; }
+        }
+    }
+
+    // queries that can see any key of this workgroup: i in [P0, P0 + 255 + M - 1], clipped to [0, T)
+    const int i_lo = max(P0, 0), i_hi = min(P0 + KBLK - 1 + M - 1, T - 1);
+    const int it_lo = i_lo >> 5, it_hi = i_hi >> 5;
+
+    // ---- staging: waves 0-3 take the q rows of a tile (-> Qw, Qr images), waves 4-7 its dO rows and the new Rd block
+    u32x4 tq = {0u, 0u, 0u, 0u}, rr = {0u, 0u, 0u, 0u};
+    float tl = 0.f;
+    const int t2 = tid & 255, srow_ = t2 >> 3, sch_ = t2 & 7;
+    auto load_q = [&](int it) {
+        const int I = it * QT;
+        const size_t qi = (size_t)min(I + srow_, T - 1);
+        if (tid < 256) tq = *reinterpret_cast<const u32x4*>(qbase + qi * p.q_rs + sch_ * 8);
+        else tq = *reinterpret_cast<const u32x4*>(dobase + qi * p.o_rs + sch_ * 8);
+        if (tid < 64) {
+            const size_t sidx = ((size_t)b * p.H + h) * T + min(I + (tid & 31), T - 1);
+            tl = (tid < 32) ? p.lse[sidx] : p.delta[sidx];
+        }
+    };
+    auto store_q = [&](int buf) {
+        char* sQw = sQ + buf * QSET;
+        char* sQr = sQw + QIMG;
+        char* sDO = sQr + QIMG;
+        float* sLse = reinterpret_cast<float*>(sDO + QIMG);
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
+        if (tid < 256) {
+            u32x4 ww, wr;
+            bf16_t* dw = reinterpret_cast<bf16_t*>(&ww);
+            bf16_t* dr = reinterpret_cast<bf16_t*>(&wr);
+            const f32x4 bw0 = *reinterpret_cast<const f32x4*>(sBias + sch_ * 8), bw1 = *reinterpret_cast<const f32x4*>(sBias + sch_ * 8 + 4);
+            const f32x4 br0 = *reinterpret_cast<const f32x4*>(sBias + 64 + sch_ * 8), br1 = *reinterpret_cast<const f32x4*>(sBias + 64 + sch_ * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {     // operand scaling as in relattn_fwd.hip: the recomputed scores match its LSE bit for bit
+                const float qf = bf2f(src[j]);
+                const float bw = j < 4 ? bw0[j & 3] : bw1[j & 3], br = j < 4 ? br0[j & 3] : br1[j & 3];
+                dw[j] = f2bf((qf + bw) * p.scale_log2e);
+                dr[j] = f2bf((qf + br) * p.scale_log2e);
+            }
+            *reinterpret_cast<u32x4*>(sQw + qoff(srow_, sch_)) = ww;
+            *reinterpret_cast<u32x4*>(sQr + qoff(srow_, sch_)) = wr;
+        } else {
+            u32x4 wd;
+            bf16_t* dd = reinterpret_cast<bf16_t*>(&wd);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dd[j] = f2bf(bf2f(src[j]) * p.scale);
+            *reinterpret_cast<u32x4*>(sDO + qoff(srow_, sch_)) = wd;
+        }
+        if (tid < 32) sLse[tid] = -tl * LOG2E;
+        else if (tid < 64) sLse[tid] = -p.scale * tl;            // sDl = sLse + 32
+    };
+    auto load_r = [&](int n) {                  // 32 Rd rows of distance block n (row index clamped: out-of-range cells are masked)
+        if (tid >= 256) {
+            int d = 32 * n + srow_;
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            rr = *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + sch_ * 8);
+        }
+    };
+    auto store_r = [&](int n) {
+        if (tid >= 256) {
+            const int slot = (n + RING_OFF) % RING_BLKS;
+            *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = rr;
+        }
+    };
+    // G^T block j of the window whose first block index is n0 (lane = query, registers = distances) -> fp16 skew buffer
+    auto gblock = [&](int j, int n0, const char* sQr) {
+        f32x16 g;
+#pragma unroll
+        for (int t = 0; t < 16; t++) g[t] = 0.f;
+        const char* rb = sR + ((n0 + j + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+            const bf16x8 bq = *reinterpret_cast<const bf16x8*>(sQr + (rowq ^ (ks << 5)));
+            g = mfma32(a, bq, g);
+        }
+        char* gw = sG + r * GP + (32 * j + 4 * hh) * 2;
+#pragma unroll
+        for (int grp = 0; grp < 4; grp++) {
+            const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+            *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
+        }
+    };
+    auto gblocks = [&](int I, const char* sQr) {        // the nine blocks of the tile at I: wave w takes block w, wave 0 also block 8
+        const int n0 = (I - P0 - KBLK) >> 5;
+        gblock(w, n0, sQr);
+        if (w == 0) gblock(8, n0, sQr);
+    };
+
+    {
+        const int n0 = (it_lo * QT - P0 - KBLK) >> 5;
+        load_q(it_lo);
+        __syncthreads();                        // biases in LDS
+        store_q(0);
+        // the nine Rd blocks of the first window: 9 x 256 sixteen-byte chunks over all 512 threads, loads first
+        u32x4 pr_[5];
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            const int c = tid + n * 512;
+            int d = 32 * n0 + (c >> 3);
+            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+            pr_[n] = (c < 9 * 256) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + (c & 7) * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            const int c = tid + n * 512;
+            if (c < 9 * 256) {
+                const int slot = (n0 + (c >> 8) + RING_OFF) % RING_BLKS;
+                *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff((c >> 3) & 31, c & 7)) = pr_[n];
+            }
+        }
+    }
+    __syncthreads();
+    gblocks(it_lo * QT, sQ + QIMG);
+    __syncthreads();
+
+    f32x16 ak[2], av[2], rd_acc[2];             // dK^T, dV^T : [e][key];  dRd block : [distance][e]
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; rd_acc[e][j] = 0.f; }
+    int acc_n = -1000000;                       // distance block whose sum rd_acc holds (none yet)
+    float cw = 0.f, cr = 0.f;                   // running column sums of this wave's dQw / dQr pieces (d r_w_bias / d r_r_bias)
+
+    auto drd_flush = [&]() {
+        if (acc_n >= 0 && acc_n < MB) {
+            const float f = 1.f / p.scale_log2e;            // the Qr image carries scale * log2(e)
+            float* dst = p.drd + (size_t)(32 * acc_n + 4 * hh) * p.drd_ld + h * 64 + r;
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    atomicAdd(dst + (size_t)((j & 3) + 8 * (j >> 2)) * p.drd_ld + 32 * e, rd_acc[e][j] * f);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) rd_acc[e][j] = 0.f;
+    };
+
+    int cur = 0;
+#pragma unroll 1
+    for (int it = it_lo; it <= it_hi; it++) {
+        const int I = it * QT;
+        const bool more = it < it_hi;
+        const char* sQw = sQ + cur * QSET;
+        const char* sQr = sQw + QIMG;
+        const char* sDO = sQr + QIMG;
+        const float* sLse = reinterpret_cast<const float*>(sDO + QIMG);
+        const float* sDl = sLse + QT;
+        const int n0 = (I - P0 - KBLK) >> 5;    // first distance block of this tile's window: column c = distance - 32 n0
+        if (more) { load_q(it + 1); load_r(n0 + 9); }
+
+        // =============================== phase A: scores, dV, dK, dS -> X / Y ===============================
+        const int dmin_w = I - Pw - 31, dmax_w = I + 31 - Pw;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pw < T);
+        if (active) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                const f32x4 cl = *reinterpret_cast<const f32x4*>(sLse + 8 * grp + 4 * hh);
+                const f32x4 cd = *reinterpret_cast<const f32x4*>(sDl + 8 * grp + 4 * hh);
+#pragma unroll
+                for (int t = 0; t < 4; t++) { s[4 * grp + t] = cl[t]; dp[4 * grp + t] = cd[t]; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQw + (rowq ^ (ks << 5)));
+                s = mfma32(a, kf[ks], s);
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sDO + (rowq ^ (ks << 5)));
+                dp = mfma32(ad, vf[ks], dp);
+            }
+            uint32_t bdu[16];
+            gskew_read16(gRb, bdu);
+            const bool full = __builtin_amdgcn_readfirstlane(
+                (int)((dmin_w >= 0) && (dmax_w <= M - 1) && (Pw + 31 < T))) != 0;
+            f32x16 pr;
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
+                    pr[j] = pv;
+                    s[j] = pv * dp[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const int d = I + ii - pk;
+                    const bool valid = (d >= 0) && (d <= M - 1) && kok;
+                    const float pv = valid ? __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j])) : 0.f;
+                    pr[j] = pv;
+                    s[j] = valid ? pv * dp[j] : 0.f;
+                }
+            }
+            uint32_t dsw[8];          // dS as bf16 pairs (2m, 2m + 1): MFMA operand and the source of both LDS images
+#pragma unroll
+            for (int m = 0; m < 8; m++) dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]);
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++)
+                *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{dsw[2 * grp], dsw[2 * grp + 1]};
+            yskew_write16(yWb, dsw);
+            // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order)
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const u32x4 pw = {pack2bf(pr[8 * st], pr[8 * st + 1]), pack2bf(pr[8 * st + 2], pr[8 * st + 3]),
+                                  pack2bf(pr[8 * st + 4], pr[8 * st + 5]), pack2bf(pr[8 * st + 6], pr[8 * st + 7])};
+                const u32x4 dw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), df = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const char* a0 = sDO + 16 * st * ROWB + tk0;
+                    const bf16x8 a1 = tr_pair(a0 + 64 * e, a0 + 8 * ROWB + 64 * (1 - e));
+                    av[e] = mfma32(a1, pf, av[e]);
+                    const char* c0 = sQw + 16 * st * ROWB + tk0;
+                    const bf16x8 a2 = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
+                    ak[e] = mfma32(a2, df, ak[e]);
+                }
+            }
+        } else {
+            // no valid cell for this wave's keys in this tile: its rows of X and its cells of Y still have to read as zero
+            const uint32_t z[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{0u, 0u};
+            yskew_write16(yWb, z);
+        }
+        if (more) { store_q(cur ^ 1); store_r(n0 + 9); }
+        __syncthreads();
+
+        // =============================== phase B: dq piece, dRd block, next tile's G ===============================
+        {
+            f32x4 aw4 = {0.f, 0.f, 0.f, 0.f}, ar4 = {0.f, 0.f, 0.f, 0.f};
+            // keys that can hold a non-zero dS in this tile: key position <= I + 31 and >= I - (M - 1)
+            const int u_hi = min(7, (I + 31 - P0) >> 5);
+            const int u_lo = max(0, (I - (M - 1) - P0) >> 5);
+#pragma unroll 1
+            for (int u = u_lo; u <= u_hi; u++) {
+                const bf16x8 a = tr_pair(sX + u * 2048 + xa0, sX + u * 2048 + xa1);
+                const bf16x8 bk = tr_pair(sK + u * 4096 + ka0, sK + u * 4096 + ka1);
+                aw4 = mfma16(a, bk, aw4);
+            }
+            // distance blocks of the window that lie in [0, M)
+            const int v_lo = max(0, -n0), v_hi = min(8, MB - 1 - n0);
+#pragma unroll 1
+            for (int v = v_lo; v <= v_hi; v++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sY + yq0 + v * 64);
+                const char* rb = sR + ((n0 + v + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+                const bf16x8 br = tr_pair(rb + ka0, rb + ka1);
+                ar4 = mfma16(a, br, ar4);
+            }
+            // this tile's partial dq -> slab of this key block (rows = queries 16 ih + 4 (l >> 4) + t, column = element)
+            {
+                const int x = I - M - 254 - p0;
+                const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
+                float* dst = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride +
+                             ((size_t)b * T + I + 16 * ih + 4 * g16) * (size_t)(p.H * 64) + h * 64 + 16 * eq + (l & 15);
+#pragma unroll
+                for (int t = 0; t < 4; t++) dst[(size_t)t * (p.H * 64)] = aw4[t] + ar4[t];
+                cw += (aw4[0] + aw4[1]) + (aw4[2] + aw4[3]);
+                cr += (ar4[0] + ar4[1]) + (ar4[2] + ar4[3]);
+            }
+            // dRd: the block of this wave's residue class.  Window position j0 = (w - n0) mod 8; at 0 the block leaves the window
+            // after this tile (flush) and the class's next block enters at position 8.
+            auto drd_block = [&](int j) {
+                const int n = n0 + j;
+                if (n < 0 || n >= MB) return;
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    const char* ya = sY + ya0 + 16 * st * YP + 64 * j;
+                    const bf16x8 a = tr_pair(ya, ya + 8 * YP);
+                    const char* c0 = sQr + 16 * st * ROWB + tk0;
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const bf16x8 bq = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
+                        rd_acc[e] = mfma32(a, bq, rd_acc[e]);
+                    }
+                }
+            };
+            const int j0 = (w - n0) & 7;
+            if (j0 == 0) {
+                acc_n = n0;                     // (at the wave's first tile the accumulator is still empty)
+                drd_block(0);
+                drd_flush();
+                acc_n = n0 + 8;
+                drd_block(8);
+            } else {
+                acc_n = n0 + j0;
+                drd_block(j0);
+            }
+            if (more) gblocks(I + QT, sQ + (cur ^ 1) * QSET + QIMG);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    drd_flush();
+
+    // ---- epilogue: bias gradients (stored keys' part), dk, dv
+    {
+        float a = cw, c = cr;
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+        if (l < 16) {
+            atomicAdd(p.d_rwb + h * 64 + 16 * eq + l, a);
+            atomicAdd(p.d_rrb + h * 64 + 16 * eq + l, c);
+        }
+    }
+    {
+        const float fk = 1.f / p.scale_log2e, fv = 1.f / p.scale;      // dK was accumulated against scale*log2(e)*Qw, dV against scale*dO
+        if (kok) {
+            const size_t srow = (size_t)(pk - p0);
+            bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
+            bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const int e0 = 32 * e + 8 * grp + 4 * hh;
+                    const u32x2 wk = {pack2bf(ak[e][4 * grp] * fk, ak[e][4 * grp + 1] * fk), pack2bf(ak[e][4 * grp + 2] * fk, ak[e][4 * grp + 3] * fk)};
+                    const u32x2 wv = {pack2bf(av[e][4 * grp] * fv, av[e][4 * grp + 1] * fv), pack2bf(av[e][4 * grp + 2] * fv, av[e][4 * grp + 3] * fv)};
+                    *reinterpret_cast<u32x2*>(dkp + e0) = wk;
+                    *reinterpret_cast<u32x2*>(dvp + e0) = wv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dq[b,i,:] = bf16( sum over the key blocks that see query tile i/32 of their slab rows  +  phantom term ),
+// phantom term (zero memories, oph != NULL):  -scale * delta[b,h,i] * 2^(mph[b,h,i] - lse[b,h,i] log2 e) * oph[b,i,h,:]
+// -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Its column sums
+// over (b, i) are those cells' part of d r_r_bias.  One workgroup = one 32-query tile of one sequence, thread = 8 consecutive
+// elements of a 64-element head, rows swept in turn (every slab access is a contiguous run of the row).
+// ---------------------------------------------------------------------------------------------------------------
+struct FinP {
+    const float* slab; const bf16_t* oph; const float *mph, *lse, *delta;
+    bf16_t* dq; float* d_rrb;
+    int B, T, H, M, Kc;
+    long long slab_stride, o_bs, dq_bs; int o_rs, dq_rs;
+    float scale;
+};
+__global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
+    const int it = blockIdx.x, b = blockIdx.y;
+    const int I = it * QT, d = p.H * 64;
+    const int p0 = p.T - p.Kc;
+    const int nkb = (p.Kc + KBLK - 1) / KBLK;
+    const int x = I - p.M - 254 - p0;
+    const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
+    const int kb_hi = min(nkb - 1, (I + 31 - p0) >> 8);
+    const int nsl = kb_hi - kb_lo + 1;
+    const int nch = d >> 3;                              // 8-element chunks per row
+    const int rgs = max(1, 256 / nch);                   // rows in flight per sweep (thread = (row group, chunk))
+    const int rg = threadIdx.x / nch;
+    if (rg < rgs) {
+        const int c = threadIdx.x % nch;
+        const int h = c >> 3;
+        float cs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) cs[j] = 0.f;
+#pragma unroll 1
+        for (int ii = rg; ii < QT; ii += rgs) {
+            const int i = I + ii;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0.f;
+            const float* sp = p.slab + ((size_t)b * p.T + i) * (size_t)d + c * 8;
+            for (int s = 0; s < nsl; s++) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
+            }
+            if (p.oph) {
+                const size_t sidx = ((size_t)b * p.H + h) * p.T + i;
+                const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
+                const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float t = f * bf2f((bf16_t)o[j]);
+                    acc[j] += t;
+                    cs[j] += t;
+                }
+            }
+            const u32x4 wq = {pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+            *reinterpret_cast<u32x4*>(p.dq + (size_t)b * p.dq_bs + (size_t)i * p.dq_rs + c * 8) = wq;
+        }
+        if (p.oph) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) atomicAdd(p.d_rrb + c * 8 + j, cs[j]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M) {
+    if (B <= 0 || T <= 0 || H <= 0 || dh != 64 || M <= 0) return 0;
+    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(float);
+}
+
+extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                     const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
+                                     void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
+                                     const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
+                                     long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
+                                     long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream) {
+    MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv && d_rd && d_r_w_bias &&
+                  d_r_r_bias && ws);
+    if (dh != 64) return MXL_EUNSUPPORTED;
+    MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T && drd_ld >= H * 64);
+    if ((T % 32) != 0 || (M % 256) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
+    // key positions below the first stored one are phantom distances: the caller must have their dq part in oph / mph (zero memories),
+    // unless every visible key is stored (Kc == M + T)
+    MXL_CHECK_ARG(Kc == M + T || (oph && mph));
+    MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 8) == 0 && (dq_rs % 8) == 0 && (dkv_rs % 4) == 0);
+    MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 8) == 0 && (dq_bs % 8) == 0 && (dkv_bs % 4) == 0);
+    MXL_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)rd % 16) == 0 &&
+                  ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dq % 16) == 0 && ((uintptr_t)ws % 16) == 0 &&
+                  (oph == nullptr || ((uintptr_t)oph % 16) == 0));
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DELTA, s);
+        hipLaunchKernelGGL(fused_delta_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, B, T,
+                           H, o_bs, o_rs);
+    }
+    FusedP p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.rd = (const bf16_t*)rd; p.dout = (const bf16_t*)dout;
+    p.rwb = r_w_bias; p.rrb = r_r_bias; p.lse = lse; p.delta = delta;
+    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.slab = ws; p.drd = d_rd; p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
+    p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
+    p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.dkv_bs = dkv_bs; p.slab_stride = (long long)B * T * H * 64;
+    p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dkv_rs = dkv_rs; p.drd_ld = drd_ld;
+    p.scale = scale; p.scale_log2e = scale * LOG2E;
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_FUSED, s);
+        hipLaunchKernelGGL(relattn_bwd_fused_kernel, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
+    }
+    FinP f;
+    f.slab = ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
+    f.dq = (bf16_t*)dq; f.d_rrb = d_r_r_bias;
+    f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
+    f.slab_stride = p.slab_stride; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
+    {
+        mxl_kt::Scope kt(MXL_KT_RELATTN_DQFIN, s);
+        hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3(T / QT, B), dim3(256), 0, s, f);
+    }
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}

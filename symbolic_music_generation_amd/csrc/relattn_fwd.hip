@@ -40,6 +40,9 @@ struct RelAttnP {
     // an elementwise product in the query-owner backward, instead of a second pass over G, exp and an MFMA product there.
     bf16_t* oph;           // (B, T, H*dh) like out, or null
     float* mph;            // (B, H, T) like lse
+    // 1: oph sums over EVERY phantom cell (key position below the first stored key tile) -- what mxl_relattn_bwd_fused consumes;
+    // 0: over the all-phantom 256-distance blocks only (mxl_relattn_bwd_sparse_dg_oph walks the others itself)
+    int oph_all;
 };
 
 constexpr int QB = 128;      // queries per workgroup
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     for (int j = 0; j < 16; j++) { g[j] = __builtin_amdgcn_exp2f(g[j]); rs += g[j]; }   // exp2(NEG_BIG) = 0 for masked cells
                     l_run += rs;
                     // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
-                    if (p.oph && (dblk & ~255) > iw0 + 31 - pz) {
+                    if (p.oph && (p.oph_all || (dblk & ~255) > iw0 + 31 - pz)) {
                         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
                         const char* rb = sR + (dblk & 255) * G::ROWB;      // a multiple of 32 rows: + 0..31 does not wrap
 #pragma unroll
@@ -577,8 +580,9 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
 static int relattn_fwd_launch(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                              float scale, void* oph, float* mph, void* stream) {
+                              float scale, void* oph, float* mph, void* stream, int oph_all = 0) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
+    if (oph_all) MXL_CHECK_ARG(oph && ((T - Kc) % 64) == 0);
     if (oph) MXL_CHECK_ARG(mph && (M % 256) == 0 && (T % 32) == 0 && ((uintptr_t)oph % 8) == 0);
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
@@ -591,7 +595,7 @@ static int relattn_fwd_launch(const void* q, const void* k, const void* v, const
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.oph = (bf16_t*)oph; p.mph = mph;
+    p.oph = (bf16_t*)oph; p.mph = mph; p.oph_all = oph_all ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_fwd<16>(p, s);
@@ -616,4 +620,13 @@ extern "C" int mxl_relattn_fwd_phantom(const void* q, const void* k, const void*
     MXL_CHECK_ARG(oph && mph);
     return relattn_fwd_launch(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
                               o_rs, scale, oph, mph, stream);
+}
+
+extern "C" int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
+                                        const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, int B, int T,
+                                        int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                                        long long o_bs, int o_rs, float scale, void* stream) {
+    MXL_CHECK_ARG(oph && mph);
+    return relattn_fwd_launch(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
+                              o_rs, scale, oph, mph, stream, oph_all);
 }

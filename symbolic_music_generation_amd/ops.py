@@ -57,7 +57,7 @@ def _cut(cutoffs: Sequence[int]):
     return n, arr
 
 
-KT_NAMES = ('fwd', 'delta', 'dq8', 'dkv', 'drd', 'rowbias')      # MXL_KT_* ids of include/musicxl.h
+KT_NAMES = ('fwd', 'delta', 'dq8', 'dkv', 'drd', 'rowbias', 'fused', 'dqfin')      # MXL_KT_* ids of include/musicxl.h
 
 
 def ktime_enable(on: bool):
@@ -232,11 +232,24 @@ def phantom_sum_applies(*, T, dh, M, Kc) -> bool:
             and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0' and os.environ.get('MXL_NO_OPH') != '1')
 
 
+def fused_bwd_applies(*, T, dh, M, Kc) -> bool:
+    """the shapes mxl_relattn_bwd_fused takes (one pass over the score cells, no dG tensor): the training shapes of every
+    BASELINE config; anything else stays on relattn_bwd's three kernels"""
+    return (dh == 64 and T % 32 == 0 and M % 256 == 0 and Kc % 32 == 0 and (T - Kc) % 64 == 0
+            and os.environ.get('MXL_NO_FUSED_BWD') != '1')
+
+
 def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,
-                o_bs, o_rs, scale=None, oph=None, mph=None):
+                o_bs, o_rs, scale=None, oph=None, mph=None, oph_all=False):
     """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements.
-    `oph` (like out) / `mph` (B, H, T) f32: also write the phantom value-sum relattn_bwd(..., oph=, mph=) consumes."""
+    `oph` (like out) / `mph` (B, H, T) f32: also write the phantom value-sum relattn_bwd(..., oph=, mph=) consumes
+    (oph_all: over every phantom cell, the form relattn_bwd_fused consumes)."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    if oph is not None and oph_all:
+        check(lib().mxl_relattn_fwd_phantom2(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), _p(oph),
+                                             _p(mph), 1, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs,
+                                             float(scale), _stream()), 'mxl_relattn_fwd_phantom2')
+        return out
     if oph is not None:
         check(lib().mxl_relattn_fwd_phantom(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), _p(oph),
                                             _p(mph), B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, float(scale),
@@ -431,6 +444,35 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
         launch(b0, n)
         drd(b0, n)
     return (lambda: None) if defer_drd else None
+
+
+def relattn_bwd_fused_ws_numel(B, T, H, dh, M) -> int:
+    """fp32 elements of the partial-dq slabs mxl_relattn_bwd_fused needs"""
+    return int(lib().mxl_relattn_bwd_fused_ws_bytes(B, T, H, dh, M)) // 4
+
+
+def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, d_rd, d_rwb, d_rrb, ws, qr_buf, *,
+                      B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
+                      scale=None, oph=None, mph=None, defer_drd=False):
+    """Backward of relattn_fwd in one pass over the score cells (mxl_relattn_bwd_fused): dq, dk, dv written, d_rd (M, H*dh) f32 /
+    d_rwb / d_rrb accumulated.  With zero memories (Kc < M + T) `oph` / `mph` must come from relattn_fwd(..., oph_all=True), and
+    the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom (needs the (B, T, H*dh) bf16 scratch `qr_buf`)."""
+    scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    d = H * dh
+    check(lib().mxl_relattn_bwd_fused(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse), _p(delta),
+                                      _p(dq), _p(dk), _p(dv), _p(d_rd), d_rd.stride(0), _p(d_rwb), _p(d_rrb), _p(oph), _p(mph), _p(ws),
+                                      B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
+                                      float(scale), _stream()), 'mxl_relattn_bwd_fused')
+
+    def phantom():
+        if Kc < M + T:
+            add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
+            check(lib().mxl_relattn_drd_phantom(_p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d_rd.stride(0), _p(rd), int(rd_rs),
+                                                _p(lse), _p(delta), float(scale), Kc, _stream()), 'mxl_relattn_drd_phantom')
+    if defer_drd:
+        return phantom
+    phantom()
+    return None
 
 
 def relattn_drd(q, r_r_bias, dg, d_rd, qr_buf, *, B, T, H, dh, M, q_bs, q_rs, rd=None, rd_rs=0, d_rrb=None, d_rwb=None,

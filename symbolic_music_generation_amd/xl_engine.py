@@ -218,7 +218,9 @@ class XLEngine:
         ws.lse = [torch.empty(B, H, T, **f32) for _ in range(keep)]
         # zero-memory training: the forward's phantom value-sum per layer (ops.relattn_fwd(..., oph=, mph=)), which spares the
         # query-owner backward its walk over the all-phantom distance blocks
-        use_oph = train and ops.phantom_sum_applies(T=T, dh=c.d_head, M=M, Kc=Kc)
+        # the fused attention backward (ops.relattn_bwd_fused) at the shapes it takes; it wants the value-sum over every phantom cell
+        ws.fused_bwd = train and ops.fused_bwd_applies(T=T, dh=c.d_head, M=M, Kc=Kc)
+        use_oph = train and ((ws.fused_bwd and Kc < M + T) or ops.phantom_sum_applies(T=T, dh=c.d_head, M=M, Kc=Kc))
         ws.oph = [torch.empty(N, d, **bf) for _ in range(keep)] if use_oph else None
         ws.mph = [torch.empty(B, H, T, **f32) for _ in range(keep)] if use_oph else None
         ws.tmp = torch.empty(N, d, **bf)
@@ -243,7 +245,11 @@ class XLEngine:
             ws.dF = torch.empty(N, Fi, **bf)
             ws.dqkv = torch.empty(B, Kc, 3 * d, **bf)
             ws.delta = torch.empty(B, H, T, **f32)
-            ws.dg = torch.empty(B, H, T, M, **bf)
+            if ws.fused_bwd:      # no dG tensor: the partial-dq slabs instead ((M/256 + 1) x (B, T, d) fp32)
+                ws.dg = None
+                ws.dq_slabs = torch.empty(ops.relattn_bwd_fused_ws_numel(B, T, H, c.d_head, M), **f32)
+            else:
+                ws.dg = torch.empty(B, H, T, M, **bf)
             ws.qr = torch.empty(B, T, d, **bf)
             ws.d_rd = torch.empty(M, d, **f32)
             ws.d_rd16 = torch.empty(M, d, **bf)
@@ -313,7 +319,8 @@ class XLEngine:
             ops.relattn_fwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[s],
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
                             ws.av[s], ws.lse[s], oph=ws.oph[s].view(B, T, d) if (train and ws.oph is not None) else None,
-                            mph=ws.mph[s] if (train and ws.oph is not None) else None, **st)
+                            mph=ws.mph[s] if (train and ws.oph is not None) else None,
+                            oph_all=bool(train and getattr(ws, 'fused_bwd', False)), **st)
             ops.gemm(ws.av[s], self._lw(l, 'dec_attn.o_net.weight'), ws.tmp, N, d, d)
             ops.ln_residual_fwd(ws.tmp, h_in, self._lw(l, 'dec_attn.layer_norm.weight', self.P),
                                 self._lw(l, 'dec_attn.layer_norm.bias', self.P), ws.h1[s],
@@ -607,13 +614,22 @@ class XLEngine:
             ops.gemm(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d)   # d attn_vec
             qkv, dqkv = ws.qkv[l], ws.dqkv
             ws.d_rd.zero_()
-            ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
-                            self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
-                            ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
-                            ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
-                            dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr,
-                            oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
-                            mph=ws.mph[l] if ws.oph is not None else None, **st)
+            if ws.fused_bwd:
+                ops.relattn_bwd_fused(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
+                                      self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
+                                      ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
+                                      ws.d_rd, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), ws.dq_slabs, ws.qr,
+                                      dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
+                                      oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
+                                      mph=ws.mph[l] if ws.oph is not None else None, **st)
+            else:
+                ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
+                                self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
+                                ws.dC, ws.lse[l], ws.delta, dqkv[:, Kc - T:, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:],
+                                ws.dg, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), dq_bs=Kc * 3 * d, dq_rs=3 * d,
+                                dkv_bs=Kc * 3 * d, dkv_rs=3 * d, d_rd=ws.d_rd, qr_buf=ws.qr,
+                                oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
+                                mph=ws.mph[l] if ws.oph is not None else None, **st)
             # r_net: dW_r = d_rd^T . phi
             ops.cast_bf16(ws.d_rd, ws.d_rd16)
             ops.gemm(ws.d_rd16, ws.phi_c, gw(l, 'dec_attn.r_net.weight'), d, d, M, trans_a=True, trans_b=True, flags=AT,
