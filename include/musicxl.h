@@ -184,10 +184,12 @@ int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const 
                              long long o_bs, int o_rs, float scale, void* stream);
 /* d_rd[delta, h*64 + e] += sum over the PHANTOM cells (key position i - delta below T - Kc) of dG[b,h,i,delta] * qr[b,i,h,e],
  * with dG rebuilt on MFMA from qr = (q + r_r_bias) (bf16), rd, lse, delta as in mxl_relattn_drd_recompute -- cell by cell, so
- * that together with mxl_relattn_bwd_fused every (query, distance) pair is counted once.  (T - Kc) % 64 == 0. */
+ * that together with mxl_relattn_bwd_fused every (query, distance) pair is counted once; and those cells' part of the r_r_bias
+ * gradient, d_r_r_bias[h*64 + e] += sum_delta colsum_{b,i}(dG)[h, delta] * rd[delta, h*64 + e] (d_r_r_bias may be NULL).
+ * (T - Kc) % 64 == 0. */
 int mxl_relattn_drd_phantom(const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs, int qr_rs,
-                            int drd_ld, const void* rd, int rd_rs, const float* lse, const float* delta, float scale, int Kc,
-                            void* stream);
+                            int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, const float* lse, const float* delta,
+                            float scale, int Kc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.

@@ -1958,8 +1958,8 @@ extern "C" int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* 
 }
 
 extern "C" int mxl_relattn_drd_phantom(const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs, int qr_rs,
-                                       int drd_ld, const void* rd, int rd_rs, const float* lse, const float* delta, float scale,
-                                       int Kc, void* stream) {
-    return relattn_drd_impl(nullptr, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, nullptr, nullptr, lse, delta, scale, Kc,
-                            1, stream, 1);
+                                       int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, const float* lse, const float* delta,
+                                       float scale, int Kc, void* stream) {
+    return relattn_drd_impl(nullptr, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, d_r_r_bias, nullptr, lse, delta, scale,
+                            Kc, 1, stream, 1);
 }

@@ -33,6 +33,7 @@
 // Zero memories (the reference's training, mode R): key positions below the first stored one exist only as distances.  Their
 // part of dq comes from the forward's value-sum over ALL such cells (mxl_relattn_fwd_phantom2, oph_all = 1), added by the
 // finishing kernel; their part of d_rd is rebuilt on MFMA from q, rd, lse, delta by mxl_relattn_drd_phantom (relattn_bwd.hip).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "musicxl_internal.h"
@@ -44,6 +45,9 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef MXL_FUSED_NSUB_DEFAULT
+#define MXL_FUSED_NSUB_DEFAULT 1
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KBLK = 256;                       // keys per workgroup
 constexpr int QT = 32;                          // queries per tile
@@ -62,6 +66,21 @@ constexpr int Y_BYTES = QT * YP;
 constexpr int BIAS_BYTES = 2 * 64 * 4;
 constexpr int SMEM = K_BYTES + RING_BYTES + 2 * QSET + G_BYTES + X_BYTES + Y_BYTES + BIAS_BYTES;   // 153 344 B: one workgroup per CU
 constexpr int RING_OFF = 10240;                 // multiple of RING_BLKS added to (possibly negative) block indices before the modulo
+
+// In-kernel stamps (diagnostic builds only: scripts/ab_build.sh relattn_bwd_fused stamp -DMXL_STAMP; the shipped library has none).
+// Per wave, shader cycles between consecutive stamps are summed per segment and added to g_fused_stamps at the end.
+#ifdef MXL_STAMP
+__device__ unsigned long long g_fused_stamps[16];
+#define STAMP_DECL unsigned long long st_last, st_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; \
+    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); st_acc[i] += t_ - st_last; st_last = t_; }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_fused_stamps[i_], st_acc[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
 
 struct FusedP {
     const bf16_t *q, *k, *v, *rd, *dout;
@@ -91,6 +110,9 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 // sixteen genuine 16-bit LDS reads: register j belongs to query ii = pat(j) + 4 hh, pat(j) = (j & 3) + 8 (j >> 2), and needs
 // column ii + 256 - kloc of row ii of the skew buffer: lane base + pat(j) * (GP + 2)
+// (issued WITHOUT a wait: LDS operations complete in order, so any later wait of the wave's own LDS reads covers these; the
+// caller places gskew_wait() in front of the first use -- hipcc does not count loads made by inline asm)
+__device__ __forceinline__ void gskew_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void gskew_read16(uint32_t base, uint32_t (&u)[16]) {
     static_assert(GP == 584, "offsets below are pat(j) * (GP + 2)");
     asm volatile(
@@ -99,8 +121,7 @@ __device__ __forceinline__ void gskew_read16(uint32_t base, uint32_t (&u)[16]) {
         "ds_read_u16 %6, %16 offset:5860\n\t"   "ds_read_u16 %7, %16 offset:6446\n\t"   "ds_read_u16 %8, %16 offset:9376\n\t"
         "ds_read_u16 %9, %16 offset:9962\n\t"   "ds_read_u16 %10, %16 offset:10548\n\t" "ds_read_u16 %11, %16 offset:11134\n\t"
         "ds_read_u16 %12, %16 offset:14064\n\t" "ds_read_u16 %13, %16 offset:14650\n\t" "ds_read_u16 %14, %16 offset:15236\n\t"
-        "ds_read_u16 %15, %16 offset:15822\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "ds_read_u16 %15, %16 offset:15822"
         : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
           "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
         : "v"(base)
@@ -163,7 +184,17 @@ __global__ __launch_bounds__(256) void fused_delta_kernel(const bf16_t* o, const
     }
 }
 
-__global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
+// Four waves (one per SIMD, the whole 512-register file each), wave w = keys 64w .. 64w + 63 as two 32-key sub-blocks.  At 8 waves x
+// 32 keys (256 registers) the first version spilled and every phase was a serial LDS -> wait -> MFMA chain (12.7 k cycles per
+// tile for 1.1 k of MFMA per wave, profiles/r04_fused_stamp_anatomy.txt): with two sub-blocks a wave has four independent score
+// chains, every LDS operand read (query rows, transposed query / dO fragments, K / Rd fragments of the dq piece) feeds two MFMAs,
+// and the scheduler has the registers to run the reads of one product under the MFMAs of another.
+// NSUB = 32-key sub-blocks per wave: 2 -> four waves x 64 keys (one wave per SIMD, 512 registers), 1 -> eight waves x 32 keys (two waves
+// per SIMD, 256 registers).
+template <int NSUB>
+__global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP p) {
+    constexpr int NW = 8 / NSUB, NT = 64 * NW;       // waves, threads
+    constexpr int NIH = NSUB;                        // 16-row halves of the dq piece a wave forms (all 32 queries at four waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sR = sK + K_BYTES;
@@ -173,6 +204,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     char* sY = sX + X_BYTES;
     float* sBias = reinterpret_cast<float*>(sY + Y_BYTES);       // r_w_bias[64], r_r_bias[64] of this head
 
+    STAMP_DECL
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63, r = l & 31, hh = l >> 5;
@@ -181,10 +213,8 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;                    // lowest stored key position (a multiple of 32)
     const int P0 = p0 + KBLK * bx_;             // first key position of the workgroup
-    const int Pw = P0 + 32 * w;
-    const int kloc = 32 * w + r;
-    const int pk = Pw + r;                      // this lane's key position
-    const bool kok = pk < T;
+    const int Pw = P0 + 32 * NSUB * w;          // first key position of the wave (sub-block kb: + 32 kb)
+    const int kloc0 = 32 * NSUB * w + r;        // this lane's key inside the workgroup, sub-block 0 (sub-block 1: + 32)
     const int MB = M >> 5;
 
     const bf16_t* qbase = p.q + (size_t)b * p.q_bs + (size_t)h * 64;
@@ -198,38 +228,44 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     const int rowq = qoff(r, hh);                                  // Q-set row fragment, k-step ks: rowq ^ (ks << 5)
     const int rows = r * ROWB + ((hh ^ sswz(r)) << 4);             // ring row fragment,   k-step ks: rows ^ (ks << 5)
     const int tk0 = qeoff(4 * hh + q4, 16 * (gq & 1) + 4 * pp);    // Q-set transposed pattern (relattn_bwd.hip, tk0)
-    const uint32_t gRb = lds_addr(sG) + 4 * hh * (GP + 2) + (256 - kloc) * 2;
-    const uint32_t yWb = lds_addr(sY) + 4 * hh * (YP + 2) + (256 - kloc) * 2;
-    // X[key][query]: 8-byte granule g of row p at g ^ ((p >> 1) & 7): this lane's group `grp` (queries 8 grp + 4 hh ..) at xw ^ (grp << 4)
-    const int xf = (kloc >> 1) & 7;
-    const int xw = kloc * 64 + ((((hh ^ (xf & 1)) | (xf & 6))) << 3);
+    // skew buffers: sub-block kb sits 32 keys higher = 32 columns lower = 64 bytes lower
+    const uint32_t gRb = lds_addr(sG) + 4 * hh * (GP + 2) + (256 - kloc0) * 2;
+    const uint32_t yWb = lds_addr(sY) + 4 * hh * (YP + 2) + (256 - kloc0) * 2;
+    // X[key][query]: 8-byte granule g of row p at g ^ ((p >> 1) & 7): this lane's group `grp` (queries 8 grp + 4 hh ..) at xw ^ (grp << 4);
+    // sub-block 1 is 32 rows further ((p >> 1) & 7 is the same: 32 rows = 16 steps of it)
+    const int xf = (kloc0 >> 1) & 7;
+    const int xw = kloc0 * 64 + ((((hh ^ (xf & 1)) | (xf & 6))) << 3);
     const int ya0 = (4 * hh + q4) * YP + (16 * (gq & 1) + 4 * pp) * 2;          // Y transposed pattern (32x32x16 A fragment of dRd)
-    // 16 x 16 piece of dq this wave forms: queries 16 ih .., elements 16 eq ..
-    const int ih = w & 1, eq = w >> 1;
+    // dq piece of this wave: elements 16 eq .. 16 eq + 15 of the 16-row halves ih0 .. ih0 + NIH - 1 of the tile's queries
+    const int eq = NSUB == 2 ? w : (w >> 1), ih0 = NSUB == 2 ? 0 : (w & 1);
     const int g16 = l >> 4, q16 = (l & 15) >> 2;                   // 16x16x32 transposed pattern: rows 8 g16 + q16 (+4), 4 columns at 4 pp
-    const int xa0 = (8 * g16 + q16) * 64 + (((4 * ih + pp) ^ ((4 * g16 + (q16 >> 1)) & 7)) << 3);
-    const int xa1 = (8 * g16 + q16 + 4) * 64 + (((4 * ih + pp) ^ ((4 * g16 + 2 + (q16 >> 1)) & 7)) << 3);
+    const int xa0 = ((8 * g16 + q16) * 64 + ((pp ^ ((4 * g16 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);          // next half: ^ 32
+    const int xa1 = ((8 * g16 + q16 + 4) * 64 + ((pp ^ ((4 * g16 + 2 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);
     const int kch = 2 * eq + (pp >> 1);
     const int ksw = ((g16 & 1) << 2) | (((q16 >> 1) & 1) << 1);
     const int ka0 = (8 * g16 + q16) * ROWB + ((kch ^ ksw) << 4) + ((pp & 1) << 3);
     const int ka1 = (8 * g16 + q16 + 4) * ROWB + ((kch ^ (ksw | 1)) << 4) + ((pp & 1) << 3);
-    const int yq0 = (16 * ih + (l & 15)) * YP + 16 * g16;          // Y row fragment (16x16x32 A): row = query, 8 columns at 8 g16
+    const int yq0 = (16 * ih0 + (l & 15)) * YP + 16 * g16;         // Y row fragment (16x16x32 A): row = query (next half: + 16 YP)
 
     // ---- prologue: biases, K image, Y zeroed, K / V fragments (B operands: lane = key, k = 16 ks + 8 hh + j)
     if (tid < 128) sBias[tid] = (tid < 64) ? p.rwb[h * 64 + tid] : p.rrb[h * 64 + tid - 64];
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
-        const int c = tid + n * 512;
+    for (int n = 0; n < 2048 / NT; n++) {
+        const int c = tid + n * NT;
         const int row = c >> 3, ch = c & 7;
         const int srow = KBLK * bx_ + row;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (srow < p.Kc) val = *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8);
         *reinterpret_cast<u32x4*>(sK + soff(row, ch)) = val;
     }
-    for (int i = tid; i < Y_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(sY)[i] = u32x4{0u, 0u, 0u, 0u};
-    bf16x8 kf[4], vf[4];
-    {
-        const size_t srow = (size_t)(kok ? pk - p0 : 0);
+    for (int i = tid; i < Y_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(sY)[i] = u32x4{0u, 0u, 0u, 0u};
+    bf16x8 kf[NSUB][4], vf[NSUB][4];
+    bool kok[NSUB];
+#pragma unroll
+    for (int kb = 0; kb < NSUB; kb++) {
+        const int pk = Pw + 32 * kb + r;
+        kok[kb] = pk < T;
+        const size_t srow = (size_t)(kok[kb] ? pk - p0 : 0);
         const bf16_t* kp = kbase + srow * p.kv_rs;
         const bf16_t* vp = vbase + srow * p.kv_rs;
 #pragma unroll
@@ -237,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
             const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * hh);
             const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
 #pragma unroll
-            for (int j = 0; j < 8; j++) { kf[ks][j] = kok ? kv[j] : (short)0; vf[ks][j] = kok ? vv[j] : (short)0; }
+            for (int j = 0; j < 8; j++) { kf[kb][ks][j] = kok[kb] ? kv[j] : (short)0; vf[kb][ks][j] = kok[kb] ? vv[j] : (short)0; }
         }
     }
 
@@ -245,19 +281,36 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     const int i_lo = max(P0, 0), i_hi = min(P0 + KBLK - 1 + M - 1, T - 1);
     const int it_lo = i_lo >> 5, it_hi = i_hi >> 5;
 
-    // ---- staging: waves 0-3 take the q rows of a tile (-> Qw, Qr images), waves 4-7 its dO rows and the new Rd block
-    u32x4 tq = {0u, 0u, 0u, 0u}, rr = {0u, 0u, 0u, 0u};
-    float tl = 0.f;
-    const int t2 = tid & 255, srow_ = t2 >> 3, sch_ = t2 & 7;
-    auto load_q = [&](int it) {
+    // ---- staging: every thread owns one 16-byte chunk of a tile's q rows, of its dO rows and of the new Rd block.
+    // Every global access of the tile loop goes through a buffer descriptor (wave-uniform base in scalar registers) with a 32-bit
+    // lane offset and a scalar tile offset: with flat 64-bit lane pointers hipcc kept the per-lane bases in registers across the
+    // loop, spilled them, and the reload's s_waitcnt vmcnt(0) at the top of every tile drained the previous tile's slab stores and
+    // atomics before the next tile's rows were even requested (1.4 k of 13.8 k cycles per tile in the stamps).
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rd = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + ((size_t)b * p.H + h) * T), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + ((size_t)b * p.H + h) * T), 0, -1, 0x00020000);
+    u32x4 tq = {0u, 0u, 0u, 0u}, tdo = {0u, 0u, 0u, 0u}, rr = {0u, 0u, 0u, 0u};
+    float tl = 0.f, tdl = 0.f;
+    // four waves: every thread takes a chunk of each; eight waves: waves 0-3 the q rows, waves 4-7 the dO rows and the Rd block
+    const bool st_q = NSUB == 2 || tid < 256, st_do = NSUB == 2 || tid >= 256;
+    const int srow_ = (tid & 255) >> 3, sch_ = tid & 7;
+    const int vo_q = (srow_ * p.q_rs + sch_ * 8) * 2, vo_do = (srow_ * p.o_rs + sch_ * 8) * 2;     // byte offsets inside a tile
+    auto load_q = [&](int it) {                 // T % 32 == 0: every row of a tile exists
         const int I = it * QT;
-        const size_t qi = (size_t)min(I + srow_, T - 1);
-        if (tid < 256) tq = *reinterpret_cast<const u32x4*>(qbase + qi * p.q_rs + sch_ * 8);
-        else tq = *reinterpret_cast<const u32x4*>(dobase + qi * p.o_rs + sch_ * 8);
-        if (tid < 64) {
-            const size_t sidx = ((size_t)b * p.H + h) * T + min(I + (tid & 31), T - 1);
-            tl = (tid < 32) ? p.lse[sidx] : p.delta[sidx];
+        if (NSUB == 2) {
+            tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q, I * p.q_rs * 2, 0));
+            tdo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_do, vo_do, I * p.o_rs * 2, 0));
+        } else {                                // one staging register: the q chunk (waves 0-3) or the dO chunk (waves 4-7)
+            if (st_q) tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q, I * p.q_rs * 2, 0));
+            else tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_do, vo_do, I * p.o_rs * 2, 0));
         }
+        // (every thread, no branch: behind a lane-dependent branch hipcc loaded into a scratch register and moved the value at
+        // once, i.e. waited s_waitcnt vmcnt(0) at the top of every tile)
+        tl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lse, (tid & 31) * 4, I * 4, 0));
+        tdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dl, (tid & 31) * 4, I * 4, 0));
     };
     auto store_q = [&](int buf) {
         char* sQw = sQ + buf * QSET;
@@ -265,7 +318,8 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
         char* sDO = sQr + QIMG;
         float* sLse = reinterpret_cast<float*>(sDO + QIMG);
         const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
-        if (tid < 256) {
+        const bf16_t* sdo = reinterpret_cast<const bf16_t*>(NSUB == 2 ? &tdo : &tq);
+        if (st_q) {
             u32x4 ww, wr;
             bf16_t* dw = reinterpret_cast<bf16_t*>(&ww);
             bf16_t* dr = reinterpret_cast<bf16_t*>(&wr);
@@ -280,41 +334,38 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
             }
             *reinterpret_cast<u32x4*>(sQw + qoff(srow_, sch_)) = ww;
             *reinterpret_cast<u32x4*>(sQr + qoff(srow_, sch_)) = wr;
-        } else {
+        }
+        if (st_do) {
             u32x4 wd;
             bf16_t* dd = reinterpret_cast<bf16_t*>(&wd);
 #pragma unroll
-            for (int j = 0; j < 8; j++) dd[j] = f2bf(bf2f(src[j]) * p.scale);
+            for (int j = 0; j < 8; j++) dd[j] = f2bf(bf2f(sdo[j]) * p.scale);
             *reinterpret_cast<u32x4*>(sDO + qoff(srow_, sch_)) = wd;
         }
-        if (tid < 32) sLse[tid] = -tl * LOG2E;
-        else if (tid < 64) sLse[tid] = -p.scale * tl;            // sDl = sLse + 32
+        if (tid < 32) { sLse[tid] = -tl * LOG2E; sLse[QT + tid] = -p.scale * tdl; }
     };
     auto load_r = [&](int n) {                  // 32 Rd rows of distance block n (row index clamped: out-of-range cells are masked)
-        if (tid >= 256) {
-            int d = 32 * n + srow_;
-            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
-            rr = *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + sch_ * 8);
-        }
+        if (!st_do) return;
+        int d = 32 * n + srow_;
+        d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+        rr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rd, (d * p.rd_rs + sch_ * 8) * 2, 0, 0));
     };
     auto store_r = [&](int n) {
-        if (tid >= 256) {
-            const int slot = (n + RING_OFF) % RING_BLKS;
-            *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = rr;
-        }
+        if (!st_do) return;
+        const int slot = (n + RING_OFF) % RING_BLKS;
+        *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = rr;
     };
     // G^T block j of the window whose first block index is n0 (lane = query, registers = distances) -> fp16 skew buffer
-    auto gblock = [&](int j, int n0, const char* sQr) {
+    auto gblock = [&](int j, int n0, const bf16x8 (&bq)[4]) {
         f32x16 g;
 #pragma unroll
         for (int t = 0; t < 16; t++) g[t] = 0.f;
         const char* rb = sR + ((n0 + j + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+        bf16x8 a[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
-            const bf16x8 bq = *reinterpret_cast<const bf16x8*>(sQr + (rowq ^ (ks << 5)));
-            g = mfma32(a, bq, g);
-        }
+        for (int ks = 0; ks < 4; ks++) a[ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) g = mfma32(a[ks], bq[ks], g);
         char* gw = sG + r * GP + (32 * j + 4 * hh) * 2;
 #pragma unroll
         for (int grp = 0; grp < 4; grp++) {
@@ -322,10 +373,14 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
             *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
         }
     };
-    auto gblocks = [&](int I, const char* sQr) {        // the nine blocks of the tile at I: wave w takes block w, wave 0 also block 8
+    auto gblocks = [&](int I, const char* sQr) {        // the nine blocks of the tile at I: wave w takes blocks w and w + 4, wave 0 also 8
         const int n0 = (I - P0 - KBLK) >> 5;
-        gblock(w, n0, sQr);
-        if (w == 0) gblock(8, n0, sQr);
+        bf16x8 bq[4];                                   // the tile's Qr rows (B operand), shared by the wave's blocks
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bq[ks] = *reinterpret_cast<const bf16x8*>(sQr + (rowq ^ (ks << 5)));
+#pragma unroll
+        for (int c = 0; c < NSUB; c++) gblock(w + NW * c, n0, bq);
+        if (w == 0) gblock(8, n0, bq);
     };
 
     {
@@ -333,18 +388,19 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
         load_q(it_lo);
         __syncthreads();                        // biases in LDS
         store_q(0);
-        // the nine Rd blocks of the first window: 9 x 256 sixteen-byte chunks over all 512 threads, loads first
-        u32x4 pr_[5];
+        // the nine Rd blocks of the first window: 9 x 256 sixteen-byte chunks, loads first
+        constexpr int NPR = (9 * 256 + NT - 1) / NT;
+        u32x4 pr_[NPR];
 #pragma unroll
-        for (int n = 0; n < 5; n++) {
-            const int c = tid + n * 512;
+        for (int n = 0; n < NPR; n++) {
+            const int c = tid + n * NT;
             int d = 32 * n0 + (c >> 3);
             d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
             pr_[n] = (c < 9 * 256) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + (c & 7) * 8) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int n = 0; n < 5; n++) {
-            const int c = tid + n * 512;
+        for (int n = 0; n < NPR; n++) {
+            const int c = tid + n * NT;
             if (c < 9 * 256) {
                 const int slot = (n0 + (c >> 8) + RING_OFF) % RING_BLKS;
                 *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff((c >> 3) & 31, c & 7)) = pr_[n];
@@ -355,31 +411,59 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     gblocks(it_lo * QT, sQ + QIMG);
     __syncthreads();
 
-    f32x16 ak[2], av[2], rd_acc[2];             // dK^T, dV^T : [e][key];  dRd block : [distance][e]
+    f32x16 ak[NSUB][2], av[NSUB][2];            // dK^T, dV^T : [sub-block][e half][e][key]
+    f32x16 rd_acc[NSUB][2];                     // dRd blocks of the wave's residue classes (w + NW c mod 8): [class][e half][distance][e]
 #pragma unroll
-    for (int e = 0; e < 2; e++)
+    for (int a = 0; a < NSUB; a++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; rd_acc[e][j] = 0.f; }
-    int acc_n = -1000000;                       // distance block whose sum rd_acc holds (none yet)
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) { ak[a][e][j] = 0.f; av[a][e][j] = 0.f; rd_acc[a][e][j] = 0.f; }
+    int acc_n[NSUB];                            // distance block whose sum rd_acc[c] holds (none yet)
+#pragma unroll
+    for (int a = 0; a < NSUB; a++) acc_n[a] = -1000000;
     float cw = 0.f, cr = 0.f;                   // running column sums of this wave's dQw / dQr pieces (d r_w_bias / d r_r_bias)
 
-    auto drd_flush = [&]() {
-        if (acc_n >= 0 && acc_n < MB) {
+    auto drd_flush = [&](int c) {
+#ifndef MXL_ABL_NO_ATOMICS
+        if (acc_n[c] >= 0 && acc_n[c] < MB) {
             const float f = 1.f / p.scale_log2e;            // the Qr image carries scale * log2(e)
-            float* dst = p.drd + (size_t)(32 * acc_n + 4 * hh) * p.drd_ld + h * 64 + r;
+            float* dst = p.drd + (size_t)(32 * acc_n[c] + 4 * hh) * p.drd_ld + h * 64 + r;
 #pragma unroll
             for (int e = 0; e < 2; e++)
 #pragma unroll
                 for (int j = 0; j < 16; j++)
-                    atomicAdd(dst + (size_t)((j & 3) + 8 * (j >> 2)) * p.drd_ld + 32 * e, rd_acc[e][j] * f);
+                    atomicAdd(dst + (size_t)((j & 3) + 8 * (j >> 2)) * p.drd_ld + 32 * e, rd_acc[c][e][j] * f);
         }
+#endif
 #pragma unroll
         for (int e = 0; e < 2; e++)
 #pragma unroll
-            for (int j = 0; j < 16; j++) rd_acc[e][j] = 0.f;
+            for (int j = 0; j < 16; j++) rd_acc[c][e][j] = 0.f;
     };
 
+    // The score phase's operand reads (query / dO rows as A fragments, the per-query constants) do not depend on anything the
+    // other waves write during a tile: a tile's Q set is complete at barrier 1 of the tile before.  They are requested at the END
+    // of the previous tile, ahead of barrier 2, and are in registers when the chains start.
+    bf16x8 aq[4], ad[4];
+    f32x4 cl[4], cd[4];
+    auto read_rows = [&](int buf) {
+        const char* sQw_ = sQ + buf * QSET;
+        const char* sDO_ = sQw_ + 2 * QIMG;
+        const float* sLse_ = reinterpret_cast<const float*>(sDO_ + QIMG);
+#pragma unroll
+        for (int grp = 0; grp < 4; grp++) {
+            cl[grp] = *reinterpret_cast<const f32x4*>(sLse_ + 8 * grp + 4 * hh);
+            cd[grp] = *reinterpret_cast<const f32x4*>(sLse_ + QT + 8 * grp + 4 * hh);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            aq[ks] = *reinterpret_cast<const bf16x8*>(sQw_ + (rowq ^ (ks << 5)));
+            ad[ks] = *reinterpret_cast<const bf16x8*>(sDO_ + (rowq ^ (ks << 5)));
+        }
+    };
     int cur = 0;
+    STAMP(15)
 #pragma unroll 1
     for (int it = it_lo; it <= it_hi; it++) {
         const int I = it * QT;
@@ -390,150 +474,317 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
         const float* sLse = reinterpret_cast<const float*>(sDO + QIMG);
         const float* sDl = sLse + QT;
         const int n0 = (I - P0 - KBLK) >> 5;    // first distance block of this tile's window: column c = distance - 32 n0
+#ifndef MXL_ABL_NO_LOADS
         if (more) { load_q(it + 1); load_r(n0 + 9); }
+#endif
+        STAMP(0)
 
         // =============================== phase A: scores, dV, dK, dS -> X / Y ===============================
-        const int dmin_w = I - Pw - 31, dmax_w = I + 31 - Pw;
-        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pw < T);
-        if (active) {
-            f32x16 s, dp;
+        bool active[NSUB], full[NSUB], any = false;
 #pragma unroll
-            for (int grp = 0; grp < 4; grp++) {
-                const f32x4 cl = *reinterpret_cast<const f32x4*>(sLse + 8 * grp + 4 * hh);
-                const f32x4 cd = *reinterpret_cast<const f32x4*>(sDl + 8 * grp + 4 * hh);
+        for (int kb = 0; kb < NSUB; kb++) {
+            const int Pk = Pw + 32 * kb;
+            const int dmin_w = I - Pk - 31, dmax_w = I + 31 - Pk;
+            active[kb] = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pk < T);
+            full[kb] = (dmin_w >= 0) && (dmax_w <= M - 1) && (Pk + 31 < T);
+            any = any || active[kb];
+        }
+        if (any) {
+            // every LDS read of the score phase first, then the four chains
+            uint32_t bdu[NSUB][16];
 #pragma unroll
-                for (int t = 0; t < 4; t++) { s[4 * grp + t] = cl[t]; dp[4 * grp + t] = cd[t]; }
+            for (int kb = 0; kb < NSUB; kb++) gskew_read16(gRb - 64 * kb, bdu[kb]);
+            read_rows(cur);
+            // K as the B operand of S (lane = key, k = 16 ks + 8 hh ..): registers for the whole sweep at four waves; at eight
+            // waves (256 registers) re-read per tile from the LDS image, whose swizzle makes the row reads conflict-free
+            bf16x8 kfl[4];
+            if (NSUB == 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    kfl[ks] = *reinterpret_cast<const bf16x8*>(sK + kloc0 * ROWB + ((((2 * ks + hh) ^ sswz(kloc0))) << 4));
             }
+#define KF(kb_, ks_) (NSUB == 2 ? kf[kb_][ks_] : kfl[ks_])
+            // -lse and -scale * delta of the tile's queries as ONE start tuple per chain kind (an MFMA's C operand need not be its
+            // destination): shared by the sub-blocks
+            f32x16 s[NSUB], dp[NSUB];
+            if (NSUB == 2) {
+                f32x16 c_s, c_dp;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sQw + (rowq ^ (ks << 5)));
-                s = mfma32(a, kf[ks], s);
-                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sDO + (rowq ^ (ks << 5)));
-                dp = mfma32(ad, vf[ks], dp);
-            }
-            uint32_t bdu[16];
-            gskew_read16(gRb, bdu);
-            const bool full = __builtin_amdgcn_readfirstlane(
-                (int)((dmin_w >= 0) && (dmax_w <= M - 1) && (Pw + 31 < T))) != 0;
-            f32x16 pr;
-            if (full) {
+                for (int grp = 0; grp < 4; grp++)
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
-                    pr[j] = pv;
-                    s[j] = pv * dp[j];
-                }
+                    for (int t = 0; t < 4; t++) { c_s[4 * grp + t] = cl[grp][t]; c_dp[4 * grp + t] = cd[grp][t]; }
+#pragma unroll
+                for (int kb = 0; kb < NSUB; kb++) { s[kb] = mfma32(aq[0], KF(kb, 0), c_s); dp[kb] = mfma32(ad[0], vf[kb][0], c_dp); }
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    const int d = I + ii - pk;
-                    const bool valid = (d >= 0) && (d <= M - 1) && kok;
-                    const float pv = valid ? __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j])) : 0.f;
-                    pr[j] = pv;
-                    s[j] = valid ? pv * dp[j] : 0.f;
-                }
+                for (int grp = 0; grp < 4; grp++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { s[0][4 * grp + t] = cl[grp][t]; dp[0][4 * grp + t] = cd[grp][t]; }
+                s[0] = mfma32(aq[0], KF(0, 0), s[0]);
+                dp[0] = mfma32(ad[0], vf[0][0], dp[0]);
             }
-            uint32_t dsw[8];          // dS as bf16 pairs (2m, 2m + 1): MFMA operand and the source of both LDS images
 #pragma unroll
-            for (int m = 0; m < 8; m++) dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]);
+            for (int ks = 1; ks < 4; ks++) {
 #pragma unroll
-            for (int grp = 0; grp < 4; grp++)
-                *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{dsw[2 * grp], dsw[2 * grp + 1]};
-            yskew_write16(yWb, dsw);
-            // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order)
+                for (int kb = 0; kb < NSUB; kb++) s[kb] = mfma32(aq[ks], KF(kb, ks), s[kb]);
+#pragma unroll
+                for (int kb = 0; kb < NSUB; kb++) dp[kb] = mfma32(ad[ks], vf[kb][ks], dp[kb]);
+            }
+#undef KF
+            STAMP(1)
+            gskew_wait();
+            STAMP(2)
+            // the transposed dO / Qw fragments of the dV / dK products: at four waves requested now, so that they land under the
+            // exponentials (at eight waves there are no 32 registers to park them in: requested behind the exponentials)
+            bf16x8 tdo_[2][2], tqw_[2][2];
+            auto tr_frags = [&]() {
+#pragma unroll
+                for (int st = 0; st < 2; st++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const char* a0 = sDO + 16 * st * ROWB + tk0;
+                        tdo_[st][e] = tr_pair(a0 + 64 * e, a0 + 8 * ROWB + 64 * (1 - e));
+                        const char* c0 = sQw + 16 * st * ROWB + tk0;
+                        tqw_[st][e] = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
+                    }
+            };
+            if (NSUB == 2) tr_frags();
+            uint32_t dsw[NSUB][8], prw[NSUB][8];    // dS and P as bf16 pairs (2m, 2m + 1)
+#pragma unroll
+            for (int kb = 0; kb < NSUB; kb++) {
+                const bool fl = __builtin_amdgcn_readfirstlane((int)full[kb]) != 0;
+                f32x16 pr;
+                if (fl) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const float pv = __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[kb][j]));
+                        pr[j] = pv;
+                        s[kb][j] = pv * dp[kb][j];
+                    }
+                } else {
+                    const int pk = Pw + 32 * kb + r;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                        const int d = I + ii - pk;
+                        const bool valid = (d >= 0) && (d <= M - 1) && kok[kb] && active[kb];
+                        const float pv = valid ? __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[kb][j])) : 0.f;
+                        pr[j] = pv;
+                        s[kb][j] = valid ? pv * dp[kb][j] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 8; m++) { dsw[kb][m] = pack2bf(s[kb][2 * m], s[kb][2 * m + 1]); prw[kb][m] = pack2bf(pr[2 * m], pr[2 * m + 1]); }
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++)
+                    *reinterpret_cast<u32x2*>(sX + kb * 2048 + (xw ^ (grp << 4))) = u32x2{dsw[kb][2 * grp], dsw[kb][2 * grp + 1]};
+                yskew_write16(yWb - 64 * kb, dsw[kb]);
+            }
+            STAMP(3)
+            if (NSUB == 1) tr_frags();
+            // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order; shared by the sub-blocks)
 #pragma unroll
             for (int st = 0; st < 2; st++) {
-                const u32x4 pw = {pack2bf(pr[8 * st], pr[8 * st + 1]), pack2bf(pr[8 * st + 2], pr[8 * st + 3]),
-                                  pack2bf(pr[8 * st + 4], pr[8 * st + 5]), pack2bf(pr[8 * st + 6], pr[8 * st + 7])};
-                const u32x4 dw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), df = __builtin_bit_cast(bf16x8, dw);
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const char* a0 = sDO + 16 * st * ROWB + tk0;
-                    const bf16x8 a1 = tr_pair(a0 + 64 * e, a0 + 8 * ROWB + 64 * (1 - e));
-                    av[e] = mfma32(a1, pf, av[e]);
-                    const char* c0 = sQw + 16 * st * ROWB + tk0;
-                    const bf16x8 a2 = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
-                    ak[e] = mfma32(a2, df, ak[e]);
+#ifndef MXL_ABL_NO_DVDK
+#pragma unroll
+                    for (int kb = 0; kb < NSUB; kb++) {
+                        const u32x4 pw = {prw[kb][4 * st], prw[kb][4 * st + 1], prw[kb][4 * st + 2], prw[kb][4 * st + 3]};
+                        const u32x4 dw = {dsw[kb][4 * st], dsw[kb][4 * st + 1], dsw[kb][4 * st + 2], dsw[kb][4 * st + 3]};
+                        av[kb][e] = mfma32(tdo_[st][e], __builtin_bit_cast(bf16x8, pw), av[kb][e]);
+                        ak[kb][e] = mfma32(tqw_[st][e], __builtin_bit_cast(bf16x8, dw), ak[kb][e]);
+                    }
+#endif
                 }
             }
         } else {
             // no valid cell for this wave's keys in this tile: its rows of X and its cells of Y still have to read as zero
             const uint32_t z[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int grp = 0; grp < 4; grp++) *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{0u, 0u};
-            yskew_write16(yWb, z);
+            for (int kb = 0; kb < NSUB; kb++) {
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) *reinterpret_cast<u32x2*>(sX + kb * 2048 + (xw ^ (grp << 4))) = u32x2{0u, 0u};
+                yskew_write16(yWb - 64 * kb, z);
+            }
         }
+        STAMP(4)
         if (more) { store_q(cur ^ 1); store_r(n0 + 9); }
+        STAMP(5)
         __syncthreads();
+        STAMP(6)
 
-        // =============================== phase B: dq piece, dRd block, next tile's G ===============================
+        // =============================== phase B: dq piece, dRd blocks, next tile's G ===============================
+        // Two rounds, each "every LDS read of the round, then its MFMAs" with a scheduling fence between: left to itself hipcc
+        // issues four reads, waits, issues one MFMA, 40 times per tile (profiles/r04_fused_stamp_anatomy.txt) -- a wave that is
+        // alone or nearly alone on its SIMD then sits out an LDS round trip per MFMA.  Round 1: the key half of the dq piece and
+        // the next tile's G blocks (neither needs Y); round 2: the distance half of the dq piece and the dRd blocks.
         {
-            f32x4 aw4 = {0.f, 0.f, 0.f, 0.f}, ar4 = {0.f, 0.f, 0.f, 0.f};
-            // keys that can hold a non-zero dS in this tile: key position <= I + 31 and >= I - (M - 1)
-            const int u_hi = min(7, (I + 31 - P0) >> 5);
-            const int u_lo = max(0, (I - (M - 1) - P0) >> 5);
-#pragma unroll 1
-            for (int u = u_lo; u <= u_hi; u++) {
-                const bf16x8 a = tr_pair(sX + u * 2048 + xa0, sX + u * 2048 + xa1);
-                const bf16x8 bk = tr_pair(sK + u * 4096 + ka0, sK + u * 4096 + ka1);
-                aw4 = mfma16(a, bk, aw4);
+            f32x4 aw4[NIH], ar4[NIH];
+#pragma unroll
+            for (int ih = 0; ih < NIH; ih++) { aw4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; ar4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const char* sQrN = sQ + (cur ^ 1) * QSET + QIMG;       // the next tile's Qr image (stored before barrier 1)
+            const int n0N = n0 + 1;
+            // ---- round 1 reads
+            bf16x8 bk[8], xa[8][NIH], gq_[4], ga[NSUB][4];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                bk[u] = tr_pair(sK + u * 4096 + ka0, sK + u * 4096 + ka1);
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) xa[u][ih] = tr_pair(sX + u * 2048 + (xa0 ^ (ih << 5)), sX + u * 2048 + (xa1 ^ (ih << 5)));
             }
-            // distance blocks of the window that lie in [0, M)
-            const int v_lo = max(0, -n0), v_hi = min(8, MB - 1 - n0);
-#pragma unroll 1
-            for (int v = v_lo; v <= v_hi; v++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sY + yq0 + v * 64);
-                const char* rb = sR + ((n0 + v + RING_OFF) % RING_BLKS) * RBLK_BYTES;
-                const bf16x8 br = tr_pair(rb + ka0, rb + ka1);
-                ar4 = mfma16(a, br, ar4);
+            auto g_reads = [&]() {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) gq_[ks] = *reinterpret_cast<const bf16x8*>(sQrN + (rowq ^ (ks << 5)));
+#pragma unroll
+                for (int c = 0; c < NSUB; c++) {
+                    const char* rb = sR + ((n0N + w + NW * c + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) ga[c][ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+                }
+            };
+            if (NSUB == 2) g_reads();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- round 1 MFMAs
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) aw4[ih] = mfma16(xa[u][ih], bk[u], aw4[ih]);
+            if (NSUB == 1) {            // (256 registers: the G operands get a round of their own)
+                __builtin_amdgcn_sched_barrier(0);
+                g_reads();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // this tile's partial dq -> slab of this key block (rows = queries 16 ih + 4 (l >> 4) + t, column = element)
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NSUB; c++) {
+                    f32x16 g;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) g[t] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) g = mfma32(ga[c][ks], gq_[ks], g);
+                    char* gw = sG + r * GP + (32 * (w + NW * c) + 4 * hh) * 2;
+#pragma unroll
+                    for (int grp = 0; grp < 4; grp++) {
+                        const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                        *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
+                    }
+                }
+                if (w == 0) gblock(8, n0N, gq_);
+            }
+            STAMP(7)
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- round 2a reads: distance blocks 0 - 4 of the dq piece, the dRd operands
+            bf16x8 br[5], ya[5][NIH], tqr[2][2], da[NSUB][2];
+            int jA[NSUB];
+            int slot = (n0 + RING_OFF) % RING_BLKS;
+#pragma unroll
+            for (int v = 0; v < 5; v++) {
+                const char* rb = sR + slot * RBLK_BYTES;
+                br[v] = tr_pair(rb + ka0, rb + ka1);
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) ya[v][ih] = *reinterpret_cast<const bf16x8*>(sY + yq0 + 16 * ih * YP + v * 64);
+                slot = (slot == RING_BLKS - 1) ? 0 : slot + 1;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const char* c0 = sQr + 16 * st * ROWB + tk0;
+                    tqr[st][e] = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
+                }
+#pragma unroll
+            for (int c = 0; c < NSUB; c++) {
+                jA[c] = (w + NW * c - n0) & 7;          // window position of the class's block (0: its last tile)
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    const char* ya_ = sY + ya0 + 16 * st * YP + 64 * jA[c];
+                    da[c][st] = tr_pair(ya_, ya_ + 8 * YP);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- round 2a MFMAs
+#pragma unroll
+            for (int v = 0; v < 5; v++)
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya[v][ih], br[v], ar4[ih]);
+#pragma unroll
+            for (int c = 0; c < NSUB; c++) {
+                const int nA = n0 + jA[c];
+                acc_n[c] = nA;                  // (at the wave's first tile the accumulator is still empty)
+                if (nA >= 0 && nA < MB) {
+#pragma unroll
+                    for (int st = 0; st < 2; st++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) rd_acc[c][e] = mfma32(da[c][st], tqr[st][e], rd_acc[c][e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- round 2b reads: distance blocks 5 - 8, and the NEXT tile's score-phase operand rows (ahead of barrier 2)
+            bf16x8 br2[4], ya2[4][NIH];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const char* rb = sR + slot * RBLK_BYTES;
+                br2[v] = tr_pair(rb + ka0, rb + ka1);
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) ya2[v][ih] = *reinterpret_cast<const bf16x8*>(sY + yq0 + 16 * ih * YP + (v + 5) * 64);
+                slot = (slot == RING_BLKS - 1) ? 0 : slot + 1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+#pragma unroll
+                for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya2[v][ih], br2[v], ar4[ih]);
+            STAMP(8)
+            // this tile's partial dq -> slab of this key block (rows = queries 16 ih + 4 (l >> 4) + t, column = element 16 eq + (l & 15))
             {
                 const int x = I - M - 254 - p0;
                 const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
-                float* dst = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride +
-                             ((size_t)b * T + I + 16 * ih + 4 * g16) * (size_t)(p.H * 64) + h * 64 + 16 * eq + (l & 15);
+                const int rowb = p.H * 64 * 4;              // bytes per dq row of a slab
+                float* tile = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride + ((size_t)b * T + I + 16 * ih0) * (size_t)(p.H * 64) + h * 64 + 16 * eq;
+                const __amdgpu_buffer_rsrc_t rs_sl = __builtin_amdgcn_make_buffer_rsrc((void*)tile, 0, -1, 0x00020000);
+                const int vo = 4 * g16 * rowb + (l & 15) * 4;
 #pragma unroll
-                for (int t = 0; t < 4; t++) dst[(size_t)t * (p.H * 64)] = aw4[t] + ar4[t];
-                cw += (aw4[0] + aw4[1]) + (aw4[2] + aw4[3]);
-                cr += (ar4[0] + ar4[1]) + (ar4[2] + ar4[3]);
+                for (int ih = 0; ih < NIH; ih++) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, aw4[ih][t] + ar4[ih][t]), rs_sl, vo, (16 * ih + t) * rowb, 0);
+                    cw += (aw4[ih][0] + aw4[ih][1]) + (aw4[ih][2] + aw4[ih][3]);
+                    cr += (ar4[ih][0] + ar4[ih][1]) + (ar4[ih][2] + ar4[ih][3]);
+                }
             }
-            // dRd: the block of this wave's residue class.  Window position j0 = (w - n0) mod 8; at 0 the block leaves the window
-            // after this tile (flush) and the class's next block enters at position 8.
-            auto drd_block = [&](int j) {
-                const int n = n0 + j;
-                if (n < 0 || n >= MB) return;
+            STAMP(9)
+            // dRd: a block at window position 0 leaves the window after this tile (flush) and the class's next block enters at 8
 #pragma unroll
-                for (int st = 0; st < 2; st++) {
-                    const char* ya = sY + ya0 + 16 * st * YP + 64 * j;
-                    const bf16x8 a = tr_pair(ya, ya + 8 * YP);
-                    const char* c0 = sQr + 16 * st * ROWB + tk0;
+            for (int c = 0; c < NSUB; c++) {
+                if (jA[c] == 0) {
+                    drd_flush(c);
+                    acc_n[c] = n0 + 8;
+                    if (n0 + 8 >= 0 && n0 + 8 < MB) {
+                        bf16x8 d8[2];
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const bf16x8 bq = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
-                        rd_acc[e] = mfma32(a, bq, rd_acc[e]);
+                        for (int st = 0; st < 2; st++) {
+                            const char* ya_ = sY + ya0 + 16 * st * YP + 64 * 8;
+                            d8[st] = tr_pair(ya_, ya_ + 8 * YP);
+                        }
+#pragma unroll
+                        for (int st = 0; st < 2; st++)
+#pragma unroll
+                            for (int e = 0; e < 2; e++) rd_acc[c][e] = mfma32(d8[st], tqr[st][e], rd_acc[c][e]);
                     }
                 }
-            };
-            const int j0 = (w - n0) & 7;
-            if (j0 == 0) {
-                acc_n = n0;                     // (at the wave's first tile the accumulator is still empty)
-                drd_block(0);
-                drd_flush();
-                acc_n = n0 + 8;
-                drd_block(8);
-            } else {
-                acc_n = n0 + j0;
-                drd_block(j0);
             }
-            if (more) gblocks(I + QT, sQ + (cur ^ 1) * QSET + QIMG);
+            STAMP(10)
+            STAMP(11)
         }
         __syncthreads();
+        STAMP(12)
         cur ^= 1;
     }
-    drd_flush();
+#pragma unroll
+    for (int c = 0; c < NSUB; c++) drd_flush(c);
+    STAMP(13)
+    STAMP_FLUSH
 
     // ---- epilogue: bias gradients (stored keys' part), dk, dv
     {
@@ -547,19 +798,24 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     }
     {
         const float fk = 1.f / p.scale_log2e, fv = 1.f / p.scale;      // dK was accumulated against scale*log2(e)*Qw, dV against scale*dO
-        if (kok) {
-            const size_t srow = (size_t)(pk - p0);
-            bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
-            bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+        for (int kb = 0; kb < NSUB; kb++) {
+            if (kok[kb]) {
+                const size_t srow = (size_t)(Pw + 32 * kb + r - p0);
+                bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
+                bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
 #pragma unroll
-                for (int grp = 0; grp < 4; grp++) {
-                    const int e0 = 32 * e + 8 * grp + 4 * hh;
-                    const u32x2 wk = {pack2bf(ak[e][4 * grp] * fk, ak[e][4 * grp + 1] * fk), pack2bf(ak[e][4 * grp + 2] * fk, ak[e][4 * grp + 3] * fk)};
-                    const u32x2 wv = {pack2bf(av[e][4 * grp] * fv, av[e][4 * grp + 1] * fv), pack2bf(av[e][4 * grp + 2] * fv, av[e][4 * grp + 3] * fv)};
-                    *reinterpret_cast<u32x2*>(dkp + e0) = wk;
-                    *reinterpret_cast<u32x2*>(dvp + e0) = wv;
+                for (int e = 0; e < 2; e++) {
+#pragma unroll
+                    for (int grp = 0; grp < 4; grp++) {
+                        const int e0 = 32 * e + 8 * grp + 4 * hh;
+                        const u32x2 wk = {pack2bf(ak[kb][e][4 * grp] * fk, ak[kb][e][4 * grp + 1] * fk),
+                                          pack2bf(ak[kb][e][4 * grp + 2] * fk, ak[kb][e][4 * grp + 3] * fk)};
+                        const u32x2 wv = {pack2bf(av[kb][e][4 * grp] * fv, av[kb][e][4 * grp + 1] * fv),
+                                          pack2bf(av[kb][e][4 * grp + 2] * fv, av[kb][e][4 * grp + 3] * fv)};
+                        *reinterpret_cast<u32x2*>(dkp + e0) = wk;
+                        *reinterpret_cast<u32x2*>(dvp + e0) = wv;
+                    }
                 }
             }
         }
@@ -569,70 +825,65 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
 // ---------------------------------------------------------------------------------------------------------------
 // dq[b,i,:] = bf16( sum over the key blocks that see query tile i/32 of their slab rows  +  phantom term ),
 // phantom term (zero memories, oph != NULL):  -scale * delta[b,h,i] * 2^(mph[b,h,i] - lse[b,h,i] log2 e) * oph[b,i,h,:]
-// -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Its column sums
-// over (b, i) are those cells' part of d r_r_bias.  One workgroup = one 32-query tile of one sequence, thread = 8 consecutive
-// elements of a 64-element head, rows swept in turn (every slab access is a contiguous run of the row).
+// -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Elementwise:
+// thread = 8 consecutive elements of one row; the (at most M/256 + 1) slab reads of a thread are independent 32-byte loads.
+// (Those cells' part of d r_r_bias, the column sums of the phantom term, is formed by mxl_relattn_drd_phantom, which holds the
+// column sums of their dG anyway.)
 // ---------------------------------------------------------------------------------------------------------------
 struct FinP {
     const float* slab; const bf16_t* oph; const float *mph, *lse, *delta;
-    bf16_t* dq; float* d_rrb;
+    bf16_t* dq;
     int B, T, H, M, Kc;
     long long slab_stride, o_bs, dq_bs; int o_rs, dq_rs;
     float scale;
 };
 __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
-    const int it = blockIdx.x, b = blockIdx.y;
-    const int I = it * QT, d = p.H * 64;
+    const int d = p.H * 64, nch = d >> 3;
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long long)p.B * p.T * nch) return;
+    const int c = (int)(item % nch);
+    const long long row = item / nch;
+    const int b = (int)(row / p.T), i = (int)(row % p.T);
+    const int I = i & ~31;
     const int p0 = p.T - p.Kc;
     const int nkb = (p.Kc + KBLK - 1) / KBLK;
     const int x = I - p.M - 254 - p0;
     const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
     const int kb_hi = min(nkb - 1, (I + 31 - p0) >> 8);
     const int nsl = kb_hi - kb_lo + 1;
-    const int nch = d >> 3;                              // 8-element chunks per row
-    const int rgs = max(1, 256 / nch);                   // rows in flight per sweep (thread = (row group, chunk))
-    const int rg = threadIdx.x / nch;
-    if (rg < rgs) {
-        const int c = threadIdx.x % nch;
-        const int h = c >> 3;
-        float cs[8];
+    float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) cs[j] = 0.f;
-#pragma unroll 1
-        for (int ii = rg; ii < QT; ii += rgs) {
-            const int i = I + ii;
-            float acc[8];
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    const float* sp = p.slab + (size_t)row * (size_t)d + c * 8;
+#pragma unroll 3
+    for (int s = 0; s < nsl; s++) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride + 4);
 #pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = 0.f;
-            const float* sp = p.slab + ((size_t)b * p.T + i) * (size_t)d + c * 8;
-            for (int s = 0; s < nsl; s++) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride + 4);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
-            }
-            if (p.oph) {
-                const size_t sidx = ((size_t)b * p.H + h) * p.T + i;
-                const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
-                const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float t = f * bf2f((bf16_t)o[j]);
-                    acc[j] += t;
-                    cs[j] += t;
-                }
-            }
-            const u32x4 wq = {pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
-            *reinterpret_cast<u32x4*>(p.dq + (size_t)b * p.dq_bs + (size_t)i * p.dq_rs + c * 8) = wq;
-        }
-        if (p.oph) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) atomicAdd(p.d_rrb + c * 8 + j, cs[j]);
-        }
+        for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
     }
+    if (p.oph) {
+        const size_t sidx = ((size_t)b * p.H + (c >> 3)) * p.T + i;
+        const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] += f * bf2f((bf16_t)o[j]);
+    }
+    const u32x4 wq = {pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(p.dq + (size_t)b * p.dq_bs + (size_t)i * p.dq_rs + c * 8) = wq;
 }
 
 }  // namespace
+
+#ifdef MXL_STAMP
+extern "C" int mxl_debug_fused_stamps(unsigned long long* host_out16) {
+    hipError_t e = hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M) {
     if (B <= 0 || T <= 0 || H <= 0 || dh != 64 || M <= 0) return 0;
@@ -661,8 +912,9 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -681,16 +933,19 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     p.scale = scale; p.scale_log2e = scale * LOG2E;
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_FUSED, s);
-        hipLaunchKernelGGL(relattn_bwd_fused_kernel, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
+        static const int nsub = getenv("MXL_FUSED_NSUB") ? atoi(getenv("MXL_FUSED_NSUB")) : MXL_FUSED_NSUB_DEFAULT;
+        if (nsub == 2) hipLaunchKernelGGL(relattn_bwd_fused_kernel<2>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(256), SMEM, s, p);
+        else hipLaunchKernelGGL(relattn_bwd_fused_kernel<1>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
     }
     FinP f;
     f.slab = ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
-    f.dq = (bf16_t*)dq; f.d_rrb = d_r_r_bias;
+    f.dq = (bf16_t*)dq;
     f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
     f.slab_stride = p.slab_stride; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_DQFIN, s);
-        hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3(T / QT, B), dim3(256), 0, s, f);
+        const long long items = (long long)B * T * (H * 8);
+        hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, f);
     }
     MXL_LAUNCH_CHECK();
     return MXL_OK;

@@ -468,7 +468,8 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
         if Kc < M + T:
             add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
             check(lib().mxl_relattn_drd_phantom(_p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d_rd.stride(0), _p(rd), int(rd_rs),
-                                                _p(lse), _p(delta), float(scale), Kc, _stream()), 'mxl_relattn_drd_phantom')
+                                                _p(d_rrb), _p(lse), _p(delta), float(scale), Kc, _stream()),
+                  'mxl_relattn_drd_phantom')
     if defer_drd:
         return phantom
     phantom()
