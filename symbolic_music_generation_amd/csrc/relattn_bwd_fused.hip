@@ -409,6 +409,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     }
     __syncthreads();
     gblocks(it_lo * QT, sQ + QIMG);
+    if (it_lo < it_hi) { load_q(it_lo + 1); load_r(((it_lo * QT - P0 - KBLK) >> 5) + 9); }      // stored at the top of the first tile
     __syncthreads();
 
     f32x16 ak[NSUB][2], av[NSUB][2];            // dK^T, dV^T : [sub-block][e half][e][key]
@@ -474,9 +475,12 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         const float* sLse = reinterpret_cast<const float*>(sDO + QIMG);
         const float* sDl = sLse + QT;
         const int n0 = (I - P0 - KBLK) >> 5;    // first distance block of this tile's window: column c = distance - 32 n0
-#ifndef MXL_ABL_NO_LOADS
-        if (more) { load_q(it + 1); load_r(n0 + 9); }
-#endif
+        // The rows of tile it + 1 were requested a whole tile ago: their LDS images (into the Q set and the ring slot that phase
+        // B of tile it - 1 was the last to read) go in now, and the rows of tile it + 2 are requested.  (Requested at the top of
+        // the tile that stores them, the loads were still in flight at the end of its score phase: 23 % of the wave time of
+        // the eight-wave form was that wait, profiles/r04_fused_stamp_anatomy.txt.)
+        if (more) { store_q(cur ^ 1); store_r(n0 + 9); }
+        if (it + 1 < it_hi) { load_q(it + 2); load_r(n0 + 10); }
         STAMP(0)
 
         // =============================== phase A: scores, dV, dK, dS -> X / Y ===============================
@@ -609,7 +613,6 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             }
         }
         STAMP(4)
-        if (more) { store_q(cur ^ 1); store_r(n0 + 9); }
         STAMP(5)
         __syncthreads();
         STAMP(6)
