@@ -1644,14 +1644,12 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         };
         const float nsc = -p.scale;
         for (int g = 0; g < min(PA, SA); g++) issueA(g);
-        if (SA > PA) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");      // 2 (PA - 1): step 0 has landed
+        if (SA > PA) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // 2 (PA - 2): steps 0 and 1 have landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-        for (int g = 0; g < SA; g++) {
-            // stage (g + PA) % 16 was last read in step g + PA - 16 < g: every wave passed that step's barrier long ago
-            const bool issued = g + PA < SA;
-            if (issued) issueA(g + PA);
+        // TWO steps per barrier (round 4): a step is 36 short MFMAs between an LDS round trip and a workgroup barrier, and at one
+        // barrier per step the four waves spent more time meeting than computing (1.04 ms for 0.24 ms of MFMA at the bench shape)
+        auto step = [&](int g) {
             const int tix = g % nph;
             const bool mixed = p.phantom_only && tix >= tph;      // wave-uniform: this tile also holds stored-key cells
             const char* st = smem + (g & (NSTA - 1)) * STA;
@@ -1702,8 +1700,17 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
                     accs[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa),
                                                                       __builtin_bit_cast(mfma_bf16x8, ones), accs[f], 0, 0, 0);
             }
-            // step g + 1 must have landed before the next iteration reads it; in the tail (nothing left to issue) drain once
-            if (issued) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        };
+#pragma unroll 1
+        for (int g = 0; g < SA; g += 2) {
+            // stages (g + PA) % 16 and (g + PA + 1) % 16 were last read in steps g - 4 and g - 3: that pair's barrier is behind every wave
+            const bool two = g + PA + 1 < SA;
+            if (g + PA < SA) issueA(g + PA);
+            if (two) issueA(g + PA + 1);
+            step(g);
+            if (g + 1 < SA) step(g + 1);
+            // steps g + 2 and g + 3 must have landed before the next pair reads them; in the tail (nothing left to issue) drain once
+            if (two) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();

@@ -104,6 +104,15 @@ __device__ __forceinline__ int qeoff(int row, int e) { return qoff(row, e >> 3) 
 __device__ __forceinline__ int sswz(int row) { return (((row >> 3) & 1) << 2) | (((row >> 1) & 1) << 1) | ((row >> 2) & 1); }
 __device__ __forceinline__ int soff(int row, int ch) { return row * ROWB + ((ch ^ sswz(row)) << 4); }
 
+// workgroup barrier for LDS hand-offs: waits for this wave's LDS operations only.  __syncthreads() also waits s_waitcnt vmcnt(0), i.e.
+// for every global store and atomic the wave has in flight -- the tile loop's slab stores and dRd atomics would be drained twice
+// per tile, with the other waves of the workgroup waiting at the barrier for the slowest drain.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
 }
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         }
         STAMP(4)
         STAMP(5)
-        __syncthreads();
+        lds_barrier();
         STAMP(6)
 
         // =============================== phase B: dq piece, dRd blocks, next tile's G ===============================
@@ -624,6 +633,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         // the next tile's G blocks (neither needs Y); round 2: the distance half of the dq piece and the dRd blocks.
         {
             f32x4 aw4[NIH], ar4[NIH];
+            f32x4 aw4b = {0.f, 0.f, 0.f, 0.f}, ar4b = {0.f, 0.f, 0.f, 0.f};      // eight waves: a second chain per product
 #pragma unroll
             for (int ih = 0; ih < NIH; ih++) { aw4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; ar4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             const char* sQrN = sQ + (cur ^ 1) * QSET + QIMG;       // the next tile's Qr image (stored before barrier 1)
@@ -649,10 +659,15 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             if (NSUB == 2) g_reads();
             __builtin_amdgcn_sched_barrier(0);
             // ---- round 1 MFMAs
+            if (NSUB == 2) {
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+                for (int u = 0; u < 8; u++)
 #pragma unroll
-                for (int ih = 0; ih < NIH; ih++) aw4[ih] = mfma16(xa[u][ih], bk[u], aw4[ih]);
+                    for (int ih = 0; ih < NIH; ih++) aw4[ih] = mfma16(xa[u][ih], bk[u], aw4[ih]);
+            } else {                    // one 16-row half per wave: two independent chains instead of one of eight dependent MFMAs
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { aw4[0] = mfma16(xa[u][0], bk[u], aw4[0]); aw4b = mfma16(xa[u + 1][0], bk[u + 1], aw4b); }
+            }
             if (NSUB == 1) {            // (256 registers: the G operands get a round of their own)
                 __builtin_amdgcn_sched_barrier(0);
                 g_reads();
@@ -707,10 +722,15 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- round 2a MFMAs
+            if (NSUB == 2) {
 #pragma unroll
-            for (int v = 0; v < 5; v++)
+                for (int v = 0; v < 5; v++)
 #pragma unroll
-                for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya[v][ih], br[v], ar4[ih]);
+                    for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya[v][ih], br[v], ar4[ih]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 5; v++) { if (v & 1) ar4b = mfma16(ya[v][0], br[v], ar4b); else ar4[0] = mfma16(ya[v][0], br[v], ar4[0]); }
+            }
 #pragma unroll
             for (int c = 0; c < NSUB; c++) {
                 const int nA = n0 + jA[c];
@@ -734,10 +754,17 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
                 slot = (slot == RING_BLKS - 1) ? 0 : slot + 1;
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (NSUB == 2) {
 #pragma unroll
-            for (int v = 0; v < 4; v++)
+                for (int v = 0; v < 4; v++)
 #pragma unroll
-                for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya2[v][ih], br2[v], ar4[ih]);
+                    for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya2[v][ih], br2[v], ar4[ih]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; v++) { if (v & 1) ar4b = mfma16(ya2[v][0], br2[v], ar4b); else ar4[0] = mfma16(ya2[v][0], br2[v], ar4[0]); }
+#pragma unroll
+                for (int t = 0; t < 4; t++) { aw4[0][t] += aw4b[t]; ar4[0][t] += ar4b[t]; }
+            }
             STAMP(8)
             // this tile's partial dq -> slab of this key block (rows = queries 16 ih + 4 (l >> 4) + t, column = element 16 eq + (l & 15))
             {
@@ -780,7 +807,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             STAMP(10)
             STAMP(11)
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(12)
         cur ^= 1;
     }
