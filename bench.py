@@ -187,13 +187,17 @@ def train_leg(args, ranks: Ranks):
     # key-owner, the q + r_r_bias operand, the dRd contraction) inside one HIP-event bracket on the launch stream, plus the
     # library's own per-kernel event pairs (mxl_ktime_*) for the forward and each backward kernel
     br = EventBracket()
-    orig_bwd = ops.relattn_bwd
+    orig_bwd, orig_fused = ops.relattn_bwd, ops.relattn_bwd_fused
 
     def timed_relattn_bwd(*a, **k):
         return br.run(lambda: orig_bwd(*a, **k))
 
+    def timed_relattn_bwd_fused(*a, **k):          # round 4: delta + fused pass + dq finish + (zero memories) the phantom cells' dRd
+        return br.run(lambda: orig_fused(*a, **k))
+
     if not args.no_roofline:
         ops.relattn_bwd = timed_relattn_bwd
+        ops.relattn_bwd_fused = timed_relattn_bwd_fused
 
     def on_timed(on):
         br.on = on and not args.no_roofline
@@ -209,7 +213,7 @@ def train_leg(args, ranks: Ranks):
             eng.optimizer_step(lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_scale=1.0 / world)
 
     dt = timed_steps(ranks, step, args.steps, args.warmup, on_timed=on_timed)
-    ops.relattn_bwd = orig_bwd
+    ops.relattn_bwd, ops.relattn_bwd_fused = orig_bwd, orig_fused
     kt = ops.ktime_collect() if not args.no_roofline else {}
     with torch.no_grad():
         loss = model(input_ids=ids, labels=labels).loss.item()
@@ -241,27 +245,44 @@ def train_leg(args, ranks: Ranks):
             # phantom value-sum, ops.relattn_fwd(..., oph=)) and enters the query-owner backward as an elementwise term: those
             # FLOPs are counted where they are executed, not in the backward group
             moved = 0.0
+            fused = bool(getattr(eng._last, 'fused_bwd', False))
+            Kc = eng._last.qkv[0].shape[1]
             if getattr(eng._last, 'oph', None) is not None:
-                Kc = eng._last.qkv[0].shape[1]
                 pz = -(((Kc - T) + 63) // 64) * 64
-                cells = sum(32 * max(0, M - (((g0 + 31 - pz) | 255) + 1)) for g0 in range(0, T, 32))
+                if fused:       # every key position below the first stored one (oph_all)
+                    cells = sum(max(0, M - 1 - (i - pz)) for i in range(T))
+                else:           # the all-phantom 256-distance blocks
+                    cells = sum(32 * max(0, M - (((g0 + 31 - pz) | 255) + 1)) for g0 in range(0, T, 32))
                 moved = 2.0 * B * d * cells
             alg -= moved
             ach = alg / (ms * 1e-3) / 1e12
             traffic, src = pmc_traffic(args.workload, B)
-            kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('relattn_bwd_delta_kernel', 0.0),
-                    'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M) - moved),
-                    'dkv': ('relattn_bwd_dkv_kernel', B * T * 4 * d * nbar), 'rowbias': ('add_rowbias_kernel', 0.0),
-                    'drd': ('relattn_drd_kernel', B * T * 2 * d * M)}
+            if fused:
+                # per query: n_real stored keys in its window, M - n_real phantom distances.  The fused pass owns dP, dQw, dK, dV,
+                # dQr and dRd over the stored keys (6 products); the phantom cells' dRd is the recompute kernel's; their dQr the forward's
+                n_real = sum(min(M, i - (T - Kc) + 1) for i in range(T)) / T
+                kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('fused_delta_kernel', 0.0),
+                        'fused': ('relattn_bwd_fused_kernel', B * T * 12.0 * d * n_real), 'dqfin': ('relattn_dq_finish_kernel', 0.0),
+                        'rowbias': ('add_rowbias_kernel', 0.0), 'drd': ('relattn_drd_kernel (phantom cells)', B * T * 2.0 * d * (M - n_real))}
+                group = ('delta', 'fused', 'dqfin', 'rowbias', 'drd')
+                desc = ('attention backward of one layer: fused_delta + relattn_bwd_fused + relattn_dq_finish + add_rowbias + '
+                        'relattn_drd (phantom cells) (one HIP-event bracket around all five launches)')
+            else:
+                kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('relattn_bwd_delta_kernel', 0.0),
+                        'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M) - moved),
+                        'dkv': ('relattn_bwd_dkv_kernel', B * T * 4 * d * nbar), 'rowbias': ('add_rowbias_kernel', 0.0),
+                        'drd': ('relattn_drd_kernel', B * T * 2 * d * M)}
+                group = ('delta', 'dq8', 'dkv', 'rowbias', 'drd')
+                desc = ('attention backward of one layer: relattn_bwd_delta + relattn_bwd_dq8 + relattn_bwd_dkv + add_rowbias + '
+                        'relattn_drd (one HIP-event bracket around all five launches)')
             kernels = {}
             for key, (kname, kflop) in kalg.items():
                 if key in kt and kt[key][1]:
                     kms = kt[key][0] / kt[key][1]
                     kernels[key] = {'kernel': kname, 'ms': kms, 'launches_timed': kt[key][1], 'alg_flop': kflop,
                                     'frac': kflop / (kms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-            bwd_sum = sum(kernels[k]['ms'] for k in ('delta', 'dq8', 'dkv', 'rowbias', 'drd') if k in kernels)
-            out['roofline'] = {'kernel': 'attention backward of one layer: relattn_bwd_delta + relattn_bwd_dq8 + relattn_bwd_dkv + '
-                                         'add_rowbias + relattn_drd (one HIP-event bracket around all five launches)',
+            bwd_sum = sum(kernels[k]['ms'] for k in group if k in kernels)
+            out['roofline'] = {'kernel': desc,
                                'bound': 'mfma', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'HBM bytes per launch group (PMC)', 'traffic_source': src,
@@ -437,9 +458,13 @@ def pmc_traffic(workload, B):
         return None, None
     k = rec['kernels']
     names = rec.get('attention_backward_group')
-    if names is None:       # every launch of the bracketed group: delta, query-owner, key-owner, q + r_r_bias, dRd contraction
-        dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
-        names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']
+    if names is None:       # every launch of the bracketed group
+        fused = [n for n in k if n.startswith('relattn_bwd_fused_kernel')]
+        if fused:           # round 4: delta, the fused pass, the dq finish, q + r_r_bias, the phantom cells' dRd
+            names = ['fused_delta_kernel', fused[0], 'relattn_dq_finish_kernel', 'add_rowbias_kernel', 'relattn_drd_kernel']
+        else:               # delta, query-owner, key-owner, q + r_r_bias, dRd contraction
+            dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
+            names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']
     if not all(n in k for n in names):
         return None, None
     return sum(k[n]['hbm_bytes_per_launch'] * k[n].get('launches_per_group', 1) for n in names), os.path.basename(path)
