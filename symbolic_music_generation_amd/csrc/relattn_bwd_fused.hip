@@ -581,20 +581,23 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
                         const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
                         const int d = I + ii - pk;
                         const bool valid = (d >= 0) && (d <= M - 1) && kok[kb] && active[kb];
-                        const float pv = valid ? __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[kb][j])) : 0.f;
+                        // (the exponent is replaced, not the result: with `valid ? exp2(x) : 0` hipcc branches around every
+                        // exponential -- sixteen exec-masked blocks on the tiles that cross the causal diagonal)
+                        const float x = add_f16(s[kb][j], bdu[kb][j]);
+                        const float pv = __builtin_amdgcn_exp2f(valid ? x : -1.0e30f);
                         pr[j] = pv;
-                        s[kb][j] = valid ? pv * dp[kb][j] : 0.f;
+                        s[kb][j] = pv * (valid ? dp[kb][j] : 0.f);
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < 8; m++) { dsw[kb][m] = pack2bf(s[kb][2 * m], s[kb][2 * m + 1]); prw[kb][m] = pack2bf(pr[2 * m], pr[2 * m + 1]); }
+                if (NSUB == 1) tr_frags();      // the score registers are free now: requested ahead of the twenty LDS writes below
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++)
                     *reinterpret_cast<u32x2*>(sX + kb * 2048 + (xw ^ (grp << 4))) = u32x2{dsw[kb][2 * grp], dsw[kb][2 * grp + 1]};
                 yskew_write16(yWb - 64 * kb, dsw[kb]);
             }
             STAMP(3)
-            if (NSUB == 1) tr_frags();
             // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order; shared by the sub-blocks)
 #pragma unroll
             for (int st = 0; st < 2; st++) {
@@ -688,7 +691,23 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
                         *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
                     }
                 }
-                if (w == 0) gblock(8, n0N, gq_);
+                if (w == 0) {           // the ninth block of the window: its four row fragments in one batch (the registers of block w's)
+                    const char* rb = sR + ((n0N + 8 + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) ga[0][ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 g;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) g[t] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) g = mfma32(ga[0][ks], gq_[ks], g);
+                    char* gw = sG + r * GP + (32 * 8 + 4 * hh) * 2;
+#pragma unroll
+                    for (int grp = 0; grp < 4; grp++) {
+                        const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                        *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
+                    }
+                }
             }
             STAMP(7)
             __builtin_amdgcn_sched_barrier(0);
