@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument('--decode-steps', type=int, default=0, help='decode steps to time (0 = the whole C5 generation)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-context-legs', action='store_true', help='skip the C2 / mode-S / published-config legs of the default line')
     ap.add_argument('--grad-exchange', default='fp32', choices=['fp32', 'bf16'],
                     help='dtype of the data-parallel gradient all-reduce (fp32 = what HF DDP exchanges in the reference stack)')
     ap.add_argument('--master-port', type=int, default=29533)
@@ -365,6 +366,96 @@ def reformer_leg(args, ranks: Ranks, steps: int, warmup: int):
     return out
 
 
+def context_legs(args, ranks: Ranks):
+    """Extra legs of the default one-GPU line (the headline fields are untouched): BASELINE.json configs[1]
+    (C2), C3 with carried real memories (SURVEY 8(d) mode S, labelled), and the two configurations the reference's notebooks
+    logged a throughput for (a single Tesla P100 with fp16 AMP: `vs_baseline` there is this run's tokens/s
+    over that figure and says so -- different hardware, different precision, context only).  Each leg: a few untimed and at most
+    five timed optimisation steps (forward + backward + clip + AdamW, dropout on), no roofline object, no CPU baseline."""
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    dev = ranks.dev
+    steps, warmup = min(args.steps, 5), 2
+    legs = {}
+
+    def run(name, model, ids, flops_tok, workload, mems=None, extra=None):
+        eng = model.engine
+
+        def step():
+            with torch.no_grad():
+                eng.zero_grad()
+                if mems is not None:
+                    eng.forward(ids, mems=mems, labels=ids, train=True)
+                else:
+                    model(input_ids=ids, labels=ids)
+                eng.backward()
+                eng.optimizer_step(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0)
+
+        dt = timed_steps(ranks, step, steps, warmup)
+        toks = ids.numel() * steps
+        legs[name] = {'metric': 'train tokens/sec, one MI355X', 'value': toks / dt, 'unit': 'tokens/s', 'steps': steps, 'warmup': warmup,
+                      'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16', 'data': 'synthetic', 'vs_baseline': None,
+                      'config': {'workload': workload, 'per_gpu_batch': ids.shape[0], 'seq_len': ids.shape[1],
+                                 'train_flops_per_token': flops_tok,
+                                 'whole_step_mfma_frac': flops_tok * toks / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12)}}
+        if extra:
+            legs[name].update(extra)
+
+    gen = torch.Generator(device='cpu').manual_seed(77)
+    # ---- C2 (BASELINE.json configs[1]), mode R
+    wl = WORKLOADS['c2']
+    cfg = MyTransfoXLConfig(wl['size'], max_length=wl['T'], vocab_size=V, n_layer=wl['n_layer'], mem_len=wl['M'], cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
+    ids = torch.randint(4, V, (wl['B'], wl['T']), generator=gen).to(dev)
+    run('c2', model, ids, 3 * flops_per_token_fwd(cfg.n_layer, cfg.d_model, wl['T'], wl['M'], V), wl['name'])
+    del model
+    torch.cuda.empty_cache()
+    # ---- C3, mode S: the second 2048-token segment of a stream, with the first segment's (detached) memories carried in
+    wl = WORKLOADS['c3']
+    cfg = MyTransfoXLConfig(wl['size'], max_length=wl['T'], vocab_size=V, n_layer=wl['n_layer'], mem_len=wl['M'], cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
+    Bs = 32
+    seg0 = torch.randint(4, V, (Bs, wl['T']), generator=gen).to(dev)
+    ids = torch.randint(4, V, (Bs, wl['T']), generator=gen).to(dev)
+    with torch.no_grad():
+        mems = [m.detach() for m in model.engine.forward(seg0, train=False)['mems']]
+    d, L, T, M = cfg.d_model, cfg.n_layer, wl['T'], wl['M']
+    f_fwd_s = L * (24 * d * d + 6 * d * M) + 2 * d * V             # SURVEY 8(d) mode S: n_bar = M, attention 6 d M
+    run('c3_mode_s', model, ids, 3 * f_fwd_s,
+        'TransfoXL 12L/768d T=2048 M=2048 V=1190, SURVEY 8(d) MODE S: segment-recurrent, carried real memories (Kc = 4096); '
+        'the headline line is mode R', mems=mems)
+    del model, mems
+    torch.cuda.empty_cache()
+    # ---- the reference's own logged TransfoXL run: base, seq 512, mem 256, batch 32 (notebook/train/transformer-xl.ipynb:491-698)
+    cfg = MyTransfoXLConfig('base', max_length=512, vocab_size=418, mem_len=256, cutoffs=[])
+    model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).train()
+    ids = torch.randint(4, 418, (32, 512), generator=gen).to(dev)
+    run('published_transfoxl_base', model, ids, 3 * flops_per_token_fwd(cfg.n_layer, cfg.d_model, 512, 256, 418),
+        'TransfoXL base 12L/768d seq 512 mem 256 V=418 batch 32, mode R (the run logged in notebook/train/transformer-xl.ipynb)')
+    legs['published_transfoxl_base'].update(
+        vs_baseline=legs['published_transfoxl_base']['value'] / 2815.0,
+        baseline={'value': 2815.0, 'unit': 'tokens/s', 'hardware': '1x Tesla P100-PCIE-16GB, fp16 AMP (DIFFERENT HARDWARE: context only)',
+                  'source': 'BASELINE.md section 1; notebook/train/transformer-xl.ipynb:491,698 (epoch wall time)'})
+    del model
+    torch.cuda.empty_cache()
+    # ---- the reference's own logged Reformer run: base, seq 4096, num_hashes 2, batch 17 (notebook/train/reformer.ipynb:2870)
+    cfg = MyReformerConfig('base', vocab_size=420, max_position_embeddings=4096, axial_pos_shape=(64, 64))
+    model = MyReformerModelWithLMHead(cfg, device=dev, seed=77).train()
+    ids = torch.randint(4, 420, (17, 4096), generator=gen).to(dev)
+    dr, nh = cfg.hidden_size, cfg.num_hashes
+    nl = len(cfg.attn_layers) // 2
+    f_fwd_r = nl * (24 * dr * dr + 512 * dr) + nl * (22 * dr * dr + nh * (dr * 128 + 512 * dr)) + 2 * 2 * dr * 420
+    run('published_reformer_base', model, ids, 3 * f_fwd_r,
+        f'Reformer base {len(cfg.attn_layers)}L/768d seq 4096 num_hashes={nh} V=420 batch 17 (the run logged in notebook/train/reformer.ipynb)')
+    legs['published_reformer_base'].update(
+        vs_baseline=legs['published_reformer_base']['value'] / 5849.0,
+        baseline={'value': 5849.0, 'unit': 'tokens/s', 'hardware': '1x Tesla P100-PCIE-16GB, fp16 AMP (DIFFERENT HARDWARE: context only)',
+                  'source': 'BASELINE.md section 1; notebook/train/reformer.ipynb:2870-2871 (train_samples_per_second 1.428 x 4096)'})
+    del model
+    torch.cuda.empty_cache()
+    return legs
+
+
 def decode_leg(args, ranks: Ranks, warmup: int):
     """TransfoXL 12L/768d cached-mem decode, batch 64 prompts x 256 tokens, top-k 8, generate to 2048,
     one hipGraph replay per token.  A 'step' here = one generated token for the whole batch."""
@@ -659,6 +750,8 @@ def main(argv=None):
                 dec = decode_leg(args, ranks, 3)
                 ref = reformer_leg(args, ranks, min(args.steps, 10), min(args.warmup, 3))
                 out['decode'], out['reformer'] = dec, ref
+                if not args.no_context_legs:
+                    out['context'] = context_legs(args, ranks)
     if out is not None:
         print(json.dumps(out), flush=True)
     ranks.close()
