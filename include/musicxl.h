@@ -167,14 +167,20 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
  * supplies zeros): the key positions below the first stored one have k = v = 0 and exist only as distances.  Their part of dq
  * is  -scale * delta_i * 2^(mph_i - lse_i * log2 e) * oph_i  with oph / mph from mxl_relattn_fwd_phantom2(..., oph_all = 1)
  * (required then), and their part of d_rd is owed by the caller: mxl_relattn_drd_phantom.  With Kc == M + T oph / mph are unused.
- * `delta` (B,H,T) f32 scratch is written.  dq_rs, dq_bs multiples of 8. */
+ * `delta` (B,H,T) f32 scratch is written.  dq_rs, dq_bs multiples of 8.
+ * defer_finish != 0: the slab sum is left to the caller (mxl_relattn_dq_finish, same ws / oph / mph / lse / delta / dq arguments) --
+ * it depends on nothing but this call and is HBM-bound, so the caller may run it on another stream beside
+ * mxl_relattn_drd_phantom. */
 size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M);
 int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                           const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
                           const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
                           long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                          long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream);
+                          long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, int defer_finish, void* stream);
+int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
+                          int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs, int dq_rs,
+                          float scale, void* stream);
 /* mxl_relattn_fwd_phantom with a choice of which phantom cells enter oph: oph_all = 0 is mxl_relattn_fwd_phantom (the
  * all-phantom 256-distance blocks, for mxl_relattn_bwd_sparse_dg_oph); oph_all = 1 sums over EVERY key position below the first
  * stored key tile (for mxl_relattn_bwd_fused; needs (T - Kc) % 64 == 0). */

@@ -13,6 +13,7 @@
 //                       (q + r_r_bias) by the batched TT GEMM to obtain dRd (a correlation along diagonals that neither a
 //                       query- nor a key-owner can accumulate on chip).
 //   relattn_bwd_dkv   : key-owner (lane = key): dk, dv.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "musicxl_internal.h"
@@ -1562,6 +1563,9 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
     const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
+    // phantom mode: a distance block's work grows with its index (block k recomputes 8 k + 8 query tiles per sequence): highest
+    // block first, so that the launch ends on the short workgroups
+    if (p.phantom_only) bx_ = gridDim.x - 1 - bx_;
     const int d0 = bx_ * 256;
     // tiles [0, nph) of every batch item lie entirely on phantom distances for this 256-distance block (i0 + 31 - pz < d0, the
     // rule by which the query-owner kernel skipped their dG stores): recomputed below; the others are streamed
@@ -1666,16 +1670,25 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
                 for (int ks = 0; ks < 2; ks++) qa[t][ks] = *reinterpret_cast<const bf16x8*>(st + qo[t][ks]);
 #pragma unroll
             for (int t = 0; t < 4; t++) fb[t] = trfrag(st + bo2[t], 16 * 128);
+            // the sixteen G MFMAs of the step first (all four 16-distance fragments), then per fragment exp -> pack -> contraction:
+            // the contraction MFMAs of fragment f then run under the exponentials of f + 1 instead of every fragment waiting for
+            // the G products it has just issued (round 4)
+            f32x4 cg0[4], cg1[4];
 #pragma unroll
             for (int f = 0; f < 4; f++) {
-                f32x4 c0 = {l0[0], l0[1], l0[2], l0[3]}, c1 = {l1[0], l1[1], l1[2], l1[3]};
+                cg0[f] = f32x4{l0[0], l0[1], l0[2], l0[3]};
+                cg1[f] = f32x4{l1[0], l1[1], l1[2], l1[3]};
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[0][ks]),
-                                                                 __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[1][ks]),
-                                                                 __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), c1, 0, 0, 0);
+                    cg0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[0][ks]),
+                                                                     __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), cg0[f], 0, 0, 0);
+                    cg1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, qa[1][ks]),
+                                                                     __builtin_bit_cast(mfma_bf16x8, rdf[f][ks]), cg1[f], 0, 0, 0);
                 }
+            }
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const f32x4 c0 = cg0[f], c1 = cg1[f];
                 float g0[4], g1[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1937,6 +1950,14 @@ static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, 
     // batch groups: fill the 512 resident workgroup slots about once (each workgroup ends with 64 KB of fp32 atomics)
     const int tiles = ((M + 255) / 256) * H;
     int groups = 512 / tiles;
+    // phantom mode: the workgroups of distance block k run 8 k + 8 steps per sequence (8 .. 64 at M = 2048), so one workgroup per
+    // resident slot leaves the launch as long as its longest members (832 steps against a mean of 468 at the bench shape): three
+    // six times as many, shorter workgroups, the long ones first, and the dispatcher balances them (200 MB of end-of-workgroup
+    // atomics per launch instead of 31): 1.03 -> 0.80 ms (factor 2 / 3 / 4 / 6 / 12: 0.95 / 0.85 / 0.83 / 0.80 / 0.84)
+    if (phantom_only) {
+        static const int fac = getenv("MXL_DRD_PH_FACTOR") ? atoi(getenv("MXL_DRD_PH_FACTOR")) : 6;
+        groups = (fac * 512 + tiles - 1) / tiles;
+    }
     if (groups < 1) groups = 1;
     if (groups > B) groups = B;
     p.bgroup = (B + groups - 1) / groups;

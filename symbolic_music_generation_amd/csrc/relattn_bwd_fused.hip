@@ -944,7 +944,8 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
                                      void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
                                      const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
                                      long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                                     long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, void* stream) {
+                                     long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, int defer_finish,
+                                     void* stream) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out && dout && lse && delta && dq && dk && dv && d_rd && d_r_w_bias &&
                   d_r_r_bias && ws);
     if (dh != 64) return MXL_EUNSUPPORTED;
@@ -986,11 +987,25 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
         if (nsub == 2) hipLaunchKernelGGL(relattn_bwd_fused_kernel<2>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(256), SMEM, s, p);
         else hipLaunchKernelGGL(relattn_bwd_fused_kernel<1>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
     }
+    MXL_LAUNCH_CHECK();
+    if (defer_finish) return MXL_OK;
+    return mxl_relattn_dq_finish(ws, oph, mph, lse, delta, dq, B, T, H, dh, M, Kc, o_bs, o_rs, dq_bs, dq_rs, scale, stream);
+}
+
+extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
+                                     int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs, int dq_rs,
+                                     float scale, void* stream) {
+    MXL_CHECK_ARG(ws && lse && delta && dq && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
+    if (dh != 64 || (T % 32) != 0 || (M % 256) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
+    MXL_CHECK_ARG(Kc == M + T || (oph && mph));
+    MXL_CHECK_ARG((o_rs % 8) == 0 && (o_bs % 8) == 0 && (dq_rs % 8) == 0 && (dq_bs % 8) == 0 && ((uintptr_t)dq % 16) == 0 &&
+                  ((uintptr_t)ws % 16) == 0 && (oph == nullptr || ((uintptr_t)oph % 16) == 0));
+    hipStream_t s = (hipStream_t)stream;
     FinP f;
     f.slab = ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
     f.dq = (bf16_t*)dq;
     f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
-    f.slab_stride = p.slab_stride; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
+    f.slab_stride = (long long)B * T * H * 64; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_DQFIN, s);
         const long long items = (long long)B * T * (H * 8);
