@@ -272,11 +272,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform: no phantom cell in this block
                     f32x16 g = cinit;
                     const int slot = (dblk + r) & 255;
+                    {
+                        bf16x8 ra[KS];           // the block's four Rd fragments in one batch, then the chain (round 4)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ks++) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
-                        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                                    __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
+                        for (int ks = 0; ks < KS; ks++) ra[ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ks++)
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[ks]),
+                                                                        __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                     }
                     // every (query, distance) cell of the block phantom and in range?  (scalar)
                     const bool fullblk = __builtin_amdgcn_readfirstlane(
@@ -405,16 +409,26 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             const char* cV = sV;
             const int dlo = iw0 - P - 64;
             // ---- S^T = K . Qw^T : two 32-key blocks
+            // (round 4) every K fragment of the tile first, a scheduling fence, then the two chains: left alone hipcc emits
+            // [one or two reads, wait, one MFMA] sixteen times -- an LDS round trip per MFMA with two waves per SIMD to hide it
             f32x16 s[2];
+            {
+                bf16x8 ka[2][KS];
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                s[kb] = cinit;               // = -m_run: the scores come out relative to the softmax reference
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++)
+                        ka[kb][ks] = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
+                __builtin_amdgcn_sched_barrier(0);
+                s[0] = cinit; s[1] = cinit;      // = -m_run: the scores come out relative to the softmax reference
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                                    __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++)
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ka[kb][ks]),
+                                                                        __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- G^T = Rd . Qr^T for the new distance blocks -> lane-private skew buffer (fp16)
             auto gblock = [&](int gb, f16x4 (&dst)[4]) {
@@ -436,8 +450,33 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             };
             f16x4 b0[4], b1[4];
             if (!have_ring) gblock(2, carry);
-            gblock(0, b0);
-            gblock(1, b1);
+            {   // both new distance blocks: eight Rd fragments, then two interleaved chains
+                bf16x8 ra[2][KS];
+#pragma unroll
+                for (int gb = 0; gb < 2; gb++) {
+                    const int slot = (dlo + 32 * gb + r) & 255;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 g0, g1;
+#pragma unroll
+                for (int j = 0; j < 16; j++) { g0[j] = 0.f; g1[j] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[0][ks]),
+                                                                 __builtin_bit_cast(mfma_bf16x8, qr[ks]), g0, 0, 0, 0);
+                    g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[1][ks]),
+                                                                 __builtin_bit_cast(mfma_bf16x8, qr[ks]), g1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const f32x4v v0 = {g0[4 * grp], g0[4 * grp + 1], g0[4 * grp + 2], g0[4 * grp + 3]};
+                    const f32x4v v1 = {g1[4 * grp], g1[4 * grp + 1], g1[4 * grp + 2], g1[4 * grp + 3]};
+                    b0[grp] = __builtin_convertvector(v0, f16x4);
+                    b1[grp] = __builtin_convertvector(v1, f16x4);
+                }
+            }
 #pragma unroll
             for (int grp = 0; grp < 4; grp++) {
                 *reinterpret_cast<f16x4*>(gW + 8 * grp) = b0[grp];
