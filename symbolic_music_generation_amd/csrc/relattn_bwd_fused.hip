@@ -86,7 +86,7 @@ struct FusedP {
     const bf16_t *q, *k, *v, *rd, *dout;
     const float *rwb, *rrb, *lse, *delta;
     bf16_t *dk, *dv;
-    float* slab;          // [nslot][B][T][H*64] fp32 partial dq, slot = key block - first key block that sees the query tile
+    bf16_t* slab;         // [nslot][B][T][H*64] bf16 partial dq, slot = key block - first key block that sees the query tile
     float* drd;           // (M, drd_ld) fp32, +=
     float *d_rwb, *d_rrb; // (H, 64) fp32, +=  (the stored keys' part)
     int B, T, H, M, Kc;
@@ -664,12 +664,15 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             // ---- round 1 MFMAs
             if (NSUB == 2) {
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-#pragma unroll
+                for (int u = 0; u < 8; u++) {
+    #pragma unroll
                     for (int ih = 0; ih < NIH; ih++) aw4[ih] = mfma16(xa[u][ih], bk[u], aw4[ih]);
+                }
             } else {                    // one 16-row half per wave: two independent chains instead of one of eight dependent MFMAs
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) { aw4[0] = mfma16(xa[u][0], bk[u], aw4[0]); aw4b = mfma16(xa[u + 1][0], bk[u + 1], aw4b); }
+                for (int u = 0; u < 8; u++) {
+                        if (u & 1) aw4b = mfma16(xa[u][0], bk[u], aw4b); else aw4[0] = mfma16(xa[u][0], bk[u], aw4[0]);
+                }
             }
             if (NSUB == 1) {            // (256 registers: the G operands get a round of their own)
                 __builtin_amdgcn_sched_barrier(0);
@@ -743,12 +746,15 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             // ---- round 2a MFMAs
             if (NSUB == 2) {
 #pragma unroll
-                for (int v = 0; v < 5; v++)
+                for (int v = 0; v < 5; v++) {
 #pragma unroll
                     for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya[v][ih], br[v], ar4[ih]);
+                }
             } else {
 #pragma unroll
-                for (int v = 0; v < 5; v++) { if (v & 1) ar4b = mfma16(ya[v][0], br[v], ar4b); else ar4[0] = mfma16(ya[v][0], br[v], ar4[0]); }
+                for (int v = 0; v < 5; v++) {
+                    if (v & 1) ar4b = mfma16(ya[v][0], br[v], ar4b); else ar4[0] = mfma16(ya[v][0], br[v], ar4[0]);
+                }
             }
 #pragma unroll
             for (int c = 0; c < NSUB; c++) {
@@ -775,12 +781,15 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             __builtin_amdgcn_sched_barrier(0);
             if (NSUB == 2) {
 #pragma unroll
-                for (int v = 0; v < 4; v++)
+                for (int v = 0; v < 4; v++) {
 #pragma unroll
                     for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya2[v][ih], br2[v], ar4[ih]);
+                }
             } else {
 #pragma unroll
-                for (int v = 0; v < 4; v++) { if (v & 1) ar4b = mfma16(ya2[v][0], br2[v], ar4b); else ar4[0] = mfma16(ya2[v][0], br2[v], ar4[0]); }
+                for (int v = 0; v < 4; v++) {
+                    if (v & 1) ar4b = mfma16(ya2[v][0], br2[v], ar4b); else ar4[0] = mfma16(ya2[v][0], br2[v], ar4[0]);
+                }
 #pragma unroll
                 for (int t = 0; t < 4; t++) { aw4[0][t] += aw4b[t]; ar4[0][t] += ar4b[t]; }
             }
@@ -789,15 +798,27 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             {
                 const int x = I - M - 254 - p0;
                 const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
-                const int rowb = p.H * 64 * 4;              // bytes per dq row of a slab
-                float* tile = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride + ((size_t)b * T + I + 16 * ih0) * (size_t)(p.H * 64) + h * 64 + 16 * eq;
+                // The slabs are bf16 (half the bytes of the round trip through the finish kernel, which sums them in fp32): a lane owns one
+                // column of four rows, so neighbouring lanes trade values (DPP quad swap) and the even lane stores the packed pair of
+                // rows 0 / 1, the odd lane that of rows 2 / 3 -- two 4-byte stores per lane instead of four.
+                const int rowb = p.H * 64 * 2;              // bytes per dq row of a slab
+                bf16_t* tile = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride + ((size_t)b * T + I + 16 * ih0) * (size_t)(p.H * 64) + h * 64 + 16 * eq;
                 const __amdgpu_buffer_rsrc_t rs_sl = __builtin_amdgcn_make_buffer_rsrc((void*)tile, 0, -1, 0x00020000);
-                const int vo = 4 * g16 * rowb + (l & 15) * 4;
+                const bool odd = (l & 1) != 0;
+                const int vo = (4 * g16 + (odd ? 2 : 0)) * rowb + ((l & 15) >> 1) * 4;
 #pragma unroll
                 for (int ih = 0; ih < NIH; ih++) {
+                    float v[4], nb[4];
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, aw4[ih][t] + ar4[ih][t]), rs_sl, vo, (16 * ih + t) * rowb, 0);
+                    for (int t = 0; t < 4; t++) {
+                        v[t] = aw4[ih][t] + ar4[ih][t];
+                        nb[t] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[t]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {       // even lanes: rows 0, 1 (own column first); odd lanes: rows 2, 3 (the neighbour's first)
+                        const float lo = odd ? nb[2 + u] : v[u], hi = odd ? v[2 + u] : nb[u];
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pack2bf(lo, hi), rs_sl, vo, (16 * ih + u) * rowb, 0);
+                    }
                     cw += (aw4[ih][0] + aw4[ih][1]) + (aw4[ih][2] + aw4[ih][3]);
                     cr += (ar4[ih][0] + ar4[ih][1]) + (ar4[ih][2] + ar4[ih][3]);
                 }
@@ -875,12 +896,12 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
 // dq[b,i,:] = bf16( sum over the key blocks that see query tile i/32 of their slab rows  +  phantom term ),
 // phantom term (zero memories, oph != NULL):  -scale * delta[b,h,i] * 2^(mph[b,h,i] - lse[b,h,i] log2 e) * oph[b,i,h,:]
 // -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Elementwise:
-// thread = 8 consecutive elements of one row; the (at most M/256 + 1) slab reads of a thread are independent 32-byte loads.
+// thread = 8 consecutive elements of one row; the (at most M/256 + 1) slab reads of a thread are independent 16-byte loads (the slabs are bf16, the sum fp32).
 // (Those cells' part of d r_r_bias, the column sums of the phantom term, is formed by mxl_relattn_drd_phantom, which holds the
 // column sums of their dG anyway.)
 // ---------------------------------------------------------------------------------------------------------------
 struct FinP {
-    const float* slab; const bf16_t* oph; const float *mph, *lse, *delta;
+    const bf16_t* slab; const bf16_t* oph; const float *mph, *lse, *delta;
     bf16_t* dq;
     int B, T, H, M, Kc;
     long long slab_stride, o_bs, dq_bs; int o_rs, dq_rs;
@@ -903,13 +924,12 @@ __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
-    const float* sp = p.slab + (size_t)row * (size_t)d + c * 8;
+    const bf16_t* sp = p.slab + (size_t)row * (size_t)d + c * 8;
 #pragma unroll 3
     for (int s = 0; s < nsl; s++) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * p.slab_stride + 4);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sp + (size_t)s * p.slab_stride);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
+        for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)a[j]);
     }
     if (p.oph) {
         const size_t sidx = ((size_t)b * p.H + (c >> 3)) * p.T + i;
@@ -936,7 +956,7 @@ extern "C" int mxl_debug_fused_stamps(unsigned long long* host_out16) {
 
 extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M) {
     if (B <= 0 || T <= 0 || H <= 0 || dh != 64 || M <= 0) return 0;
-    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(float);
+    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(bf16_t);
 }
 
 extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
@@ -976,7 +996,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     FusedP p;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.rd = (const bf16_t*)rd; p.dout = (const bf16_t*)dout;
     p.rwb = r_w_bias; p.rrb = r_r_bias; p.lse = lse; p.delta = delta;
-    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.slab = ws; p.drd = d_rd; p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
+    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.slab = (bf16_t*)ws; p.drd = d_rd; p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.dkv_bs = dkv_bs; p.slab_stride = (long long)B * T * H * 64;
     p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dkv_rs = dkv_rs; p.drd_ld = drd_ld;
@@ -1002,7 +1022,7 @@ extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const flo
                   ((uintptr_t)ws % 16) == 0 && (oph == nullptr || ((uintptr_t)oph % 16) == 0));
     hipStream_t s = (hipStream_t)stream;
     FinP f;
-    f.slab = ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
+    f.slab = (const bf16_t*)ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
     f.dq = (bf16_t*)dq;
     f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
     f.slab_stride = (long long)B * T * H * 64; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
