@@ -168,7 +168,8 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
  * is  -scale * delta_i * 2^(mph_i - lse_i * log2 e) * oph_i  with oph / mph from mxl_relattn_fwd_phantom2(..., oph_all = 1)
  * (required then), and their part of d_rd is owed by the caller: mxl_relattn_drd_phantom.  With Kc == M + T oph / mph are unused.
  * `delta` (B,H,T) f32 scratch is written.  dq_rs, dq_bs multiples of 8.
- * defer_finish != 0: the slab sum is left to the caller (mxl_relattn_dq_finish, same ws / oph / mph / lse / delta / dq arguments) --
+ * defer_finish != 0: the slab sum is left to the caller (mxl_relattn_dq_finish, same ws / oph / mph / lse / delta / dq / d_r_r_bias
+ * arguments: with oph it also adds the phantom cells' part of d_r_r_bias, the column sums of their dq term; d_r_r_bias may be NULL) --
  * it depends on nothing but this call and is HBM-bound, so the caller may run it on another stream beside
  * mxl_relattn_drd_phantom. */
 size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M);
@@ -179,8 +180,8 @@ int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const voi
                           long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
                           long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, int defer_finish, void* stream);
 int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
-                          int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs, int dq_rs,
-                          float scale, void* stream);
+                          float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs,
+                          int dq_rs, float scale, void* stream);
 /* mxl_relattn_fwd_phantom with a choice of which phantom cells enter oph: oph_all = 0 is mxl_relattn_fwd_phantom (the
  * all-phantom 256-distance blocks, for mxl_relattn_bwd_sparse_dg_oph); oph_all = 1 sums over EVERY key position below the first
  * stored key tile (for mxl_relattn_bwd_fused; needs (T - Kc) % 64 == 0). */
@@ -189,12 +190,17 @@ int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const 
                              int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                              long long o_bs, int o_rs, float scale, void* stream);
 /* d_rd[delta, h*64 + e] += sum over the PHANTOM cells (key position i - delta below T - Kc) of dG[b,h,i,delta] * qr[b,i,h,e],
- * with dG rebuilt on MFMA from qr = (q + r_r_bias) (bf16), rd, lse, delta as in mxl_relattn_drd_recompute -- cell by cell, so
- * that together with mxl_relattn_bwd_fused every (query, distance) pair is counted once; and those cells' part of the r_r_bias
- * gradient, d_r_r_bias[h*64 + e] += sum_delta colsum_{b,i}(dG)[h, delta] * rd[delta, h*64 + e] (d_r_r_bias may be NULL).
- * (T - Kc) % 64 == 0. */
-int mxl_relattn_drd_phantom(const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs, int qr_rs,
-                            int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, const float* lse, const float* delta,
+ * qr = q + r_r_bias, with dG[i,delta] = -scale * delta_i * exp(scale * qr_i . rd[delta] - lse_i) rebuilt on MFMA (two products and
+ * one exponential per cell, nothing streamed) -- cell by cell, so that together with mxl_relattn_bwd_fused every (query, distance)
+ * pair is counted once.  (T - Kc) % 64 == 0, T % 32 == 0, M % 256 == 0, M <= 8192, dh == 64.
+ * mxl_relattn_drd_phantom_prep fills `ws` (mxl_relattn_drd_phantom_ws_bytes bytes, 16-byte aligned) with one record per
+ * (sequence, head, 32-query tile): the tile's bf16(q + r_r_bias) rows in the kernel's LDS image order, -lse * log2 e and delta of
+ * its queries; mxl_relattn_drd_phantom reads nothing else of the activations.  Those cells' part of d r_r_bias is added by
+ * mxl_relattn_dq_finish. */
+size_t mxl_relattn_drd_phantom_ws_bytes(int B, int T, int H);
+int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q_rs, const float* r_r_bias, const float* lse, const float* delta,
+                                 void* ws, int B, int T, int H, int dh, void* stream);
+int mxl_relattn_drd_phantom(const void* ws, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld, const void* rd, int rd_rs,
                             float scale, int Kc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------

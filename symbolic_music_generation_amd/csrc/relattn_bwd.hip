@@ -1519,9 +1519,6 @@ struct DrdP {
     // recompute form (mxl_relattn_drd_recompute): the cells the query-owner kernel did not store are phantom distances, whose
     // score gradient needs no K / V:  dG[i, d] = -scale * delta_i * exp(scale * (q_i + r_r_bias) . Rd[d] - lse_i)
     const float* lse; const float* delta; float scale; int pz; int recompute;
-    // mxl_relattn_drd_phantom: nothing is streamed (dg unused); EVERY phantom cell (distance > i - pz) is rebuilt, so the tiles
-    // that straddle the first stored key are recomputed too, with the stored keys' cells masked out
-    int phantom_only;
 };
 constexpr int DRD_A = 32 * 512;        // dG tile  [32 i][256 delta] bf16
 constexpr int DRD_B = 32 * 128;        // Qr tile  [32 i][64 e] bf16
@@ -1563,15 +1560,12 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
     const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-    // phantom mode: a distance block's work grows with its index (block k recomputes 8 k + 8 query tiles per sequence): highest
-    // block first, so that the launch ends on the short workgroups
-    if (p.phantom_only) bx_ = gridDim.x - 1 - bx_;
     const int d0 = bx_ * 256;
     // tiles [0, nph) of every batch item lie entirely on phantom distances for this 256-distance block (i0 + 31 - pz < d0, the
     // rule by which the query-owner kernel skipped their dG stores): recomputed below; the others are streamed
     const int tph = (d0 + p.pz) >> 5;                // first tile with a stored-key cell in this distance block (may be < 0)
-    const int nph = p.recompute ? max(0, min(spb, p.phantom_only ? tph + 8 : tph)) : 0;
-    const int nst = p.phantom_only ? 0 : spb - nph;
+    const int nph = p.recompute ? max(0, min(spb, tph)) : 0;
+    const int nst = spb - nph;
     const int S = nb * nst;
 
     // dG tile: DMA instruction j (0..3) of wave w fills rows 2(4j + w), +1 (512-byte rows): lane -> row l >> 5, 16-byte slot
@@ -1654,8 +1648,6 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
         // TWO steps per barrier (round 4): a step is 36 short MFMAs between an LDS round trip and a workgroup barrier, and at one
         // barrier per step the four waves spent more time meeting than computing (1.04 ms for 0.24 ms of MFMA at the bench shape)
         auto step = [&](int g) {
-            const int tix = g % nph;
-            const bool mixed = p.phantom_only && tix >= tph;      // wave-uniform: this tile also holds stored-key cells
             const char* st = smem + (g & (NSTA - 1)) * STA;
             const float* sv = reinterpret_cast<const float*>(st + 4096 + wid * 256);
             const f32x4 ls0 = *reinterpret_cast<const f32x4*>(sv + 4 * gq), ls1 = *reinterpret_cast<const f32x4*>(sv + 16 + 4 * gq);
@@ -1694,14 +1686,6 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_kernel(DrdP p) {
                 for (int r = 0; r < 4; r++) {
                     g0[r] = __builtin_amdgcn_exp2f(c0[r]) * n0[r];
                     g1[r] = __builtin_amdgcn_exp2f(c1[r]) * n1[r];
-                }
-                if (mixed) {          // keep the phantom cells only: distance >= query - pz + 1
-                    const int dd = d0 + 64 * wid + 16 * f + (l & 15) + p.pz - (tix << 5) - 4 * gq;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        g0[r] = (dd >= r + 1) ? g0[r] : 0.f;
-                        g1[r] = (dd >= r + 17) ? g1[r] : 0.f;
-                    }
                 }
                 const u32x4 fw = {pack2bf(g0[0], g0[1]), pack2bf(g0[2], g0[3]), pack2bf(g1[0], g1[1]), pack2bf(g1[2], g1[3])};
                 const bf16x8 fa = __builtin_bit_cast(bf16x8, fw);
@@ -1922,13 +1906,11 @@ extern "C" int mxl_relattn_bwd_sparse_dg_oph(const void* q, const void* k, const
 static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, int T, int H, int dh, int M,
                             long long qr_bs, int qr_rs, int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias,
                             float* d_r_w_bias_fix, const float* lse, const float* delta, float scale, int Kc, int recompute,
-                            void* stream, int phantom_only = 0) {
-    MXL_CHECK_ARG((dg || phantom_only) && qr && d_rd && B > 0 && T > 0 && H > 0 && M > 0);
-    if (phantom_only) MXL_CHECK_ARG(recompute && ((T - Kc) % 64) == 0);
+                            void* stream) {
+    MXL_CHECK_ARG(dg && qr && d_rd && B > 0 && T > 0 && H > 0 && M > 0);
     if (recompute) MXL_CHECK_ARG(rd && lse && delta && (M % 256) == 0 && Kc >= T && Kc <= M + T);
     if (dh != 64 || (T % 32) != 0 || (M % 8) != 0 || M < 8) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG((qr_rs % 8) == 0 && (qr_bs % 8) == 0 && drd_ld >= H * dh && ((uintptr_t)dg % 16) == 0 && ((uintptr_t)qr % 16) == 0);
-    if (phantom_only && Kc >= M + T) return MXL_OK;          // every visible key is stored: no phantom cell
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_drd_kernel),
@@ -1942,7 +1924,6 @@ static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, 
     MXL_CHECK_ARG(!d_r_r_bias || rd);
     p.rd = (const bf16_t*)rd; p.rd_rs = rd_rs; p.d_rrb = d_r_r_bias; p.d_rwb = d_r_w_bias_fix;
     p.lse = lse; p.delta = delta; p.scale = scale; p.recompute = recompute ? 1 : 0;
-    p.phantom_only = phantom_only ? 1 : 0;
     {   // first stored key tile of the attention kernels (floor(p0 / 64) * 64, p0 = T - Kc <= 0): key positions below it are phantom
         const int p0 = T - Kc;
         p.pz = recompute ? -(((-p0) + 63) / 64) * 64 : 0;
@@ -1950,14 +1931,6 @@ static int relattn_drd_impl(const void* dg, const void* qr, float* d_rd, int B, 
     // batch groups: fill the 512 resident workgroup slots about once (each workgroup ends with 64 KB of fp32 atomics)
     const int tiles = ((M + 255) / 256) * H;
     int groups = 512 / tiles;
-    // phantom mode: the workgroups of distance block k run 8 k + 8 steps per sequence (8 .. 64 at M = 2048), so one workgroup per
-    // resident slot leaves the launch as long as its longest members (832 steps against a mean of 468 at the bench shape): three
-    // six times as many, shorter workgroups, the long ones first, and the dispatcher balances them (200 MB of end-of-workgroup
-    // atomics per launch instead of 31): 1.03 -> 0.80 ms (factor 2 / 3 / 4 / 6 / 12: 0.95 / 0.85 / 0.83 / 0.80 / 0.84)
-    if (phantom_only) {
-        static const int fac = getenv("MXL_DRD_PH_FACTOR") ? atoi(getenv("MXL_DRD_PH_FACTOR")) : 6;
-        groups = (fac * 512 + tiles - 1) / tiles;
-    }
     if (groups < 1) groups = 1;
     if (groups > B) groups = B;
     p.bgroup = (B + groups - 1) / groups;
@@ -1983,11 +1956,4 @@ extern "C" int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* 
                                          void* stream) {
     return relattn_drd_impl(dg, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, d_r_r_bias, d_r_w_bias_fix, lse, delta,
                             scale, Kc, 1, stream);
-}
-
-extern "C" int mxl_relattn_drd_phantom(const void* qr, float* d_rd, int B, int T, int H, int dh, int M, long long qr_bs, int qr_rs,
-                                       int drd_ld, const void* rd, int rd_rs, float* d_r_r_bias, const float* lse, const float* delta,
-                                       float scale, int Kc, void* stream) {
-    return relattn_drd_impl(nullptr, qr, d_rd, B, T, H, dh, M, qr_bs, qr_rs, drd_ld, rd, rd_rs, d_r_r_bias, nullptr, lse, delta, scale,
-                            Kc, 1, stream, 1);
 }

@@ -895,51 +895,109 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
 // ---------------------------------------------------------------------------------------------------------------
 // dq[b,i,:] = bf16( sum over the key blocks that see query tile i/32 of their slab rows  +  phantom term ),
 // phantom term (zero memories, oph != NULL):  -scale * delta[b,h,i] * 2^(mph[b,h,i] - lse[b,h,i] log2 e) * oph[b,i,h,:]
-// -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Elementwise:
-// thread = 8 consecutive elements of one row; the (at most M/256 + 1) slab reads of a thread are independent 16-byte loads (the slabs are bf16, the sum fp32).
-// (Those cells' part of d r_r_bias, the column sums of the phantom term, is formed by mxl_relattn_drd_phantom, which holds the
-// column sums of their dG anyway.)
+// -- the dQr of every key position below the first stored one, from the forward's value-sum (relattn_fwd.hip).  Elementwise and
+// HBM-bound: a workgroup takes sixteen query rows (they share the slab range), a thread 8 consecutive elements of a row, four such
+// items per pass; the (at most M/256 + 1) slab reads of an item are independent 16-byte loads (the slabs are bf16, the sum fp32).
+// The column sums of the phantom term are those cells' part of d r_r_bias (d r_r_bias = sum_i dQr_i): kept in the registers of the
+// thread that owns the column chunk, one float atomic per column and workgroup at the end (measured on the way: ds_add_f32 per
+// element doubled the kernel's time, and so did a flush per row group -- 6 M float atomics on 3 KB of addresses).
 // ---------------------------------------------------------------------------------------------------------------
 struct FinP {
     const bf16_t* slab; const bf16_t* oph; const float *mph, *lse, *delta;
-    bf16_t* dq;
+    bf16_t* dq; float* d_rrb;
     int B, T, H, M, Kc;
     long long slab_stride, o_bs, dq_bs; int o_rs, dq_rs;
     float scale;
 };
+#ifndef FIN_K_
+#define FIN_K_ 1
+#endif
+constexpr int FIN_K = FIN_K_;                   // rows per thread and pass
+constexpr int FIN_ROWS = 16;                    // query rows per row group (half a tile: the rows share the slab range)
 __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
+    __shared__ float s_red[256 * 8];
     const int d = p.H * 64, nch = d >> 3;
-    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (item >= (long long)p.B * p.T * nch) return;
-    const int c = (int)(item % nch);
-    const long long row = item / nch;
-    const int b = (int)(row / p.T), i = (int)(row % p.T);
-    const int I = i & ~31;
+    const int per_b = p.T / FIN_ROWS;
     const int p0 = p.T - p.Kc;
     const int nkb = (p.Kc + KBLK - 1) / KBLK;
-    const int x = I - p.M - 254 - p0;
-    const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
-    const int kb_hi = min(nkb - 1, (I + 31 - p0) >> 8);
-    const int nsl = kb_hi - kb_lo + 1;
-    float acc[8];
+    const bool colsum = p.oph != nullptr && p.d_rrb != nullptr;
+    const bf16_t* __restrict__ slab = p.slab;
+    const int t = threadIdx.x;
+    // A thread owns ONE 8-element column chunk for the whole launch (so the column sums of the phantom term stay in its registers)
+    // and walks rows: cw = min(nch, 256) chunks side by side, kr = 256 / cw rows side by side (d = 768: 96 x 2, 192 threads busy);
+    // a workgroup walks row groups with the grid's stride.  One float atomic per column and WORKGROUP at the end.
+    for (int cb = 0; cb < nch; cb += 256) {
+        const int cw = min(256, nch - cb), kr = 256 / cw;
+        const int c = cb + t % cw, rsub = t / cw;
+        const bool act = rsub < kr;
+        float cs[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = 0.f;
-    const bf16_t* sp = p.slab + (size_t)row * (size_t)d + c * 8;
-#pragma unroll 3
-    for (int s = 0; s < nsl; s++) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sp + (size_t)s * p.slab_stride);
+        for (int j = 0; j < 8; j++) cs[j] = 0.f;
+        for (int rg = blockIdx.x; rg < p.B * per_b; rg += gridDim.x) {
+            const int b = rg / per_b, i0 = (rg % per_b) * FIN_ROWS;
+            const int I = i0 & ~31;
+            const int x = I - p.M - 254 - p0;
+            const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
+            const int kb_hi = min(nkb - 1, (I + 31 - p0) >> 8);
+            const int nsl = kb_hi - kb_lo + 1;
+            for (int rbase = 0; rbase < FIN_ROWS; rbase += FIN_K * kr) {
+                float acc[FIN_K][8];
+                int i_[FIN_K];
+                bool ok[FIN_K];
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)a[j]);
+                for (int k = 0; k < FIN_K; k++) {
+                    const int rr = rbase + rsub + kr * k;
+                    ok[k] = act && rr < FIN_ROWS;
+                    i_[k] = i0 + (ok[k] ? rr : 0);           // (idle slots re-read the group's first row: no store below)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[k][j] = 0.f;
+                }
+#pragma unroll 5
+                for (int s = 0; s < nsl; s++) {
+                    bf16x8 a[FIN_K];
+#pragma unroll
+                    for (int k = 0; k < FIN_K; k++)
+                        a[k] = *reinterpret_cast<const bf16x8*>(slab + (size_t)s * p.slab_stride + ((size_t)b * p.T + i_[k]) * (size_t)d + c * 8);
+#pragma unroll
+                    for (int k = 0; k < FIN_K; k++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc[k][j] += bf2f((bf16_t)a[k][j]);
+                }
+#pragma unroll
+                for (int k = 0; k < FIN_K; k++) {
+                    if (!ok[k]) continue;
+                    const int i = i_[k];
+                    if (p.oph) {
+                        const size_t sidx = ((size_t)b * p.H + (c >> 3)) * p.T + i;
+                        const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
+                        const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const float v = f * bf2f((bf16_t)o[j]);
+                            acc[k][j] += v;
+                            cs[j] += v;
+                        }
+                    }
+                    const u32x4 wq = {pack2bf(acc[k][0], acc[k][1]), pack2bf(acc[k][2], acc[k][3]), pack2bf(acc[k][4], acc[k][5]),
+                                      pack2bf(acc[k][6], acc[k][7])};
+                    *reinterpret_cast<u32x4*>(p.dq + (size_t)b * p.dq_bs + (size_t)i * p.dq_rs + c * 8) = wq;
+                }
+            }
+        }
+        if (colsum) {           // the kr row lanes of a column chunk meet in LDS; thread a = (chunk, element) in memory order adds their sum
+            __syncthreads();
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) s_red[(rsub * 8 + j) * cw + (c - cb)] = cs[j];
+            }
+            __syncthreads();
+            for (int a = t; a < cw * 8; a += blockDim.x) {
+                float v = 0.f;
+                for (int q = 0; q < kr; q++) v += s_red[(q * 8 + (a & 7)) * cw + (a >> 3)];
+                atomicAdd(p.d_rrb + cb * 8 + a, v);
+            }
+        }
     }
-    if (p.oph) {
-        const size_t sidx = ((size_t)b * p.H + (c >> 3)) * p.T + i;
-        const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
-        const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] += f * bf2f((bf16_t)o[j]);
-    }
-    const u32x4 wq = {pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
-    *reinterpret_cast<u32x4*>(p.dq + (size_t)b * p.dq_bs + (size_t)i * p.dq_rs + c * 8) = wq;
 }
 
 }  // namespace
@@ -1009,12 +1067,12 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     }
     MXL_LAUNCH_CHECK();
     if (defer_finish) return MXL_OK;
-    return mxl_relattn_dq_finish(ws, oph, mph, lse, delta, dq, B, T, H, dh, M, Kc, o_bs, o_rs, dq_bs, dq_rs, scale, stream);
+    return mxl_relattn_dq_finish(ws, oph, mph, lse, delta, dq, d_r_r_bias, B, T, H, dh, M, Kc, o_bs, o_rs, dq_bs, dq_rs, scale, stream);
 }
 
 extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
-                                     int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs, int dq_rs,
-                                     float scale, void* stream) {
+                                     float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs,
+                                     long long dq_bs, int dq_rs, float scale, void* stream) {
     MXL_CHECK_ARG(ws && lse && delta && dq && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     if (dh != 64 || (T % 32) != 0 || (M % 256) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG(Kc == M + T || (oph && mph));
@@ -1023,13 +1081,16 @@ extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const flo
     hipStream_t s = (hipStream_t)stream;
     FinP f;
     f.slab = (const bf16_t*)ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
-    f.dq = (bf16_t*)dq;
+    f.dq = (bf16_t*)dq; f.d_rrb = d_r_r_bias;
     f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
     f.slab_stride = (long long)B * T * H * 64; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_DQFIN, s);
-        const long long items = (long long)B * T * (H * 8);
-        hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, f);
+        // threads: the busy ones only (d = 768: 2 rows x 96 chunks = 192 = three whole waves), ten such workgroups per CU
+        const long long rgs = (long long)B * (T / FIN_ROWS);
+        const int nch = H * 8, cw = nch < 256 ? nch : 256, busy = (256 / cw) * cw, nthr = (busy + 63) / 64 * 64;
+        const long long want = 256ll * (2048 / nthr);
+        hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3((unsigned)(rgs < want ? rgs : want)), dim3(nthr), 0, s, f);
     }
     MXL_LAUNCH_CHECK();
     return MXL_OK;

@@ -461,12 +461,28 @@ def relattn_bwd_fused_ws_numel(B, T, H, dh, M) -> int:
     return int(lib().mxl_relattn_bwd_fused_ws_bytes(B, T, H, dh, M)) // 4
 
 
+_PH_WS = {}
+
+
+def _phantom_ws(B, T, H, device):
+    """scratch of mxl_relattn_drd_phantom_prep (one record per sequence, head and 32-query tile), one per shape and device, allocated on
+    first use; callers that capture graphs or account for every byte pass their own `ph_buf`"""
+    key = (B, T, H, str(device))
+    buf = _PH_WS.get(key)
+    if buf is None:
+        buf = torch.empty(int(lib().mxl_relattn_drd_phantom_ws_bytes(B, T, H)), device=device, dtype=torch.uint8)
+        _PH_WS[key] = buf
+    return buf
+
+
 def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, d_rd, d_rwb, d_rrb, ws, qr_buf, *,
                       B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                      scale=None, oph=None, mph=None, defer_drd=False):
+                      scale=None, oph=None, mph=None, defer_drd=False, ph_buf=None):
     """Backward of relattn_fwd in one pass over the score cells (mxl_relattn_bwd_fused): dq, dk, dv written, d_rd (M, H*dh) f32 /
     d_rwb / d_rrb accumulated.  With zero memories (Kc < M + T) `oph` / `mph` must come from relattn_fwd(..., oph_all=True), and
-    the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom (needs the (B, T, H*dh) bf16 scratch `qr_buf`)."""
+    the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom (its scratch: `ph_buf`, mxl_relattn_drd_phantom_ws_bytes
+    bytes, or one cached per shape; `qr_buf` is no longer used by this path); their part of d_rrb comes out of the dq finishing
+    kernel."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     d = H * dh
     # the slab sum (HBM-bound, 44 registers) and the phantom cells' dRd (MFMA / latency-bound) depend only on the fused pass, not on
@@ -482,17 +498,18 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
         main, side = torch.cuda.current_stream(), _side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            check(lib().mxl_relattn_dq_finish(_p(ws), _p(oph), _p(mph), _p(lse), _p(delta), _p(dq), B, T, H, dh, M, Kc, o_bs, o_rs,
-                                              dq_bs, dq_rs, float(scale), _stream()), 'mxl_relattn_dq_finish')
+            check(lib().mxl_relattn_dq_finish(_p(ws), _p(oph), _p(mph), _p(lse), _p(delta), _p(dq), _p(d_rrb), B, T, H, dh, M, Kc,
+                                              o_bs, o_rs, dq_bs, dq_rs, float(scale), _stream()), 'mxl_relattn_dq_finish')
             done = torch.cuda.Event()
             done.record(side)
 
     def phantom():
         if Kc < M + T:
-            add_rowbias(q, q_bs, q_rs, r_r_bias.reshape(-1), qr_buf, B, T, d)
-            check(lib().mxl_relattn_drd_phantom(_p(qr_buf), _p(d_rd), B, T, H, dh, M, T * d, d, d_rd.stride(0), _p(rd), int(rd_rs),
-                                                _p(d_rrb), _p(lse), _p(delta), float(scale), Kc, _stream()),
-                  'mxl_relattn_drd_phantom')
+            ph = ph_buf if ph_buf is not None else _phantom_ws(B, T, H, q.device)
+            check(lib().mxl_relattn_drd_phantom_prep(_p(q), q_bs, q_rs, _p(r_r_bias), _p(lse), _p(delta), _p(ph), B, T, H, dh,
+                                                     _stream()), 'mxl_relattn_drd_phantom_prep')
+            check(lib().mxl_relattn_drd_phantom(_p(ph), _p(d_rd), B, T, H, dh, M, d_rd.stride(0), _p(rd), int(rd_rs), float(scale),
+                                                Kc, _stream()), 'mxl_relattn_drd_phantom')
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
     if defer_drd:

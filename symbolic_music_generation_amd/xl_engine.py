@@ -248,9 +248,13 @@ class XLEngine:
             if ws.fused_bwd:      # no dG tensor: the partial-dq slabs instead ((M/256 + 1) x (B, T, d) fp32)
                 ws.dg = None
                 ws.dq_slabs = torch.empty(ops.relattn_bwd_fused_ws_numel(B, T, H, c.d_head, M), **f32)
+                # the phantom cells' dRd kernel reads q + r_r_bias, -lse and delta from per-tile records (zero memories only)
+                ws.ph = (torch.empty(int(ops.lib().mxl_relattn_drd_phantom_ws_bytes(B, T, H)), device=self.dev, dtype=torch.uint8)
+                         if Kc < M + T else None)
+                ws.qr = None
             else:
                 ws.dg = torch.empty(B, H, T, M, **bf)
-            ws.qr = torch.empty(B, T, d, **bf)
+                ws.qr = torch.empty(B, T, d, **bf)
             ws.d_rd = torch.empty(M, d, **f32)
             ws.d_rd16 = torch.empty(M, d, **bf)
             ws.phi_c = torch.empty(M, d, **bf)
@@ -621,7 +625,7 @@ class XLEngine:
                                       ws.d_rd, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), ws.dq_slabs, ws.qr,
                                       dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
                                       oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
-                                      mph=ws.mph[l] if ws.oph is not None else None, **st)
+                                      mph=ws.mph[l] if ws.oph is not None else None, ph_buf=ws.ph, **st)
             else:
                 ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
                                 self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
