@@ -266,8 +266,8 @@ def train_leg(args, ranks: Ranks):
                         'fused': ('relattn_bwd_fused_kernel', B * T * 12.0 * d * n_real), 'dqfin': ('relattn_dq_finish_kernel', 0.0),
                         'rowbias': ('phantom_prep_kernel', 0.0), 'drd': ('relattn_drd_phantom_kernel', B * T * 2.0 * d * (M - n_real))}
                 group = ('delta', 'fused', 'dqfin', 'rowbias', 'drd')
-                desc = ('attention backward of one layer: fused_delta + relattn_bwd_fused + relattn_dq_finish + phantom_prep + '
-                        'relattn_drd_phantom (one HIP-event bracket around all five launches)')
+                desc = ('attention backward of one layer: fused_delta + relattn_bwd_fused + relattn_dq_finish + relattn_drd_phantom '
+                        '(one HIP-event bracket around all four launches; the phantom kernel reads records the forward wrote)')
             else:
                 kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('relattn_bwd_delta_kernel', 0.0),
                         'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M) - moved),
@@ -552,9 +552,10 @@ def pmc_traffic(workload, B):
     if names is None:       # every launch of the bracketed group
         fused = [n for n in k if n.startswith('relattn_bwd_fused_kernel')]
         if fused:           # round 4: delta, the fused pass, the dq finish, q + r_r_bias (+ per-tile scalars), the phantom cells' dRd
-            ph = 'relattn_drd_phantom_kernel' in k
-            names = ['fused_delta_kernel', fused[0], 'relattn_dq_finish_kernel', 'phantom_prep_kernel' if ph else 'add_rowbias_kernel',
-                     'relattn_drd_phantom_kernel' if ph else 'relattn_drd_kernel']
+            if 'relattn_drd_phantom_kernel' in k:       # (the phantom kernel's records come out of the forward: no q + r_r_bias pass)
+                names = ['fused_delta_kernel', fused[0], 'relattn_dq_finish_kernel', 'relattn_drd_phantom_kernel']
+            else:
+                names = ['fused_delta_kernel', fused[0], 'relattn_dq_finish_kernel', 'add_rowbias_kernel', 'relattn_drd_kernel']
         else:               # delta, query-owner, key-owner, q + r_r_bias, dRd contraction
             dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
             names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']

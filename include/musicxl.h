@@ -184,24 +184,26 @@ int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, co
                           int dq_rs, float scale, void* stream);
 /* mxl_relattn_fwd_phantom with a choice of which phantom cells enter oph: oph_all = 0 is mxl_relattn_fwd_phantom (the
  * all-phantom 256-distance blocks, for mxl_relattn_bwd_sparse_dg_oph); oph_all = 1 sums over EVERY key position below the first
- * stored key tile (for mxl_relattn_bwd_fused; needs (T - Kc) % 64 == 0). */
+ * stored key tile (for mxl_relattn_bwd_fused; needs (T - Kc) % 64 == 0).  ph_ws (or NULL; oph_all = 1, dh = 64 only): the forward
+ * also fills the per-tile records of mxl_relattn_drd_phantom (mxl_relattn_drd_phantom_ws_bytes bytes), sparing the backward
+ * mxl_relattn_drd_phantom_prep. */
 int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                             const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, int B, int T, int H,
-                             int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
+                             const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, void* ph_ws, int B,
+                             int T, int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
                              long long o_bs, int o_rs, float scale, void* stream);
 /* d_rd[delta, h*64 + e] += sum over the PHANTOM cells (key position i - delta below T - Kc) of dG[b,h,i,delta] * qr[b,i,h,e],
  * qr = q + r_r_bias, with dG[i,delta] = -scale * delta_i * exp(scale * qr_i . rd[delta] - lse_i) rebuilt on MFMA (two products and
  * one exponential per cell, nothing streamed) -- cell by cell, so that together with mxl_relattn_bwd_fused every (query, distance)
  * pair is counted once.  (T - Kc) % 64 == 0, T % 32 == 0, M % 256 == 0, M <= 8192, dh == 64.
- * mxl_relattn_drd_phantom_prep fills `ws` (mxl_relattn_drd_phantom_ws_bytes bytes, 16-byte aligned) with one record per
- * (sequence, head, 32-query tile): the tile's bf16(q + r_r_bias) rows in the kernel's LDS image order, -lse * log2 e and delta of
- * its queries; mxl_relattn_drd_phantom reads nothing else of the activations.  Those cells' part of d r_r_bias is added by
- * mxl_relattn_dq_finish. */
+ * `ws` (mxl_relattn_drd_phantom_ws_bytes bytes, 16-byte aligned) holds one record per (sequence, head, 32-query tile): the tile's
+ * bf16((q + r_r_bias) * scale * log2 e) rows in the kernel's LDS image order and -lse * log2 e of its queries -- written by the
+ * forward (mxl_relattn_fwd_phantom2(..., ph_ws)) or by mxl_relattn_drd_phantom_prep; `delta` (B,H,T) f32 is the array
+ * mxl_relattn_bwd_fused fills.  Those cells' part of d r_r_bias is added by mxl_relattn_dq_finish. */
 size_t mxl_relattn_drd_phantom_ws_bytes(int B, int T, int H);
-int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q_rs, const float* r_r_bias, const float* lse, const float* delta,
-                                 void* ws, int B, int T, int H, int dh, void* stream);
-int mxl_relattn_drd_phantom(const void* ws, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld, const void* rd, int rd_rs,
-                            float scale, int Kc, void* stream);
+int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q_rs, const float* r_r_bias, const float* lse, void* ws, int B, int T,
+                                 int H, int dh, float scale, void* stream);
+int mxl_relattn_drd_phantom(const void* ws, const float* delta, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld,
+                            const void* rd, int rd_rs, int Kc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound layer pieces.

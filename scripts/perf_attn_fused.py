@@ -34,6 +34,8 @@ for mode in which:
         use_oph = zero_mem and ops.phantom_sum_applies(T=T, dh=dh, M=M, Kc=Kc)
     else:
         ws = torch.empty(ops.relattn_bwd_fused_ws_numel(B, T, H, dh, M), device=dev)
+        ph = (torch.empty(int(ops.lib().mxl_relattn_drd_phantom_ws_bytes(B, T, H)), device=dev, dtype=torch.uint8)
+              if (zero_mem and os.environ.get('PH_FROM_FWD', '1') == '1') else None)
     for it in range(ITERS + 1):
         if it == 1:
             ops.ktime_enable(True)
@@ -41,7 +43,7 @@ for mode in which:
         if mode == 'old':
             ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, oph=oph if use_oph else None, mph=mph if use_oph else None, **st)
         else:
-            ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, oph=oph, mph=mph, oph_all=True, **st)
+            ops.relattn_fwd(q, k, v, rd, rwb, rrb, out, lse, oph=oph, mph=mph, oph_all=True, ph_buf=ph, **st)
         ev[1].record()
         if mode == 'old':
             fin = ops.relattn_bwd(q, k, v, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc-T:, :d], dqkv[:, :, d:2*d], dqkv[:, :, 2*d:],
@@ -50,7 +52,7 @@ for mode in which:
         else:
             fin = ops.relattn_bwd_fused(q, k, v, rd, rwb, rrb, out, dout, lse, delta, dqkv[:, Kc-T:, :d], dqkv[:, :, d:2*d],
                                         dqkv[:, :, 2*d:], d_rd, a, c, ws, qr, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d,
-                                        oph=oph, mph=mph, defer_drd=True, **st)
+                                        oph=oph, mph=mph, defer_drd=True, ph_buf=ph, ph_ready=ph is not None, **st)
         ev[2].record()
         fin()
         ev[3].record()

@@ -68,13 +68,17 @@ __device__ __forceinline__ void tr_read8(uint32_t a0, uint32_t a1, bf16x8 (&fb)[
     fb[1][0] = __builtin_bit_cast(bf16x8, v10); fb[1][1] = __builtin_bit_cast(bf16x8, v11);
 }
 
-// Per (sequence, head, 32-query tile) one 4352-byte record, the exact image a step of the main kernel wants in LDS:
-//   [32 rows x 128 B of bf16(q + r_r_bias), 16-byte chunk c of row r at c ^ ph_swz(r)]  [-lse * log2 e, 32 floats]  [delta, 32 floats]
-// so that a step is four contiguous 1 KB LDS-DMA pieces (one per wave) + one 256-byte piece.
+// Per (sequence, head, 32-query tile) one 4352-byte record, what a step of the main kernel wants in LDS:
+//   [32 rows x 128 B of qs = bf16((q + r_r_bias) * scale * log2 e), 16-byte chunk c of row r at c ^ ph_swz(r)]  [-lse * log2 e, 32 floats]
+// (the scaled rows are the attention kernels' Qr operand, bit for bit: the rebuilt scores match the forward's).  A step is four
+// contiguous 1 KB LDS-DMA pieces (one per wave) + 128 bytes of -lse2 + 128 bytes of delta (from the (B,H,T) array the fused pass fills).
+// In training the forward writes the records as it goes (mxl_relattn_fwd_phantom2(..., ph_ws)); mxl_relattn_drd_phantom_prep
+// fills them from q and lse for callers that did not ask it to.
 constexpr int PH_REC = 4096 + 256;
 __device__ __forceinline__ int ph_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
-__global__ void phantom_prep_kernel(const bf16_t* q, long long q_bs, int q_rs, const float* rrb, char* rec, int B, int T, int H) {
+__global__ void phantom_prep_kernel(const bf16_t* q, long long q_bs, int q_rs, const float* rrb, char* rec, int B, int T, int H,
+                                    float scale_log2e) {
     const int chunks = H * 8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * T * chunks) return;
@@ -84,21 +88,19 @@ __global__ void phantom_prep_kernel(const bf16_t* q, long long q_bs, int q_rs, c
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(q + b * q_bs + (long long)t * q_rs + c * 8);
     float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = bf2f((bf16_t)v[j]) + rrb[c * 8 + j];
+    for (int j = 0; j < 8; j++) o[j] = (bf2f((bf16_t)v[j]) + rrb[c * 8 + j]) * scale_log2e;
     const u32x4 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     const int r = t & 31;
     char* dst = rec + (((size_t)b * H + (c >> 3)) * (T >> 5) + (t >> 5)) * PH_REC + r * 128 + (((c & 7) ^ ph_swz(r)) << 4);
     *reinterpret_cast<u32x4*>(dst) = w;
 }
-// the records' scalars: thread = (b, h, t) in memory order of lse / delta, so reads and the 128-byte runs written are whole lines
-__global__ void phantom_prep_sc_kernel(const float* lse, const float* delta, char* rec, long long n, int T) {
+// the records' -lse2: thread = (b, h, t) in memory order of lse, so reads and the 128-byte runs written are whole lines
+__global__ void phantom_prep_sc_kernel(const float* lse, char* rec, long long n, int T) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long bh = i / T;
     const int t = (int)(i % T);
-    float* dst = reinterpret_cast<float*>(rec + (bh * (T >> 5) + (t >> 5)) * PH_REC + 4096) + (t & 31);
-    dst[0] = -lse[i] * LOG2E;
-    dst[32] = delta[i];
+    reinterpret_cast<float*>(rec + (bh * (T >> 5) + (t >> 5)) * PH_REC + 4096)[t & 31] = -lse[i] * LOG2E;
 }
 
 // In-kernel stamps (diagnostic builds only: scripts/ab_build.sh relattn_drd_phantom stamp -DMXL_STAMP; scripts/stamp_phantom.py)
@@ -116,7 +118,7 @@ __device__ unsigned long long g_ph_stamps[16];
 #endif
 
 struct PhP {
-    const char* rec; const bf16_t* rd; float* drd;
+    const char* rec; const float* delta; const bf16_t* rd; float* drd;
     int B, T, H, M, bgroup;
     int rd_rs, drd_ld;
     float scale; int pz;
@@ -125,12 +127,12 @@ struct PhP {
     // workgroups) or paying a prologue and 64 KB of float atomics per short workgroup (many)
     int mk[32];
 };
-constexpr int PH_STAGE = PH_REC;            // one record: Qr tile [32][64] bf16 (4 KB) + -lse log2 e [32] + delta [32]
+constexpr int PH_STAGE = PH_REC + 256;      // a record (Qr tile 4 KB, -lse2 [32] + 128 B slack) + delta [32] (+ the next tile's 32, unused)
 #ifndef PH_NST_
 #define PH_NST_ 16
 #endif
 constexpr int PH_NST = PH_NST_, PH_PA = PH_NST_ - 4;      // ring stages, prefetch distance (steps)
-constexpr int PH_SMEM = PH_STAGE * PH_NST;  // 68 KB: two workgroups per CU
+constexpr int PH_SMEM = PH_STAGE * PH_NST;  // 72 KB: two workgroups per CU
 
 // Qr tile image (ph_swz above): 128-byte rows, 16-byte chunk c of row at c ^ s(row), s = (bit 1, bit 2, bit 3) of the row index as
 // chunk bits (2, 1, 0).  Row reads (32x32x16 A operand, ds_read_b128 lane groups of 16 rows) then cover the 64 banks once, and so
@@ -157,30 +159,26 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
     if (SA <= 0) return;
     const int tb0 = tph + 2 * wid;               // unit nt (distances d0 + 64 wid + 32 nt ..): tiles < tb0 + nt full, == diagonal, > none
 
-    // ---- the wave's Rd rows: B operand of G (lane = distance, k = e), scale * log2 e folded in (the one bf16 rounding of a factor
-    // the attention kernels put on the query operand)
+    // ---- the wave's Rd rows: B operand of G (lane = distance, k = e); scale * log2 e rides on the query rows, as in the attention kernels
     bf16x8 rdf[2][4];
-    {
-        const float f = p.scale * LOG2E;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const int dd = d0 + 64 * wid + 32 * nt + r;
-                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.rd + (size_t)dd * p.rd_rs + h * 64 + 16 * ks + 8 * hh);
-#pragma unroll
-                for (int j = 0; j < 8; j++) rdf[nt][ks][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * f);
-            }
-    }
+        for (int ks = 0; ks < 4; ks++) {
+            const int dd = d0 + 64 * wid + 32 * nt + r;
+            rdf[nt][ks] = *reinterpret_cast<const bf16x8*>(p.rd + (size_t)dd * p.rd_rs + h * 64 + 16 * ks + 8 * hh);
+        }
     // ---- LDS addresses (bytes inside a stage)
     const int A0 = r * 128 + ((hh ^ ph_swz(r)) << 4);                    // row read, k-step ks: A0 ^ (ks << 5)
     const int q4 = (l & 15) >> 2, pp = l & 3, cg_ = (l >> 4) & 1;
     // transposed read, fragment (e half et, k-step s): rows 16 s + 8 jj + 4 hh + q4 (jj = 0, 1), columns 32 et + 16 cg_ + 4 pp ..
     const int B0 = (4 * hh + q4) * 128 + ((((2 * cg_ + (pp >> 1)) ^ (4 * ((q4 >> 1) & 1) + 2 * hh))) << 4) + ((pp & 1) << 3);
-    const int sv0 = 4096 + 16 * hh;                                      // the lane's first -lse value; delta: + 128; group g4: + 32 g4
+    const int sv0 = 4096 + 16 * hh;                                      // the lane's first -lse2 value; delta: + 256; group g4: + 32 g4
 
-    // ---- LDS-DMA: a record is the stage image; wave w copies bytes [1024 w, 1024 w + 1024), wave 0 also the 256 bytes of scalars
+    // ---- LDS-DMA: wave w copies bytes [1024 w, 1024 w + 1024) of the record, wave 0 also its 256 bytes of scalars, wave 1 the
+    // tile's delta (256 bytes = this tile's 32 values and the next one's, which nobody reads; past the array the descriptor returns 0)
     const int rec_b = p.H * spb * PH_REC;      // bytes of one sequence's records
+    const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc((void*)p.delta, 0, p.B * p.H * p.T * 4, 0x00020000);
     int ib = b0, it = 0, ig = 0;               // next step to request: sequence, tile, running index
     auto issue = [&]() {
         char* st = smem + (ig & (PH_NST - 1)) * PH_STAGE;
@@ -188,12 +186,13 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
         const int so = (h * spb + it) * PH_REC;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(st + wid * 1024), 16, wid * 1024 + l * 16, so, 0, 0);
         if (wid == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(st + 4096), 4, 4096 + l * 4, so, 0, 0);
+        if (wid == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dl, (lptr_t)(st + PH_REC), 4, l * 4, (((ib * p.H + h) * spb + it) * 32) * 4, 0, 0);
         ig++;
         if (++it == nph) { it = 0; ib++; }
     };
-    // all but the (PA - 2) youngest steps' pieces landed: wave 0 has two pieces per step in flight, the others one
+    // all but the (PA - 2) youngest steps' pieces landed: waves 0 and 1 have two pieces per step in flight, the others one
     auto wait_ring = [&]() {
-        if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PH_PA - 2)) : "memory");
+        if (wid < 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PH_PA - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PH_PA - 2) : "memory");
     };
 
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
         // ---- G of unit (g, 1), then the contraction operands (one asm statement: reads + wait, under the four MFMAs just issued)
         const bool uA = tc <= tb0, uB = tc <= tb0 + 1;
         f32x16 cgB = ld16(st + sv0);
-        const f32x16 nd = ld16(st + sv0 + 128);
+        const f32x16 nd = ld16(st + sv0 + 256);
         if (uB) cgB = gprod(qa, 1, cgB);
         STAMP(1)
         bf16x8 fb[2][2];
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
 
     // ---- epilogue: acc[nt][et][t] = distance d0 + 64 wid + 32 nt + (t & 3) + 8 (t >> 2) + 4 hh, element 32 et + r: an atomic
     // instruction covers two rows x 128 contiguous bytes
-    const float nsc = -p.scale;
+    const float nsc = -1.f / LOG2E;            // dG = -scale delta P and the rows carry scale * log2 e: -scale / (scale log2 e)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -365,30 +364,31 @@ extern "C" size_t mxl_relattn_drd_phantom_ws_bytes(int B, int T, int H) {
     return (size_t)B * H * (T / 32) * PH_REC;
 }
 
-extern "C" int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q_rs, const float* r_r_bias, const float* lse,
-                                            const float* delta, void* ws, int B, int T, int H, int dh, void* stream) {
-    MXL_CHECK_ARG(q && r_r_bias && lse && delta && ws && B > 0 && T > 0 && H > 0);
+extern "C" int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q_rs, const float* r_r_bias, const float* lse, void* ws,
+                                            int B, int T, int H, int dh, float scale, void* stream) {
+    MXL_CHECK_ARG(q && r_r_bias && lse && ws && B > 0 && T > 0 && H > 0);
     if (dh != 64 || (T % 32) != 0) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG((q_rs % 8) == 0 && (q_bs % 8) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 16) == 0);
     const long long tot = (long long)B * T * (H * 8), nsc = (long long)B * H * T;
     {
         mxl_kt::Scope kt(MXL_KT_ROWBIAS, (hipStream_t)stream);
         hipLaunchKernelGGL(phantom_prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
-                           q_bs, q_rs, r_r_bias, (char*)ws, B, T, H);
-        hipLaunchKernelGGL(phantom_prep_sc_kernel, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lse, delta,
+                           q_bs, q_rs, r_r_bias, (char*)ws, B, T, H, scale * LOG2E);
+        hipLaunchKernelGGL(phantom_prep_sc_kernel, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lse,
                            (char*)ws, nsc, T);
     }
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
 
-extern "C" int mxl_relattn_drd_phantom(const void* ws, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld, const void* rd,
-                                       int rd_rs, float scale, int Kc, void* stream) {
-    MXL_CHECK_ARG(ws && d_rd && rd && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
+extern "C" int mxl_relattn_drd_phantom(const void* ws, const float* delta, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld,
+                                       const void* rd, int rd_rs, int Kc, void* stream) {
+    MXL_CHECK_ARG(ws && delta && d_rd && rd && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     if (dh != 64 || (T % 32) != 0 || (M % 256) != 0 || M / 256 > 32) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG(((T - Kc) % 64) == 0);
     MXL_CHECK_ARG((rd_rs % 8) == 0 && drd_ld >= H * 64 && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)rd % 16) == 0);
-    MXL_CHECK_ARG((long long)H * (T / 32) * PH_REC < (1ll << 31));      // 32-bit byte offsets inside one sequence's records
+    // 32-bit byte offsets inside one sequence's records and inside delta
+    MXL_CHECK_ARG((long long)H * (T / 32) * PH_REC < (1ll << 31) && (long long)B * H * T * 4 < (1ll << 31));
     if (Kc >= M + T) return MXL_OK;             // every visible key is stored: no phantom cell
     static bool attr_set = false;
     if (!attr_set) {
@@ -398,9 +398,9 @@ extern "C" int mxl_relattn_drd_phantom(const void* ws, float* d_rd, int B, int T
         attr_set = true;
     }
     PhP p;
-    p.rec = (const char*)ws; p.rd = (const bf16_t*)rd; p.drd = d_rd;
+    p.rec = (const char*)ws; p.delta = delta; p.rd = (const bf16_t*)rd; p.drd = d_rd;
     p.B = B; p.T = T; p.H = H; p.M = M; p.rd_rs = rd_rs; p.drd_ld = drd_ld;
-    p.scale = scale; p.pz = T - Kc;
+    p.scale = 0.f; p.pz = T - Kc;
     // Batch groups sized for the LONGEST distance block (steps per sequence: min(T / 32, (256 k + pz) / 32 + 8), 8 .. 64 at M = 2048),
     // `fac` times as many of them as resident workgroup slots (two per CU), the long blocks dispatched first; a shorter block takes a
     // power-of-two number of groups per workgroup so that every workgroup runs between half and all of the longest one's steps.

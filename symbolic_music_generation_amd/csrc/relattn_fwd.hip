@@ -43,6 +43,9 @@ struct RelAttnP {
     // 1: oph sums over EVERY phantom cell (key position below the first stored key tile) -- what mxl_relattn_bwd_fused consumes;
     // 0: over the all-phantom 256-distance blocks only (mxl_relattn_bwd_sparse_dg_oph walks the others itself)
     int oph_all;
+    // with oph_all: also the per-tile records of mxl_relattn_drd_phantom (relattn_drd_phantom.hip) -- this wave's 32 scaled
+    // (q + r_r_bias) rows in that kernel's LDS image order and -lse2 of its queries -- so that the backward needs no pass over q
+    char* ph_rec;          // or null
 };
 
 constexpr int QB = 128;      // queries per workgroup
@@ -172,6 +175,14 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 qr[ks][j] = (short)f2bf((qf + p.rrb[h * DH + e0 + j]) * p.scale_log2e);
             }
         }
+    }
+
+    if (p.ph_rec && iw0 < T) {
+        // record of tile iw0 / 32: row r at 128 r, 16-byte chunk c at (c ^ s(r)) << 4, s = (bit 1, bit 2, bit 3) of r -> chunk bits (2, 1, 0)
+        char* rec = p.ph_rec + (((size_t)b * p.H + h) * (size_t)(T >> 5) + (iw0 >> 5)) * 4352;
+        const int sw = (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) *reinterpret_cast<bf16x8*>(rec + r * 128 + (((2 * ks + hh) ^ sw) << 4)) = qr[ks];
     }
 
     const int p_lo = i0 - M + 1;
@@ -590,8 +601,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 }
             }
         }
-        if (hh == 0 && p.lse)
-            p.lse[((size_t)b * p.H + h) * T + qi] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        const float lse2 = m_run + __builtin_amdgcn_logf(l_tot);          // log2 units
+        if (hh == 0 && p.lse) p.lse[((size_t)b * p.H + h) * T + qi] = lse2 * 0.6931471805599453f;
+        if (hh == 0 && p.ph_rec)
+            reinterpret_cast<float*>(p.ph_rec + (((size_t)b * p.H + h) * (size_t)(T >> 5) + (iw0 >> 5)) * 4352 + 4096)[r] = -lse2;
     }
 }
 
@@ -619,9 +632,10 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
 static int relattn_fwd_launch(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,
                               long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
-                              float scale, void* oph, float* mph, void* stream, int oph_all = 0) {
+                              float scale, void* oph, float* mph, void* stream, int oph_all = 0, void* ph_ws = nullptr) {
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
     if (oph_all) MXL_CHECK_ARG(oph && ((T - Kc) % 64) == 0);
+    if (ph_ws) MXL_CHECK_ARG(oph_all && dh == 64 && ((uintptr_t)ph_ws % 16) == 0);
     if (oph) MXL_CHECK_ARG(mph && (M % 256) == 0 && (T % 32) == 0 && ((uintptr_t)oph % 8) == 0);
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
@@ -634,7 +648,7 @@ static int relattn_fwd_launch(const void* q, const void* k, const void* v, const
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.oph = (bf16_t*)oph; p.mph = mph; p.oph_all = oph_all ? 1 : 0;
+    p.oph = (bf16_t*)oph; p.mph = mph; p.oph_all = oph_all ? 1 : 0; p.ph_rec = (char*)ph_ws;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 16: return launch_fwd<16>(p, s);
@@ -662,10 +676,10 @@ extern "C" int mxl_relattn_fwd_phantom(const void* q, const void* k, const void*
 }
 
 extern "C" int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
-                                        const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, int B, int T,
-                                        int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs,
-                                        long long o_bs, int o_rs, float scale, void* stream) {
+                                        const float* r_r_bias, void* out, float* lse, void* oph, float* mph, int oph_all, void* ph_ws,
+                                        int B, int T, int H, int dh, int M, int Kc, long long q_bs, int q_rs, long long kv_bs, int kv_rs,
+                                        int rd_rs, long long o_bs, int o_rs, float scale, void* stream) {
     MXL_CHECK_ARG(oph && mph);
     return relattn_fwd_launch(q, k, v, rd, r_w_bias, r_r_bias, out, lse, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs,
-                              o_rs, scale, oph, mph, stream, oph_all);
+                              o_rs, scale, oph, mph, stream, oph_all, ph_ws);
 }

@@ -240,14 +240,15 @@ def fused_bwd_applies(*, T, dh, M, Kc) -> bool:
 
 
 def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,
-                o_bs, o_rs, scale=None, oph=None, mph=None, oph_all=False):
+                o_bs, o_rs, scale=None, oph=None, mph=None, oph_all=False, ph_buf=None):
     """q/k/v/out may be strided views (e.g. slices of one (B, Kc, 3*H*dh) qkv buffer); strides in elements.
     `oph` (like out) / `mph` (B, H, T) f32: also write the phantom value-sum relattn_bwd(..., oph=, mph=) consumes
-    (oph_all: over every phantom cell, the form relattn_bwd_fused consumes)."""
+    (oph_all: over every phantom cell, the form relattn_bwd_fused consumes; then `ph_buf`, mxl_relattn_drd_phantom_ws_bytes bytes,
+    also receives the records of the phantom cells' dRd kernel: pass the same buffer to relattn_bwd_fused(ph_buf=, ph_ready=True))."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     if oph is not None and oph_all:
         check(lib().mxl_relattn_fwd_phantom2(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(lse), _p(oph),
-                                             _p(mph), 1, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs,
+                                             _p(mph), 1, _p(ph_buf), B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs,
                                              float(scale), _stream()), 'mxl_relattn_fwd_phantom2')
         return out
     if oph is not None:
@@ -477,12 +478,13 @@ def _phantom_ws(B, T, H, device):
 
 def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, d_rd, d_rwb, d_rrb, ws, qr_buf, *,
                       B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                      scale=None, oph=None, mph=None, defer_drd=False, ph_buf=None):
+                      scale=None, oph=None, mph=None, defer_drd=False, ph_buf=None, ph_ready=False):
     """Backward of relattn_fwd in one pass over the score cells (mxl_relattn_bwd_fused): dq, dk, dv written, d_rd (M, H*dh) f32 /
     d_rwb / d_rrb accumulated.  With zero memories (Kc < M + T) `oph` / `mph` must come from relattn_fwd(..., oph_all=True), and
-    the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom (its scratch: `ph_buf`, mxl_relattn_drd_phantom_ws_bytes
-    bytes, or one cached per shape; `qr_buf` is no longer used by this path); their part of d_rrb comes out of the dq finishing
-    kernel."""
+    the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom from per-tile records (`ph_buf`,
+    mxl_relattn_drd_phantom_ws_bytes bytes; ph_ready: relattn_fwd(..., ph_buf=) has filled them, otherwise
+    mxl_relattn_drd_phantom_prep does; without `ph_buf` one scratch per shape is cached; `qr_buf` is no longer used by this path);
+    their part of d_rrb comes out of the dq finishing kernel."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     d = H * dh
     # the slab sum (HBM-bound, 44 registers) and the phantom cells' dRd (MFMA / latency-bound) depend only on the fused pass, not on
@@ -506,10 +508,11 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
     def phantom():
         if Kc < M + T:
             ph = ph_buf if ph_buf is not None else _phantom_ws(B, T, H, q.device)
-            check(lib().mxl_relattn_drd_phantom_prep(_p(q), q_bs, q_rs, _p(r_r_bias), _p(lse), _p(delta), _p(ph), B, T, H, dh,
-                                                     _stream()), 'mxl_relattn_drd_phantom_prep')
-            check(lib().mxl_relattn_drd_phantom(_p(ph), _p(d_rd), B, T, H, dh, M, d_rd.stride(0), _p(rd), int(rd_rs), float(scale),
-                                                Kc, _stream()), 'mxl_relattn_drd_phantom')
+            if not (ph_ready and ph_buf is not None):
+                check(lib().mxl_relattn_drd_phantom_prep(_p(q), q_bs, q_rs, _p(r_r_bias), _p(lse), _p(ph), B, T, H, dh, float(scale),
+                                                         _stream()), 'mxl_relattn_drd_phantom_prep')
+            check(lib().mxl_relattn_drd_phantom(_p(ph), _p(delta), _p(d_rd), B, T, H, dh, M, d_rd.stride(0), _p(rd), int(rd_rs), Kc,
+                                                _stream()), 'mxl_relattn_drd_phantom')
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
     if defer_drd:

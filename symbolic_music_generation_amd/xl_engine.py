@@ -223,6 +223,9 @@ class XLEngine:
         use_oph = train and ((ws.fused_bwd and Kc < M + T) or ops.phantom_sum_applies(T=T, dh=c.d_head, M=M, Kc=Kc))
         ws.oph = [torch.empty(N, d, **bf) for _ in range(keep)] if use_oph else None
         ws.mph = [torch.empty(B, H, T, **f32) for _ in range(keep)] if use_oph else None
+        # ... and, with the fused backward, the per-tile records its phantom-cell dRd kernel reads (q + r_r_bias rows, -lse2)
+        ws.ph = ([torch.empty(int(ops.lib().mxl_relattn_drd_phantom_ws_bytes(B, T, H)), device=self.dev, dtype=torch.uint8)
+                  for _ in range(keep)] if (use_oph and ws.fused_bwd) else None)
         ws.tmp = torch.empty(N, d, **bf)
         ws.h1 = [torch.empty(N, d, **bf) for _ in range(keep)]
         ws.a = [torch.empty(N, Fi, **bf) for _ in range(keep)]
@@ -248,9 +251,6 @@ class XLEngine:
             if ws.fused_bwd:      # no dG tensor: the partial-dq slabs instead ((M/256 + 1) x (B, T, d) fp32)
                 ws.dg = None
                 ws.dq_slabs = torch.empty(ops.relattn_bwd_fused_ws_numel(B, T, H, c.d_head, M), **f32)
-                # the phantom cells' dRd kernel reads q + r_r_bias, -lse and delta from per-tile records (zero memories only)
-                ws.ph = (torch.empty(int(ops.lib().mxl_relattn_drd_phantom_ws_bytes(B, T, H)), device=self.dev, dtype=torch.uint8)
-                         if Kc < M + T else None)
                 ws.qr = None
             else:
                 ws.dg = torch.empty(B, H, T, M, **bf)
@@ -324,7 +324,8 @@ class XLEngine:
                             self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P),
                             ws.av[s], ws.lse[s], oph=ws.oph[s].view(B, T, d) if (train and ws.oph is not None) else None,
                             mph=ws.mph[s] if (train and ws.oph is not None) else None,
-                            oph_all=bool(train and getattr(ws, 'fused_bwd', False)), **st)
+                            oph_all=bool(train and getattr(ws, 'fused_bwd', False)),
+                            ph_buf=ws.ph[s] if (train and ws.ph is not None) else None, **st)
             ops.gemm(ws.av[s], self._lw(l, 'dec_attn.o_net.weight'), ws.tmp, N, d, d)
             ops.ln_residual_fwd(ws.tmp, h_in, self._lw(l, 'dec_attn.layer_norm.weight', self.P),
                                 self._lw(l, 'dec_attn.layer_norm.bias', self.P), ws.h1[s],
@@ -625,7 +626,8 @@ class XLEngine:
                                       ws.d_rd, gw(l, 'dec_attn.r_w_bias'), gw(l, 'dec_attn.r_r_bias'), ws.dq_slabs, ws.qr,
                                       dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
                                       oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
-                                      mph=ws.mph[l] if ws.oph is not None else None, ph_buf=ws.ph, **st)
+                                      mph=ws.mph[l] if ws.oph is not None else None,
+                                      ph_buf=ws.ph[l] if ws.ph is not None else None, ph_ready=ws.ph is not None, **st)
             else:
                 ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
                                 self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],
