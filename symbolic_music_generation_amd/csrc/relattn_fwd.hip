@@ -270,73 +270,94 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     if (kt_lo * KT < pz) {
         kt_start = pz / KT;
         const int qi = iw0 + r;
-        load_r(i0 - pz);
+        const int db0 = i0 - pz;
+        // Rd rows in 64-distance chunks through the 256-row ring: chunk c + 1 is stored (from registers loaded an iteration earlier)
+        // while chunk c is read -- different ring slots -- so ONE barrier per chunk covers both "c + 1 is complete" and "everybody is
+        // done with c" (the first form stored and read the same chunk between two barriers; an iteration is only 16 MFMAs per wave)
+        load_r(db0);
+        store_r(db0);
+        if (db0 + 64 <= M - 1) load_r(db0 + 64);
+        __syncthreads();
 #pragma unroll 1
-        for (int db = i0 - pz; db <= M - 1; db += 64) {
-            store_r(db);
-            __syncthreads();
-            if (db + 64 <= M - 1) load_r(db + 64);      // prefetch the next chunk while this one is consumed
-            if (iw0 < T) {
-#pragma unroll 1
+        for (int db = db0; db <= M - 1; db += 64) {
+            if (db + 64 <= M - 1) store_r(db + 64);
+            if (db + 128 <= M - 1) load_r(db + 128);
+            // the chunk's two 32-distance blocks side by side: both G chains issued before either block's softmax work
+            bool on[2], fullb[2];
+#pragma unroll
+            for (int gb = 0; gb < 2; gb++) {
+                const int dblk = db + 32 * gb;
+                on[gb] = (iw0 < T) && !(dblk + 31 <= iw0 - pz || dblk > M - 1);        // wave-uniform: a phantom cell in this block?
+                fullb[gb] = (dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T);   // every cell phantom and in range
+            }
+            if (on[0] || on[1]) {
+                f32x16 g[2];
+                bf16x8 ra[2][KS];
+#pragma unroll
+                for (int gb = 0; gb < 2; gb++) {
+                    const int slot = (db + 32 * gb + r) & 255;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                g[0] = cinit; g[1] = cinit;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                    for (int gb = 0; gb < 2; gb++)
+                        g[gb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[gb][ks]),
+                                                                        __builtin_bit_cast(mfma_bf16x8, qr[ks]), g[gb], 0, 0, 0);
+                float mx = NEG_BIG;
+#pragma unroll
                 for (int gb = 0; gb < 2; gb++) {
                     const int dblk = db + 32 * gb;
-                    if (dblk + 31 <= iw0 - pz || dblk > M - 1) continue;   // wave-uniform: no phantom cell in this block
-                    f32x16 g = cinit;
-                    const int slot = (dblk + r) & 255;
-                    {
-                        bf16x8 ra[KS];           // the block's four Rd fragments in one batch, then the chain (round 4)
-#pragma unroll
-                        for (int ks = 0; ks < KS; ks++) ra[ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int ks = 0; ks < KS; ks++)
-                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[ks]),
-                                                                        __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
-                    }
-                    // every (query, distance) cell of the block phantom and in range?  (scalar)
-                    const bool fullblk = __builtin_amdgcn_readfirstlane(
-                        (int)((dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T))) != 0;
-                    if (!fullblk) {
+                    const bool fl = __builtin_amdgcn_readfirstlane((int)(on[gb] && fullb[gb])) != 0;
+                    if (!fl) {          // (a block that is off altogether is masked out cell by cell: d <= qi - pz or d > M - 1)
 #pragma unroll
                         for (int j = 0; j < 16; j++) {
                             const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
                             const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
-                            g[j] = valid ? g[j] : NEG_BIG;
+                            g[gb][j] = valid ? g[gb][j] : NEG_BIG;
                         }
                     }
-                    float mx = NEG_BIG;
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) mx = max3(mx, g[j], g[j + 1]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const bool unset = m_run == NEG_BIG;
-                    const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
-                    if (__any(need)) {
-                        const float delta = need ? mx : 0.f;
-                        const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
-                        l_run *= alpha;
-                        if (need) m_run = (unset ? 0.f : m_run) + delta;
-                        const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
+                    for (int j = 0; j < 16; j += 2) mx = max3(mx, g[gb][j], g[gb][j + 1]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const bool unset = m_run == NEG_BIG;
+                const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
+                if (__any(need)) {
+                    const float delta = need ? mx : 0.f;
+                    const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+                    l_run *= alpha;
+                    if (need) m_run = (unset ? 0.f : m_run) + delta;
+                    const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
 #pragma unroll
-                        for (int j = 0; j < 16; j++) { g[j] -= delta; cinit[j] = neg; }
-                        if (p.oph) {
+                    for (int j = 0; j < 16; j++) { g[0][j] -= delta; g[1][j] -= delta; cinit[j] = neg; }
+                    if (p.oph) {
 #pragma unroll
-                            for (int e = 0; e < EB; e++)
+                        for (int e = 0; e < EB; e++)
 #pragma unroll
-                                for (int j = 0; j < 16; j++) o[e][j] *= alpha;
-                        }
+                            for (int j = 0; j < 16; j++) o[e][j] *= alpha;
                     }
-                    float rs = 0.f;
+                }
+                float rs = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 16; j++) { g[j] = __builtin_amdgcn_exp2f(g[j]); rs += g[j]; }   // exp2(NEG_BIG) = 0 for masked cells
-                    l_run += rs;
-                    // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
-                    if (p.oph && (p.oph_all || (dblk & ~255) > iw0 + 31 - pz)) {
+                for (int gb = 0; gb < 2; gb++)
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { g[gb][j] = __builtin_amdgcn_exp2f(g[gb][j]); rs += g[gb][j]; }   // exp2(NEG_BIG) = 0
+                l_run += rs;
+                // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
+#pragma unroll
+                for (int gb = 0; gb < 2; gb++) {
+                    const int dblk = db + 32 * gb;
+                    if (p.oph && on[gb] && (p.oph_all || (dblk & ~255) > iw0 + 31 - pz)) {
                         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
                         const char* rb = sR + (dblk & 255) * G::ROWB;      // a multiple of 32 rows: + 0..31 does not wrap
 #pragma unroll
                         for (int st = 0; st < 2; st++) {
-                            const u32x4 pw = {pack2bf(g[8 * st], g[8 * st + 1]), pack2bf(g[8 * st + 2], g[8 * st + 3]),
-                                              pack2bf(g[8 * st + 4], g[8 * st + 5]), pack2bf(g[8 * st + 6], g[8 * st + 7])};
+                            const u32x4 pw = {pack2bf(g[gb][8 * st], g[gb][8 * st + 1]), pack2bf(g[gb][8 * st + 2], g[gb][8 * st + 3]),
+                                              pack2bf(g[gb][8 * st + 4], g[gb][8 * st + 5]), pack2bf(g[gb][8 * st + 6], g[gb][8 * st + 7])};
                             const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
                             for (int e = 0; e < EB; e++) {
