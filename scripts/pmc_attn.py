@@ -37,7 +37,9 @@ def main(*csvs):
             'active_inst/wave': d.SQ_ACTIVE_INST_ANY / d.SQ_WAVE_CYCLES,
             'valu_active/wave': d.SQ_ACTIVE_INST_VALU / d.SQ_WAVE_CYCLES,
             'lds_active/wave': d.SQ_ACTIVE_INST_LDS / d.SQ_WAVE_CYCLES,
-            'mfma_busy/(busy*4simd)': d.SQ_VALU_MFMA_BUSY_CYCLES / (d.SQ_BUSY_CYCLES * 4 * 4) if 'SQ_BUSY_CYCLES' in d else None,
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 CUs = 32 SIMDs each); SQ_VALU_MFMA_BUSY_CYCLES over all SIMDs
+            # (= MFMA instructions x their cycles).  Rounds 2-4 divided by 16 here and reported twice the occupancy.
+            'mfma_busy/simd_cycles': d.SQ_VALU_MFMA_BUSY_CYCLES / (d.SQ_BUSY_CYCLES * 32) if 'SQ_BUSY_CYCLES' in d else None,
         })
         pd.set_option('display.float_format', lambda v: f'{v:.3f}')
         print(out)

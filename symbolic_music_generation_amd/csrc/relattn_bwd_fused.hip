@@ -82,11 +82,22 @@ __device__ unsigned long long g_fused_stamps[16];
 #define STAMP_FLUSH
 #endif
 
+// Partial-dq slabs: fp32 (MXL_SLAB_BF16 = 0) or bf16.  bf16 halves the slab round trip (dq finish 0.43 -> 0.25 ms, fused pass
+// -0.03 ms at the bench shape) at the price of one bf16 rounding per key block and query in front of the fp32 sum.
+#ifndef MXL_SLAB_BF16
+#define MXL_SLAB_BF16 1
+#endif
+#if MXL_SLAB_BF16
+typedef bf16_t slab_t;
+#else
+typedef float slab_t;
+#endif
+
 struct FusedP {
     const bf16_t *q, *k, *v, *rd, *dout;
     const float *rwb, *rrb, *lse, *delta;
     bf16_t *dk, *dv;
-    bf16_t* slab;         // [nslot][B][T][H*64] bf16 partial dq, slot = key block - first key block that sees the query tile
+    slab_t* slab;         // [nslot][B][T][H*64] partial dq, slot = key block - first key block that sees the query tile
     float* drd;           // (M, drd_ld) fp32, +=
     float *d_rwb, *d_rrb; // (H, 64) fp32, +=  (the stored keys' part)
     int B, T, H, M, Kc;
@@ -801,13 +812,18 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
                 // The slabs are bf16 (half the bytes of the round trip through the finish kernel, which sums them in fp32): a lane owns one
                 // column of four rows, so neighbouring lanes trade values (DPP quad swap) and the even lane stores the packed pair of
                 // rows 0 / 1, the odd lane that of rows 2 / 3 -- two 4-byte stores per lane instead of four.
-                const int rowb = p.H * 64 * 2;              // bytes per dq row of a slab
-                bf16_t* tile = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride + ((size_t)b * T + I + 16 * ih0) * (size_t)(p.H * 64) + h * 64 + 16 * eq;
+                const int rowb = p.H * 64 * (int)sizeof(slab_t);              // bytes per dq row of a slab
+                slab_t* tile = p.slab + (size_t)(bx_ - kb_lo) * p.slab_stride + ((size_t)b * T + I + 16 * ih0) * (size_t)(p.H * 64) + h * 64 + 16 * eq;
                 const __amdgpu_buffer_rsrc_t rs_sl = __builtin_amdgcn_make_buffer_rsrc((void*)tile, 0, -1, 0x00020000);
+#if MXL_SLAB_BF16
                 const bool odd = (l & 1) != 0;
                 const int vo = (4 * g16 + (odd ? 2 : 0)) * rowb + ((l & 15) >> 1) * 4;
+#else
+                const int vo = 4 * g16 * rowb + (l & 15) * 4;
+#endif
 #pragma unroll
                 for (int ih = 0; ih < NIH; ih++) {
+#if MXL_SLAB_BF16
                     float v[4], nb[4];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
@@ -819,6 +835,11 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
                         const float lo = odd ? nb[2 + u] : v[u], hi = odd ? v[2 + u] : nb[u];
                         __builtin_amdgcn_raw_buffer_store_b32((int)pack2bf(lo, hi), rs_sl, vo, (16 * ih + u) * rowb, 0);
                     }
+#else
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, aw4[ih][t] + ar4[ih][t]), rs_sl, vo, (16 * ih + t) * rowb, 0);
+#endif
                     cw += (aw4[ih][0] + aw4[ih][1]) + (aw4[ih][2] + aw4[ih][3]);
                     cr += (ar4[ih][0] + ar4[ih][1]) + (ar4[ih][2] + ar4[ih][3]);
                 }
@@ -903,7 +924,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
 // element doubled the kernel's time, and so did a flush per row group -- 6 M float atomics on 3 KB of addresses).
 // ---------------------------------------------------------------------------------------------------------------
 struct FinP {
-    const bf16_t* slab; const bf16_t* oph; const float *mph, *lse, *delta;
+    const slab_t* slab; const bf16_t* oph; const float *mph, *lse, *delta;
     bf16_t* dq; float* d_rrb;
     int B, T, H, M, Kc;
     long long slab_stride, o_bs, dq_bs; int o_rs, dq_rs;
@@ -921,7 +942,7 @@ __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
     const int p0 = p.T - p.Kc;
     const int nkb = (p.Kc + KBLK - 1) / KBLK;
     const bool colsum = p.oph != nullptr && p.d_rrb != nullptr;
-    const bf16_t* __restrict__ slab = p.slab;
+    const slab_t* __restrict__ slab = p.slab;
     const int t = threadIdx.x;
     // A thread owns ONE 8-element column chunk for the whole launch (so the column sums of the phantom term stay in its registers)
     // and walks rows: cw = min(nch, 256) chunks side by side, kr = 256 / cw rows side by side (d = 768: 96 x 2, 192 threads busy);
@@ -954,6 +975,7 @@ __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
                 }
 #pragma unroll 5
                 for (int s = 0; s < nsl; s++) {
+#if MXL_SLAB_BF16
                     bf16x8 a[FIN_K];
 #pragma unroll
                     for (int k = 0; k < FIN_K; k++)
@@ -962,6 +984,18 @@ __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
                     for (int k = 0; k < FIN_K; k++)
 #pragma unroll
                         for (int j = 0; j < 8; j++) acc[k][j] += bf2f((bf16_t)a[k][j]);
+#else
+                    f32x4 a[FIN_K][2];
+#pragma unroll
+                    for (int k = 0; k < FIN_K; k++) {
+                        const float* sp = slab + (size_t)s * p.slab_stride + ((size_t)b * p.T + i_[k]) * (size_t)d + c * 8;
+                        a[k][0] = *reinterpret_cast<const f32x4*>(sp); a[k][1] = *reinterpret_cast<const f32x4*>(sp + 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < FIN_K; k++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { acc[k][j] += a[k][0][j]; acc[k][4 + j] += a[k][1][j]; }
+#endif
                 }
 #pragma unroll
                 for (int k = 0; k < FIN_K; k++) {
@@ -1014,7 +1048,7 @@ extern "C" int mxl_debug_fused_stamps(unsigned long long* host_out16) {
 
 extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M) {
     if (B <= 0 || T <= 0 || H <= 0 || dh != 64 || M <= 0) return 0;
-    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(bf16_t);
+    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(slab_t);
 }
 
 extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
@@ -1054,7 +1088,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     FusedP p;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.rd = (const bf16_t*)rd; p.dout = (const bf16_t*)dout;
     p.rwb = r_w_bias; p.rrb = r_r_bias; p.lse = lse; p.delta = delta;
-    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.slab = (bf16_t*)ws; p.drd = d_rd; p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
+    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.slab = (slab_t*)ws; p.drd = d_rd; p.d_rwb = d_r_w_bias; p.d_rrb = d_r_r_bias;
     p.B = B; p.T = T; p.H = H; p.M = M; p.Kc = Kc;
     p.q_bs = q_bs; p.kv_bs = kv_bs; p.o_bs = o_bs; p.dkv_bs = dkv_bs; p.slab_stride = (long long)B * T * H * 64;
     p.q_rs = q_rs; p.kv_rs = kv_rs; p.rd_rs = rd_rs; p.o_rs = o_rs; p.dkv_rs = dkv_rs; p.drd_ld = drd_ld;
@@ -1080,7 +1114,7 @@ extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const flo
                   ((uintptr_t)ws % 16) == 0 && (oph == nullptr || ((uintptr_t)oph % 16) == 0));
     hipStream_t s = (hipStream_t)stream;
     FinP f;
-    f.slab = (const bf16_t*)ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
+    f.slab = (const slab_t*)ws; f.oph = (Kc < M + T) ? (const bf16_t*)oph : nullptr; f.mph = mph; f.lse = lse; f.delta = delta;
     f.dq = (bf16_t*)dq; f.d_rrb = d_r_r_bias;
     f.B = B; f.T = T; f.H = H; f.M = M; f.Kc = Kc;
     f.slab_stride = (long long)B * T * H * 64; f.o_bs = o_bs; f.dq_bs = dq_bs; f.o_rs = o_rs; f.dq_rs = dq_rs; f.scale = scale;
