@@ -639,8 +639,8 @@ def test_c3_train_step_gradients_vs_oracle(dev):
     EVERY parameter's gradient of the 12-layer backward against the fp32 oracle's autograd.  The oracle recomputes each layer in
     its backward (`checkpoint_layers`: the same arithmetic; the dense (2048, 4096, 12) score tensors of twelve layers would need
     ~25 GB otherwise).
-    Limits: the fixed ones of C2 and of the two-layer C3 test (rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight <= 20 % /
-    >= 0.98, the last LayerNorm's bias <= 10 % / >= 0.995) or, where bf16 STORAGE alone costs more than that, 1.5 x the deviation
+    Limits: the fixed ones of C2 and of the two-layer C3 test (rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight <= 12 % /
+    >= 0.99, the last LayerNorm's bias <= 10 % / >= 0.995) or, where bf16 STORAGE alone costs more than that, 1.5 x the deviation
     of the same oracle run with bf16 storage of activations and gradient streams and exact arithmetic everywhere else
     (`_bf16_storage_train_step`), never beyond 15 % / 0.985.  Measured: that envelope is 5.9 % (layer 11) to 8.8 % (layer 0) on
     the worst tensor of a layer (the first FFN weight: 2048 tokens, one sequence), the HIP path 1.19 x it at every depth --
@@ -676,9 +676,13 @@ def test_c3_train_step_gradients_vs_oracle(dev):
         layer = int(parts[2]) if parts[1] == 'layers' else None
         # r_r_bias: like r_net.weight a sum of the un-skewed score gradient over every (query, distance) cell of a head, with
         # cancellation (the rows of dG sum to zero): 6.2 % measured at layer 1, the others 2-5 %
-        base = ((0.20, 0.98) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias or name.endswith('r_r_bias')
+        # r_net.weight: measured 2.2 - 10.0 % per layer (round 4, fused backward + phantom-cell kernel; the limit was 20 % until then)
+        base = ((0.12, 0.99) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias or name.endswith('r_r_bias')
                 else (0.06, 0.998))
-        lim = (min(0.15, max(base[0], 1.5 * ee)), max(0.985, min(base[1], 1.0 - 1.5 * (1.0 - ecos))))
+        # "1.5 x the deviation" on both measures: 1 - cosine is quadratic in the relative deviation, so 1.5 x in deviation is
+        # 2.25 x in 1 - cosine.  (Until round 4 the cosine term used 1.5 x, i.e. 1.22 x in deviation, while the HIP path sits at
+        # 1.19 - 1.24 x the envelope on every tensor: two LayerNorm weights then read 0.99797 against a limit of 0.998.)
+        lim = (min(0.15, max(base[0], 1.5 * ee)), max(0.985, min(base[1], 1.0 - 2.25 * (1.0 - ecos))))
         if e > lim[0] or cos < lim[1]:
             bad[name] = (round(e, 4), round(cos, 5), 'envelope', round(ee, 4), round(ecos, 5))
         if layer is not None and not name.endswith('r_net.weight'):
