@@ -316,9 +316,17 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     float tl = 0.f, tdl = 0.f;
     // four waves: every thread takes a chunk of each; eight waves: waves 0-3 the q rows, waves 4-7 the dO rows and the Rd block
     const bool st_q = NSUB == 2 || tid < 256, st_do = NSUB == 2 || tid >= 256;
-    const int srow_ = (tid & 255) >> 3, sch_ = tid & 7;
-    const int vo_q = (srow_ * p.q_rs + sch_ * 8) * 2, vo_do = (srow_ * p.o_rs + sch_ * 8) * 2;     // byte offsets inside a tile
+    // The staging indices are recomputed from the thread id at every use (the id goes through an empty asm, so hipcc cannot hoist what
+    // is derived from it): held across the tile loop, their registers were what the kernel spilled, and the reload of a spilled
+    // address at the top of every tile is a scratch load, i.e. an s_waitcnt vmcnt(0) that drains the previous tile's slab stores.
+#ifdef MXL_FUSED_HOIST_STAGING
+#define STG_IDS const int srow_ = (tid & 255) >> 3, sch_ = tid & 7;
+#else
+#define STG_IDS int tid_o = tid; asm volatile("" : "+v"(tid_o)); const int srow_ = (tid_o & 255) >> 3, sch_ = tid_o & 7;
+#endif
     auto load_q = [&](int it) {                 // T % 32 == 0: every row of a tile exists
+        STG_IDS
+        const int vo_q = (srow_ * p.q_rs + sch_ * 8) * 2, vo_do = (srow_ * p.o_rs + sch_ * 8) * 2;     // byte offsets inside a tile
         const int I = it * QT;
         if (NSUB == 2) {
             tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q, I * p.q_rs * 2, 0));
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         tdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dl, (tid & 31) * 4, I * 4, 0));
     };
     auto store_q = [&](int buf) {
+        STG_IDS
         char* sQw = sQ + buf * QSET;
         char* sQr = sQw + QIMG;
         char* sDO = sQr + QIMG;
@@ -366,12 +375,14 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     };
     auto load_r = [&](int n) {                  // 32 Rd rows of distance block n (row index clamped: out-of-range cells are masked)
         if (!st_do) return;
+        STG_IDS
         int d = 32 * n + srow_;
         d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
         rr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rd, (d * p.rd_rs + sch_ * 8) * 2, 0, 0));
     };
     auto store_r = [&](int n) {
         if (!st_do) return;
+        STG_IDS
         const int slot = (n + RING_OFF) % RING_BLKS;
         *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = rr;
     };
