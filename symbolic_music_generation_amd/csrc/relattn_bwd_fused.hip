@@ -1134,7 +1134,8 @@ extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const flo
         // threads: the busy ones only (d = 768: 2 rows x 96 chunks = 192 = three whole waves), ten such workgroups per CU
         const long long rgs = (long long)B * (T / FIN_ROWS);
         const int nch = H * 8, cw = nch < 256 ? nch : 256, busy = (256 / cw) * cw, nthr = (busy + 63) / 64 * 64;
-        const long long want = 256ll * (2048 / nthr);
+        static const int per_cu = getenv("MXL_DQFIN_WG_PER_CU") ? atoi(getenv("MXL_DQFIN_WG_PER_CU")) : 2048 / nthr;
+        const long long want = 256ll * per_cu;
         hipLaunchKernelGGL(relattn_dq_finish_kernel, dim3((unsigned)(rgs < want ? rgs : want)), dim3(nthr), 0, s, f);
     }
     MXL_LAUNCH_CHECK();
