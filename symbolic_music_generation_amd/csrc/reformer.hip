@@ -314,6 +314,35 @@ __global__ __launch_bounds__(64 * W) void lsh_sort_mw_kernel(const int* buckets,
 // lane = query ("swapped" S^T = K Q^T), single pass over the 128 keys.
 // =====================================================================================================================
 constexpr int SC_MAXT = 64;      // sequences up to one chunk take the single-chunk kernels
+
+// Dropout on the attention probabilities of the chunk kernels.  A cell is (query slot s = (b * H + h) * S + qslot, key index kw in
+// that slot's 128-key window).  ONE lowbias32 round serves a 2 x 2 block of cells -- slots (s, s ^ 1) x keys (kw, kw ^ 1): two 32-bit
+// words (the hash, and a multiply-xorshift of it), the word picked by the key's parity, the 16-bit half by the slot's, against a
+// 16-bit threshold (p to 1 / 65536).  The forward and the query-owner backward hold one query and two neighbouring keys per lane,
+// the key-owner backward one key and two neighbouring queries: each then hashes once per two cells instead of once per cell (the
+// per-cell hash on a 64-bit index was half of the ~30 VALU operations per cell these kernels spend next to 0.5 MFMA).
+struct ChunkDrop {
+    uint32_t key;       // block-row key: hash input of block (s >> 1, 0); block column c adds c * 0x9E3779B1
+    uint32_t t16;
+};
+__device__ __forceinline__ ChunkDrop chunk_drop_row(unsigned long long seed, unsigned site, uint64_t slot, unsigned thresh) {
+    const uint32_t mix = mxl_hash32((uint32_t)seed ^ (site * 0x9E3779B9U)) + (uint32_t)(seed >> 32);
+    const uint64_t blk = (slot >> 1) * 64;
+    ChunkDrop d;
+    d.key = (((uint32_t)blk * 0x9E3779B1U) ^ ((uint32_t)(blk >> 32) * 0x85EBCA77U)) + mix;
+    d.t16 = thresh >> 16;
+    return d;
+}
+// the two words of block column kw >> 1
+__device__ __forceinline__ void chunk_drop_words(const ChunkDrop& d, int kw, uint32_t& w0, uint32_t& w1) {
+    w0 = mxl_hash32(d.key + (uint32_t)(kw >> 1) * 0x9E3779B1U);
+    w1 = (w0 * 0x85EBCA77U) ^ (w0 >> 13);
+}
+__device__ __forceinline__ bool chunk_drop_keep(const ChunkDrop& d, uint32_t w0, uint32_t w1, int kw, int slot_parity) {
+    const uint32_t w = (kw & 1) ? w1 : w0;
+    return ((slot_parity ? (w >> 16) : (w & 0xffffu)) >= d.t16);
+}
+
 struct ChunkP {
     const bf16_t *q, *k, *v;
     const int* spos;            // (B,H,S) or null (identity)
@@ -459,7 +488,8 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
 #pragma unroll
         for (int j = 0; j < 16; j++) { const float e = __expf(s[kb][j] - mx); s[kb][j] = e; sum += e; }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
+    // the unnormalised exponentials (<= 1) go into the P V product; 1 / sum and the dropout scale are applied to O once, at the end
+    const float inv = (p.thresh ? p.dscale : 1.f) / sum;
     const size_t orow = ((size_t)b * p.n_h + round) * p.T + qpos;
     if (hh == 0 && p.lse) p.lse[(((size_t)b * p.n_h + round) * p.H + h) * p.T + qpos] = mx + __logf(sum);
     // probabilities (+ dropout), P^T fragments straight from the accumulators
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
 #pragma unroll
         for (int j = 0; j < 16; j++) o[e][j] = 0.f;
     const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
-    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
+    const ChunkDrop dr = chunk_drop_row(p.seed, p.site, ((uint64_t)b * p.H + h) * p.S + qslot, p.thresh);
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
 #pragma unroll
@@ -477,11 +507,13 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
             bf16x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                float p0 = s[kb][8 * st + j] * inv, p1 = s[kb][8 * st + j + 1] * inv;
+                float p0 = s[kb][8 * st + j], p1 = s[kb][8 * st + j + 1];
                 if (p.thresh) {
-                    const int k0 = 32 * kb + ((8 * st + j) & 3) + 8 * ((8 * st + j) >> 2) + 4 * hh;
-                    p0 = dropout_keep(p.seed, p.site, dbase + k0, p.thresh) ? p0 * p.dscale : 0.f;
-                    p1 = dropout_keep(p.seed, p.site, dbase + k0 + 1, p.thresh) ? p1 * p.dscale : 0.f;
+                    const int k0 = 32 * kb + ((8 * st + j) & 3) + 8 * ((8 * st + j) >> 2) + 4 * hh;      // even; k0 + 1 is its block partner
+                    uint32_t w0, w1;
+                    chunk_drop_words(dr, k0, w0, w1);
+                    p0 = chunk_drop_keep(dr, w0, w1, k0, qslot & 1) ? p0 : 0.f;
+                    p1 = chunk_drop_keep(dr, w0, w1, k0 + 1, qslot & 1) ? p1 : 0.f;
                 }
                 const uint32_t w = pack2bf(p0, p1);
                 pf[j] = (short)(w & 0xffff); pf[j + 1] = (short)(w >> 16);
@@ -508,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
         for (int grp = 0; grp < 4; grp++) {
             const int e0 = 32 * e + 8 * grp + 4 * hh;
             if (e0 < DH) {
-                u32x2 w = {pack2bf(o[e][4 * grp], o[e][4 * grp + 1]), pack2bf(o[e][4 * grp + 2], o[e][4 * grp + 3])};
+                u32x2 w = {pack2bf(o[e][4 * grp] * inv, o[e][4 * grp + 1] * inv), pack2bf(o[e][4 * grp + 2] * inv, o[e][4 * grp + 3] * inv)};
                 *reinterpret_cast<u32x2*>(op + e0) = w;
             }
         }
@@ -580,24 +612,30 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
                                                              __builtin_bit_cast(mfma_bf16x8, dof[ks]), dp[kb], 0, 0, 0);
         }
     }
-    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
+    const ChunkDrop dr = chunk_drop_row(p.seed, p.site, ((uint64_t)b * p.H + h) * p.S + qslot, p.thresh);
 #pragma unroll
     for (int kb = 0; kb < 4; kb++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int kk = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            const int row = kb0 + kk;
-            const int kp = sPos[row];
-            const float f = sFac[row];
-            float v = s[kb][j] * f;
-            v = (qpos >= kp) ? v : -1e9f;
-            if (p.lsh) v = (qpos != kp) ? v : -1e5f;
-            const float pr = __expf(v - lse);
-            float g = dp[kb][j];
-            if (p.thresh) g = dropout_keep(p.seed, p.site, dbase + kk, p.thresh) ? g * p.dscale : 0.f;
-            // gradient w.r.t. the raw dot (q . x_k): dS * f_k ; masked entries have pr == 0 (or constant score -> no grad)
-            const bool live = (qpos >= kp) && !(p.lsh && qpos == kp);
-            s[kb][j] = live ? (pr * (g - dlt) + dl * pr) * f : 0.f;
+        for (int j2 = 0; j2 < 16; j2 += 2) {
+            uint32_t w0 = 0u, w1 = 0u;       // registers j2, j2 + 1 are neighbouring keys: one block, one hash
+            if (p.thresh) chunk_drop_words(dr, 32 * kb + (j2 & 3) + 8 * (j2 >> 2) + 4 * hh, w0, w1);
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = j2 + jj;
+                const int kk = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                const int row = kb0 + kk;
+                const int kp = sPos[row];
+                const float f = sFac[row];
+                float v = s[kb][j] * f;
+                v = (qpos >= kp) ? v : -1e9f;
+                if (p.lsh) v = (qpos != kp) ? v : -1e5f;
+                const float pr = __expf(v - lse);
+                float g = dp[kb][j];
+                if (p.thresh) g = chunk_drop_keep(dr, w0, w1, kk, qslot & 1) ? g * p.dscale : 0.f;
+                // gradient w.r.t. the raw dot (q . x_k): dS * f_k ; masked entries have pr == 0 (or constant score -> no grad)
+                const bool live = (qpos >= kp) && !(p.lsh && qpos == kp);
+                s[kb][j] = live ? (pr * (g - dlt) + dl * pr) * f : 0.f;
+            }
         }
     // dq^T[e, q] = sum_k X^T[e, k] * dSf^T[k, q]
     f32x16 aq[EB];
@@ -781,29 +819,41 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
         }
         f32x16 pr;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-            const int qrow = q0 + ii;
-            const int qp = sQpos[qrow];
+        for (int j2 = 0; j2 < 16; j2 += 2) {
             int chunkq = kc + qsel;
             if (chunkq >= NC) chunkq -= NC;
-            const int qslot = chunkq * 64 + 32 * qb + ii;
-            float v = s[j] * fac;
-            v = (qp >= kpos) ? v : -1e9f;
-            if (p.lsh) v = (qp != kpos) ? v : -1e5f;
-            const float pv = __expf(v - sLse[qrow]);
-            float g = dp[j];
-            float pd = pv;
+            // registers j2, j2 + 1 are neighbouring query slots (even, odd): one block row, one hash
+            uint32_t w0 = 0u, w1 = 0u;
+            ChunkDrop dr;
+            dr.key = 0u; dr.t16 = 0u;
             if (p.thresh) {
-                const uint64_t dbase = (((uint64_t)b * p.H + h) * p.S + qslot) * 128;
-                const bool keep = dropout_keep(p.seed, p.site, dbase + kwin, p.thresh);
-                g = keep ? g * p.dscale : 0.f;
-                pd = keep ? pv * p.dscale : 0.f;
+                const int qs0 = chunkq * 64 + 32 * qb + (j2 & 3) + 8 * (j2 >> 2) + 4 * hh;
+                dr = chunk_drop_row(p.seed, p.site, ((uint64_t)b * p.H + h) * p.S + qs0, p.thresh);
+                chunk_drop_words(dr, kwin, w0, w1);
             }
-            const bool live = (qp >= kpos) && !(p.lsh && qp == kpos);
-            const float ds = live ? (pv * (g - sDl[qrow]) + sDlse[qrow] * pv) : 0.f;
-            pr[j] = pd;
-            s[j] = p.lsh ? ds : ds * fac;      // local: d k = dS * scale * q ; LSH: d k' = dS * q (chain applied later)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = j2 + jj;
+                const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                const int qrow = q0 + ii;
+                const int qp = sQpos[qrow];
+                const int qslot = chunkq * 64 + 32 * qb + ii;
+                float v = s[j] * fac;
+                v = (qp >= kpos) ? v : -1e9f;
+                if (p.lsh) v = (qp != kpos) ? v : -1e5f;
+                const float pv = __expf(v - sLse[qrow]);
+                float g = dp[j];
+                float pd = pv;
+                if (p.thresh) {
+                    const bool keep = chunk_drop_keep(dr, w0, w1, kwin, qslot & 1);
+                    g = keep ? g * p.dscale : 0.f;
+                    pd = keep ? pv * p.dscale : 0.f;
+                }
+                const bool live = (qp >= kpos) && !(p.lsh && qp == kpos);
+                const float ds = live ? (pv * (g - sDl[qrow]) + sDlse[qrow] * pv) : 0.f;
+                pr[j] = pd;
+                s[j] = p.lsh ? ds : ds * fac;      // local: d k = dS * scale * q ; LSH: d k' = dS * q (chain applied later)
+            }
         }
 #pragma unroll
         for (int st = 0; st < 2; st++) {
