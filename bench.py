@@ -561,6 +561,11 @@ def pmc_traffic(workload, B):
             names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']
     if not all(n in k for n in names):
         return None, None
+    if 'group_sources_sha16' in rec:      # the record is only as good as the kernels it measured: a changed source needs new PMC passes
+        sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+        import pmc_traffic as _pt
+        if _pt.sources_sha16('train') != rec['group_sources_sha16']:
+            return None, os.path.basename(path) + ' (STALE: kernel sources changed since the PMC passes)'
     return sum(k[n]['hbm_bytes_per_launch'] * k[n].get('launches_per_group', 1) for n in names), os.path.basename(path)
 
 

@@ -9,13 +9,26 @@
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KB; on gfx950 FETCH_SIZE
 tallies the 128-byte requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for
 16-byte stores and float atomics.  Infinity-Cache hits are included in both (memory-side L2 counters)."""
+import hashlib
 import json
+import os
 import sys
 
-import pandas as pd
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the translation units that hold the kernels of bench.py's roofline group: their hash goes into the record, and bench.py reports
+# the recorded traffic only while it still matches the sources (a changed kernel must be re-measured)
+GROUP_SOURCES = {'train': ['relattn_bwd_fused.hip', 'relattn_drd_phantom.hip'], 'reformer': ['gemm.hip'], 'decode': ['decode.hip']}
+
+
+def sources_sha16(kind):
+    h = hashlib.sha256()
+    for f in GROUP_SOURCES[kind]:
+        h.update(open(os.path.join(ROOT, 'symbolic_music_generation_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
+    import pandas as pd
     df = pd.read_csv(path)
     df = df[df.Counter_Name == counter]
     df = df.assign(k=df.Kernel_Name.str.replace(r'\(anonymous namespace\)::', '', regex=True).str.replace(r'\(.*', '', regex=True)
@@ -33,7 +46,8 @@ def main(fetch_csv, write_csv, out_json, batch=32, kind='train'):
         out[k] = {'launches': int(f['count'].get(k, w['count'].get(k, 0))), 'fetch_size_bytes_raw': fk,
                   'fetch_bytes_corrected_x2': 2.0 * fk, 'write_bytes': wk, 'hbm_bytes_per_launch': 2.0 * fk + wk}
     rec = {'command': 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (SURVEY C3, 1x MI355X)',
-           'per_gpu_batch': int(batch), 'units': 'bytes per launch (counter mean over launches x 1000)', 'kernels': out}
+           'per_gpu_batch': int(batch), 'units': 'bytes per launch (counter mean over launches x 1000)',
+           'group_sources': GROUP_SOURCES[kind], 'group_sources_sha16': sources_sha16(kind), 'kernels': out}
     if kind == 'decode':
         # eager decode window (bench.py --mode decode --eager --decode-steps 40): bytes of the kernels of the decode loop per step
         loop = ['advance_kernel', 'decode_attn_kernel<64>', 'decode_bd_kernel', 'decode_embed_kernel', 'gemm_skinny_kernel',
