@@ -191,6 +191,14 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
 
     // ---- staging helpers -----------------------------------------------------------------------------------
     u32x4 rk[G::NLD_K], rv[G::NLD_V], rr[G::NLD_K];
+    // K / V / Rd rows through buffer descriptors (wave-uniform base in scalar registers, 32-bit lane offset): rows below the first
+    // stored key (negative offset = huge unsigned) and past the last one fall outside num_records and read as zero -- upstream's zero
+    // memories -- without a branch, a select or 64-bit lane address arithmetic per load (the flat-pointer form spent ~15
+    // instructions and an exec-masked branch on each of the six loads at the top of every tile)
+    const unsigned kv_bytes = (unsigned)(((long long)(p.Kc - 1) * p.kv_rs + DH) * 2);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, -1, 0x00020000);
     auto load_kv = [&](int kt) {
         const int P = kt * KT;
 #pragma unroll
@@ -198,10 +206,13 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             const int c = tid + n * 256;
             const int row = c / G::CH, ch = c % G::CH;
             const int srow = P + row - p0;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            const bool ok = (c < KT * G::CH) && (srow >= 0) && (srow < p.Kc);
-            rk[n] = ok ? *reinterpret_cast<const u32x4*>(kbase + (size_t)srow * p.kv_rs + ch * 8) : z;
-            rv[n] = ok ? *reinterpret_cast<const u32x4*>(vbase + (size_t)srow * p.kv_rs + ch * 8) : z;
+            if (KT * G::CH % 256 == 0 || c < KT * G::CH) {
+                const int off = (srow * p.kv_rs + ch * 8) * 2;
+                rk[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, off, 0, 0));
+                rv[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0));
+            } else {
+                rk[n] = u32x4{0u, 0u, 0u, 0u}; rv[n] = u32x4{0u, 0u, 0u, 0u};
+            }
         }
     };
     auto store_kv = [&]() {
@@ -223,8 +234,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             const int row = c / G::CH, ch = c % G::CH;
             int d = dbase + row;
             d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
-            u32x4 z = {0u, 0u, 0u, 0u};
-            rr[n] = (c < KT * G::CH) ? *reinterpret_cast<const u32x4*>(rbase + (size_t)d * p.rd_rs + ch * 8) : z;
+            if (KT * G::CH % 256 == 0 || c < KT * G::CH)
+                rr[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (d * p.rd_rs + ch * 8) * 2, 0, 0));
+            else rr[n] = u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto store_r = [&](int dbase) {
@@ -661,6 +673,8 @@ static int relattn_fwd_launch(const void* q, const void* k, const void* v, const
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
     MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 4) == 0);
+    // 32-bit byte offsets inside one sequence's K / V rows and inside rd (buffer addressing)
+    MXL_CHECK_ARG((long long)Kc * kv_rs * 2 < (1ll << 31) && (long long)M * rd_rs * 2 < (1ll << 31));
     MXL_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                   ((uintptr_t)rd % 16) == 0 && ((uintptr_t)out % 8) == 0);
     RelAttnP p;
