@@ -201,3 +201,33 @@ def test_shape_predicates_of_the_round3_paths():
     assert nbytes(131072, 2048) == 131072 * 2048 // 8           # C4 FFN
     assert nbytes(1000, 3072) == 0 and nbytes(2048, 200) == 0   # ragged
     assert nbytes(2048, 3072) == 0                              # fewer tiles than one round of the chip: 192-wide tiles win
+
+
+def test_recorded_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from a committed PMC record (counters cannot be collected inside the timed run): the
+    record carries a hash of the translation units that hold the measured kernels, and bench.py reports the bytes only while that
+    hash matches the sources -- otherwise `traffic` is null and the source note says the record is stale."""
+    import json
+    import shutil
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import bench
+    import pmc_traffic
+    sha = pmc_traffic.sources_sha16('train')
+    assert len(sha) == 16 and sha == pmc_traffic.sources_sha16('train')
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    names = ['fused_delta_kernel', 'relattn_bwd_fused_kernel<1>', 'relattn_dq_finish_kernel', 'relattn_drd_phantom_kernel']
+    rec = {'per_gpu_batch': 64, 'group_sources_sha16': sha, 'kernels': {n: {'hbm_bytes_per_launch': 1.0e9} for n in names}}
+    (prof / 'r99_c3_pmc_traffic.json').write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    # (the hash is taken from the real sources: bench imports pmc_traffic from ROOT/scripts, so give the fake root a copy)
+    shutil.copytree(os.path.join(ROOT, 'scripts'), tmp_path / 'scripts', ignore=shutil.ignore_patterns('__pycache__', 'ubench'))
+    got, src = bench.pmc_traffic('c3', 64)
+    assert got == 4.0e9 and src == 'r99_c3_pmc_traffic.json'
+    assert bench.pmc_traffic('c3', 32) == (None, None)           # another batch: not this measurement
+    rec['group_sources_sha16'] = '0' * 16
+    (prof / 'r99_c3_pmc_traffic.json').write_text(json.dumps(rec))
+    got, src = bench.pmc_traffic('c3', 64)
+    assert got is None and 'STALE' in src
