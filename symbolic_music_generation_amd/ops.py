@@ -232,11 +232,15 @@ def phantom_sum_applies(*, T, dh, M, Kc) -> bool:
             and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0' and os.environ.get('MXL_NO_OPH') != '1')
 
 
-def fused_bwd_applies(*, T, dh, M, Kc) -> bool:
-    """the shapes mxl_relattn_bwd_fused takes (one pass over the score cells, no dG tensor): the training shapes of every
-    BASELINE config; anything else stays on relattn_bwd's three kernels"""
-    return (dh == 64 and T % 32 == 0 and M % 256 == 0 and Kc % 32 == 0 and (T - Kc) % 64 == 0
-            and os.environ.get('MXL_NO_FUSED_BWD') != '1')
+def fused_bwd_applies(*, T, dh, M, Kc, B=None, H=None) -> bool:
+    """the shapes mxl_relattn_bwd_fused (and, with zero memories, mxl_relattn_drd_phantom) take -- one pass over the score cells, no
+    dG tensor: the training shapes of every BASELINE config; anything else stays on relattn_bwd's three kernels.  B, H (optional):
+    also the 32-bit offset limits of the phantom-cell kernel's buffer addressing."""
+    ok = (dh == 64 and T % 32 == 0 and M % 256 == 0 and M <= 8192 and Kc % 32 == 0 and (T - Kc) % 64 == 0
+          and os.environ.get('MXL_NO_FUSED_BWD') != '1')
+    if ok and B is not None and H is not None and Kc < M + T:
+        ok = H * (T // 32) * 4352 < 2 ** 31 and B * H * T * 4 < 2 ** 31
+    return ok
 
 
 def relattn_fwd(q, k, v, rd, r_w_bias, r_r_bias, out, lse, *, B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs,

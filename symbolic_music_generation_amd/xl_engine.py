@@ -219,7 +219,7 @@ class XLEngine:
         # zero-memory training: the forward's phantom value-sum per layer (ops.relattn_fwd(..., oph=, mph=)), which spares the
         # query-owner backward its walk over the all-phantom distance blocks
         # the fused attention backward (ops.relattn_bwd_fused) at the shapes it takes; it wants the value-sum over every phantom cell
-        ws.fused_bwd = train and ops.fused_bwd_applies(T=T, dh=c.d_head, M=M, Kc=Kc)
+        ws.fused_bwd = train and ops.fused_bwd_applies(T=T, dh=c.d_head, M=M, Kc=Kc, B=B, H=H)
         use_oph = train and ((ws.fused_bwd and Kc < M + T) or ops.phantom_sum_applies(T=T, dh=c.d_head, M=M, Kc=Kc))
         ws.oph = [torch.empty(N, d, **bf) for _ in range(keep)] if use_oph else None
         ws.mph = [torch.empty(B, H, T, **f32) for _ in range(keep)] if use_oph else None

@@ -162,4 +162,6 @@ def test_relattn_bwd_fused_rejects_shapes_it_does_not_take(dev):
     assert not ops.fused_bwd_applies(T=256, dh=64, M=320, Kc=256)
     assert not ops.fused_bwd_applies(T=256, dh=64, M=256, Kc=256 + 32)      # first stored key not on a 64-key tile boundary
     assert ops.fused_bwd_applies(T=2048, dh=64, M=2048, Kc=2048)
+    assert not ops.fused_bwd_applies(T=2048, dh=64, M=16384, Kc=2048)       # the phantom-cell kernel tables 32 distance blocks
+    assert not ops.fused_bwd_applies(T=2048, dh=64, M=2048, Kc=2048, B=8192, H=64)      # 32-bit offsets of its buffer addressing
     assert lib().mxl_relattn_bwd_fused_ws_bytes(2, 256, 2, 32, 256) == 0
