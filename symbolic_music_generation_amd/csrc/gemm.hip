@@ -539,10 +539,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     auto step = [&](bool first_of_later_tile, bool last_of_tile, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN], bf16x8 (&na)[FM],
                     bf16x8 (&nb)[FN]) {
         const bool issued = gi < S;
-        if (issued) issue_next();
-        // (with a bias epilogue not across a tile boundary: the 48 fragment registers are what the preloaded bias values live in;
-        // the next tile's first fragments are then read after the epilogue)
-        if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
+        // The two waves of a SIMD (w and w + 4) take the step's two halves in opposite order: waves 0-3 issue their DMAs and read the
+        // next fragments, then compute; waves 4-7 compute first (their fragments were read at the end of the previous step) and issue
+        // and read afterwards -- one wave's LDS-DMA issue (60-185 cycles a piece) and ds_reads run beside the other's MFMAs instead
+        // of both waves doing the same thing at the same time.  ffn1 forward 694 -> 650 us, ffn2 dX 699 -> 647, the K = 768 shapes
+        // -2 ... -7 %, K >= 2304 -1 % (profiles/r04_gemm_wave_phases.txt).
+        const bool late = wid >= 4;
+        if (!late) {
+            if (issued) issue_next();
+            // (with a bias epilogue not across a tile boundary: the 48 fragment registers are what the preloaded bias values live in;
+            // the next tile's first fragments are then read after the epilogue)
+            if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < FM; i++)
@@ -551,6 +559,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fb[j]),
                                                                     __builtin_bit_cast(mfma_bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
+            if (issued) issue_next();
+        }
         // (the fragment reads of step g+1 need not finish before this barrier: their stage is not re-filled before the
         // barrier of step g+1, and the MFMAs of step g+1 wait for them anyway)
         if (last_of_tile || !issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -790,8 +803,11 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(GemmP p) {
     int g = 0;
     auto step = [&](bf16x8 (&fa)[8], bf16x8 (&fb)[4], bf16x8 (&na)[8], bf16x8 (&nb)[4]) {
         const bool issued = gi < S;
-        if (issued) issue_next();
-        if (g + 1 < S) frags(g + 1, na, nb);
+        const bool late = wid >= 4;       // the SIMD's second wave computes first, loads afterwards (as in gemm_nt256_kernel): -5 ... -8 %
+        if (!late) {
+            if (issued) issue_next();
+            if (g + 1 < S) frags(g + 1, na, nb);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -800,6 +816,11 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(GemmP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, fa[i]),
                                                                     __builtin_bit_cast(mfma_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < S) frags(g + 1, na, nb);
+            if (issued) issue_next();
+        }
         // the next step's fragments have landed (asm loads: hipcc does not count them) and so has the stage after it
         if (!issued) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
