@@ -958,6 +958,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         else if (p.alpha != 1.f && (p.flags & MXL_GEMM_BIAS) && !(p.flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS))) MXL_NT256_LAUNCH(-1);
         else if (p.alpha != 1.f && (p.flags & MXL_GEMM_SAVE_RELU_MASK)) return MXL_EUNSUPPORTED;
         else if (p.flags == MXL_GEMM_BIAS) MXL_NT256_LAUNCH(MXL_GEMM_BIAS);
+        else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_OUT_F32)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_OUT_F32);     // the heads' fp32 logits
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT)) MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT);
         else if (p.flags == (MXL_GEMM_BIAS | MXL_GEMM_RELU | MXL_GEMM_DROPOUT | MXL_GEMM_SAVE_RELU_MASK))
