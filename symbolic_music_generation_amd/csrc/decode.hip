@@ -111,40 +111,69 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     const bf16_t* kb = kc + ((size_t)b * H + h) * M * DH + c8 * 8;     // head-major ring: rows are DH apart
     const bf16_t* vb = vc + ((size_t)b * H + h) * M * DH + c8 * 8;
 
-    // pass 1: scores.  Explicit batches of U key groups: all U loads are issued before any is consumed, so each wave keeps
-    // U KiB in flight (a plain unroll pragma left one load per iteration on the critical path: ~HBM latency per 8 keys).
+    // pass 1: scores.  Explicit batches of U key groups: all U loads of a batch are issued before any is consumed, and batch i + 1
+    // is requested before batch i is consumed (two register sets), so each wave keeps 16-32 KiB in flight the whole pass (a plain
+    // unroll pragma left one load per iteration on the critical path: ~HBM latency per 8 keys; single batches of 16 drained
+    // between batches: 1.31 -> 1.24 ms per full-ring step with the second set and the V prefetch below).
     // The ring rows are read once per step and there are 4.8 GB of them: non-temporal loads, so that they do not push the
     // step's weights, bd and activations out of L2 / MALL (measured over the C5 generation: 51.6 -> 56.2 k tok/s; U 8 -> 16
-    // another +1 %).
-    constexpr int U = 16;
+    // another +1 %).  250 registers: two workgroups per CU; 12 / 16-deep batches held to 168 registers (three per CU) spill and run at
+    // half the speed, 20-deep ones spill too (gpurun_out/r04_decode_db3.log).
+    constexpr int U = 16;                   // double-buffered batches: batch i + 1 is requested before batch i is consumed
     float mx = -1e30f;
-    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW * U) {
-        bf16x8 kvv[U];
-        float bdv[U];
+    {
+        bf16x8 kA[U], kB[U];
+        float bA[U], bB[U];
+        auto load_k = [&](int s0, bf16x8 (&kv)[U], float (&bv)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u * 4 * KPW + ksub;
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                kv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH)) : z;
+                int dist = tm - s;
+                if (dist < 0) dist += M;
+                bv[u] = (s < M && c8 == 0) ? bdrow[dist] : 0.f;
+            }
+        };
+        auto use_k = [&](int s0, const bf16x8 (&kv)[U], const float (&bv)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u * 4 * KPW + ksub;
+                float acc = bv[u];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc += qw[j] * bf2f((bf16_t)kv[u][j]);
+#pragma unroll
+                for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
+                acc *= scale;
+                if (s < M) {
+                    if (c8 == 0) sc[s] = acc;
+                    mx = fmaxf(mx, acc);
+                }
+            }
+        };
+        constexpr int ST = 4 * KPW * U;
+        int s0 = wid * KPW;
+        if (s0 < M) load_k(s0, kA, bA);
+        for (; s0 < M; s0 += 2 * ST) {
+            if (s0 + ST < M) load_k(s0 + ST, kB, bB);
+            use_k(s0, kA, bA);
+            if (s0 + ST < M) {
+                if (s0 + 2 * ST < M) load_k(s0 + 2 * ST, kA, bA);
+                use_k(s0 + ST, kB, bB);
+            }
+        }
+    }
+    // the first V batch is requested before the softmax section: its latency runs under the two barriers and the exponentials
+    bf16x8 vA[U], vB[U];
+    auto load_v = [&](int s0, bf16x8 (&vv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = s0 + u * 4 * KPW + ksub;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            kvv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH)) : z;
-            int dist = tm - s;
-            if (dist < 0) dist += M;
-            bdv[u] = (s < M && c8 == 0) ? bdrow[dist] : 0.f;
+            vv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH)) : z;
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = s0 + u * 4 * KPW + ksub;
-            float acc = bdv[u];
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc += qw[j] * bf2f((bf16_t)kvv[u][j]);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
-            acc *= scale;
-            if (s < M) {
-                if (c8 == 0) sc[s] = acc;
-                mx = fmaxf(mx, acc);
-            }
-        }
-    }
+    };
+    if (wid * KPW < M) load_v(wid * KPW, vA);
     mx = wave_max(mx);
     if (lane == 0) wred[wid] = mx;
     __syncthreads();
@@ -164,20 +193,25 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = 0.f;
-    for (int s0 = wid * KPW; s0 < M; s0 += 4 * KPW * U) {
-        bf16x8 vvv[U];
+    {
+        auto use_v = [&](int s0, const bf16x8 (&vv)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = s0 + u * 4 * KPW + ksub;
-            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            vvv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH)) : z;
-        }
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u * 4 * KPW + ksub;
+                const float pv = (s < M) ? bf2f(f2bf(sc[s])) : 0.f;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = s0 + u * 4 * KPW + ksub;
-            const float pv = (s < M) ? bf2f(f2bf(sc[s])) : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vvv[u][j]);
+                for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vv[u][j]);
+            }
+        };
+        constexpr int ST = 4 * KPW * U;
+        int s0 = wid * KPW;
+        for (; s0 < M; s0 += 2 * ST) {
+            if (s0 + ST < M) load_v(s0 + ST, vB);
+            use_v(s0, vA);
+            if (s0 + ST < M) {
+                if (s0 + 2 * ST < M) load_v(s0 + 2 * ST, vA);
+                use_v(s0 + ST, vB);
+            }
         }
     }
 #pragma unroll
