@@ -238,6 +238,13 @@ int mxl_ln_residual_bwd_colsum(const void* dy, const void* dy2, const void* z, c
 int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                             const float* gamma, const void* dadd, void* dres, float* dgamma, float* dbeta, int N, int d,
                             void* stream);
+/* same, and in the same pass dx = dropout(dres) (mask of (seed, site), element index row * d + column: the mask mxl_dropout_bf16
+ * applies to a compact (N, d) matrix) and, if dxsum != NULL, dxsum[c] += sum_rows dx[row][c] -- what mxl_dropout_bf16 /
+ * mxl_dropout_colsum_bf16 over dres would produce, bit for bit, without the extra pass (the Reformer backward's
+ * y = x + dropout(f(.)) chains: HF modeling_reformer.py:1462-1533 ReformerLayer.backward_pass).  dx may alias dy; d <= 1024 */
+int mxl_ln_residual_bwd_add_drop(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                 const float* gamma, const void* dadd, void* dres, void* dx, float* dxsum, float* dgamma,
+                                 float* dbeta, int N, int d, float drop_p, unsigned long long seed, unsigned site, void* stream);
 /* out[b][t][:] = bf16(x[b][t][:] + bias[:]) with x strided (x_bs, x_rs elements), out compact (B,T,n) */
 int mxl_add_rowbias_bf16(const void* x, long long x_bs, int x_rs, const float* bias, void* out, int B, int T, int n,
                          void* stream);

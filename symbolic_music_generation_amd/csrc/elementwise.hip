@@ -282,11 +282,12 @@ __global__ __launch_bounds__(LNB_THREADS) __attribute__((amdgpu_waves_per_eu(NCH
             const int c = lane + i * 64;
             if (c < chunks) {
                 float o[8], ox[8];
+                const bool drop_sum = dadd && dres && dx;       // dx = dropout(dres as stored): the mask goes on the SUM (mxl_ln_residual_bwd_add_drop)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
                     ox[j] = o[j];
-                    if (thresh) ox[j] = dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
+                    if (thresh && !drop_sum) ox[j] = dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + j, thresh) ? o[j] * dscale : 0.f;
                 }
                 if (dres) {
                     if (dadd) {
@@ -296,6 +297,14 @@ __global__ __launch_bounds__(LNB_THREADS) __attribute__((amdgpu_waves_per_eu(NCH
                     }
                     u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
                     *reinterpret_cast<u32x4*>(dres + (size_t)row * d + c * 8) = ov;
+                    if (drop_sum) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {        // from the rounded values, as a separate dropout pass over dres would read them
+                            const float lo = __uint_as_float(ov[j] << 16), hi = __uint_as_float(ov[j] & 0xffff0000u);
+                            ox[2 * j] = !thresh ? lo : dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + 2 * j, thresh) ? lo * dscale : 0.f;
+                            ox[2 * j + 1] = !thresh ? hi : dropout_keep32(seed, site, (uint32_t)row * d + c * 8 + 2 * j + 1, thresh) ? hi * dscale : 0.f;
+                        }
+                    }
                 }
                 if (dx) {
                     u32x4 ov = {pack2bf(ox[0], ox[1]), pack2bf(ox[2], ox[3]), pack2bf(ox[4], ox[5]), pack2bf(ox[6], ox[7])};
@@ -634,6 +643,26 @@ extern "C" int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const vo
     hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (d <= 1024 ? LNB_THREADS / 64 : 1) * 2 * d * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
                        (bf16_t*)dres, (bf16_t*)nullptr, dgamma, dbeta, N, d, 0u, 1.f, 0ull, 0u, (const bf16_t*)dadd, (float*)nullptr);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+// dres = LayerNorm-backward(dy + dy2) + dadd and, in the same pass, dx = dropout(dres) with the mask of (seed, site) (the element
+// index is row * d + column, as in mxl_dropout_bf16) and, with dxsum, dxsum[c] += column sums of dx: what mxl_ln_residual_bwd_add
+// followed by mxl_dropout_bf16 / mxl_dropout_colsum_bf16 over dres produce, bit for bit.  dx may alias dy (a wave reads its whole
+// row before it writes it).
+extern "C" int mxl_ln_residual_bwd_add_drop(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                                            const float* gamma, const void* dadd, void* dres, void* dx, float* dxsum, float* dgamma,
+                                            float* dbeta, int N, int d, float drop_p, unsigned long long seed, unsigned site,
+                                            void* stream) {
+    MXL_CHECK_ARG(dy && z && mean && rstd && gamma && dadd && dres && dx && dgamma && dbeta && N > 0 && (d % 8) == 0 && d <= 1024);
+    MXL_CHECK_ARG(dres != dx && dres != dy && drop_p > 0.f && drop_p < 1.f && (unsigned long long)N * d <= 0xffffffffull);
+    const auto kfn = dxsum ? (d <= 512 ? ln_res_bwd_kernel<1, true> : ln_res_bwd_kernel<2, true>)
+                           : (d <= 512 ? ln_res_bwd_kernel<1> : ln_res_bwd_kernel<2>);
+    hipLaunchKernelGGL(kfn, dim3((N + LNB_ROWS - 1) / LNB_ROWS), dim3(LNB_THREADS), (LNB_THREADS / 64) * 2 * d * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, mean, rstd, gamma,
+                       (bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, N, d, dropout_thresh(drop_p), 1.f / (1.f - drop_p), seed, site,
+                       (const bf16_t*)dadd, dxsum);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

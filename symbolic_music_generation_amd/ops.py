@@ -208,6 +208,15 @@ def ln_bwd_add(dy, dy2, z, mean, rstd, gamma, dadd, dres, dgamma, dbeta):
                                         _p(dbeta), N, d, _stream()), 'mxl_ln_residual_bwd_add')
 
 
+def ln_bwd_add_drop(dy, dy2, z, mean, rstd, gamma, dadd, dres, dx, dxsum, dgamma, dbeta, p: float, seed: int, site: int):
+    """dres = LayerNorm-backward(dy + dy2) + dadd;  dx = dropout(dres) under (seed, site);  dxsum (optional) += column sums of dx"""
+    d = z.shape[-1]
+    N = z.numel() // d
+    check(lib().mxl_ln_residual_bwd_add_drop(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dadd), _p(dres), _p(dx),
+                                             _p(dxsum), _p(dgamma), _p(dbeta), N, d, float(p), seed, site, _stream()),
+          'mxl_ln_residual_bwd_add_drop')
+
+
 def dropout_colsum(x: torch.Tensor, y: torch.Tensor, out: torch.Tensor, M: int, N: int, p: float, seed: int, site: int):
     """y = dropout(x) (the mask of mxl_dropout_bf16) and out[n] += column sums of y, one pass"""
     check(lib().mxl_dropout_colsum_bf16(_p(x), _p(y), _p(out), M, N, float(p), seed, site, _stream()), 'mxl_dropout_colsum_bf16')

@@ -8,6 +8,7 @@ HF state-dict names, explicit layer loop over libmusicxl kernels, saved activati
     logits = LN_2d(cat(y1, y2)) . Wd^T + b ;  loss = shifted cross-entropy (ignore -100)
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -421,11 +422,18 @@ class RFEngine:
         # ws.hcat now holds d cat; split into the two streams
         ws.g1.copy_(ws.hcat[:, :d]); ws.g2.copy_(ws.hcat[:, d:])
         g1, g2, t1, t2 = ws.g1, ws.g2, ws.t1, ws.t2
+        # the masked copies of g2 / g1 that the two branch inputs need (the forward's dropout masks regenerated) come out of the
+        # LayerNorm backward that forms g2 / g1 -- mxl_ln_residual_bwd_add_drop -- instead of a pass of their own
+        # (MXL_RF_NO_LN_DROP=1: the separate passes, for A/B and the equivalence test)
+        fuse_drop = p > 0 and d <= 1024 and N * d < (1 << 32) and os.environ.get('MXL_RF_NO_LN_DROP') != '1'
+        dff_ready = False
         for l in reversed(range(L)):
             kind = c.attn_layers[l]
             x1, x2, y1 = ws.x1[l], ws.x2[l], ws.x1[l + 1]
             # ---- y2 = x2 + drop(a W2^T + b2)
-            if p > 0:       # the forward's mask regenerated and the bias gradient (column sums of the masked gradient) in one pass
+            if p > 0 and dff_ready:     # t1 = dropout(g2) and its column sums: written by the layer above's last LayerNorm backward
+                dff = t1
+            elif p > 0:     # the forward's mask regenerated and the bias gradient (column sums of the masked gradient) in one pass
                 ops.dropout_colsum(g2, t1, gl(l, 'feed_forward.output.dense.bias'), N, d, p, seed, self._site(l, 3))
                 dff = t1
             else:
@@ -443,11 +451,18 @@ class RFEngine:
                      ksplits=self._ks(Fi, d))
             ops.gemm(ws.dF, self.WT[(l, 'ff1')], t2, N, d, Fi)
             # g1 <- g1 + LN2-backward(t2)            (y1 feeds the FF branch and the y1 output)
-            ops.ln_bwd_add(t2, None, y1, ws.st2[l][0], ws.st2[l][1], self._l(l, 'feed_forward.layer_norm.weight', self.P), g1, t1,
-                           gl(l, 'feed_forward.layer_norm.weight'), gl(l, 'feed_forward.layer_norm.bias'))
+            if fuse_drop:       # ... and t2 (its own input) <- dropout(new g1) under the attention-output site
+                ops.ln_bwd_add_drop(t2, None, y1, ws.st2[l][0], ws.st2[l][1], self._l(l, 'feed_forward.layer_norm.weight', self.P), g1,
+                                    t1, t2, None, gl(l, 'feed_forward.layer_norm.weight'), gl(l, 'feed_forward.layer_norm.bias'),
+                                    p, seed, self._site(l, 1))
+            else:
+                ops.ln_bwd_add(t2, None, y1, ws.st2[l][0], ws.st2[l][1], self._l(l, 'feed_forward.layer_norm.weight', self.P), g1, t1,
+                               gl(l, 'feed_forward.layer_norm.weight'), gl(l, 'feed_forward.layer_norm.bias'))
             g1, t1 = t1, g1
             # ---- y1 = x1 + drop(av Wo^T)
-            if p > 0:
+            if fuse_drop:
+                dao = t2
+            elif p > 0:
                 ops.dropout(g1, t2, p, seed=seed, site=self._site(l, 1))
                 dao = t2
             else:
@@ -485,8 +500,15 @@ class RFEngine:
             dhn = ws.dF.view(-1)[:N * d].view(N, d)
             ops.gemm(dqkv, self.WT[(l, 'proj')], dhn, N, d, nproj * d)
             # g2 <- g2 + LN1-backward(dhn)
-            ops.ln_bwd_add(dhn, None, x2, ws.st1[l][0], ws.st1[l][1], self._l(l, 'attention.layer_norm.weight', self.P), g2, t2,
-                           gl(l, 'attention.layer_norm.weight'), gl(l, 'attention.layer_norm.bias'))
+            if fuse_drop and l > 0:     # ... and t1 <- dropout(new g2) under the NEXT layer's FFN-output site, with that layer's bias gradient
+                ops.ln_bwd_add_drop(dhn, None, x2, ws.st1[l][0], ws.st1[l][1], self._l(l, 'attention.layer_norm.weight', self.P), g2,
+                                    t2, t1, gl(l - 1, 'feed_forward.output.dense.bias'), gl(l, 'attention.layer_norm.weight'),
+                                    gl(l, 'attention.layer_norm.bias'), p, seed, self._site(l - 1, 3))
+                dff_ready = True
+            else:
+                ops.ln_bwd_add(dhn, None, x2, ws.st1[l][0], ws.st1[l][1], self._l(l, 'attention.layer_norm.weight', self.P), g2, t2,
+                               gl(l, 'attention.layer_norm.weight'), gl(l, 'attention.layer_norm.bias'))
+                dff_ready = False
             g2, t2 = t2, g2
             if layer_done is not None:
                 layer_done(l)

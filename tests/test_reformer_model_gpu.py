@@ -93,6 +93,32 @@ def test_train_loop_with_dropout_decreases_loss(dev):
     assert torch.isfinite(torch.tensor(last)) and last < 0.8 * first, (first, last)
 
 
+def test_masked_branch_gradients_from_the_layernorm_backward_equal_the_separate_passes(dev, monkeypatch):
+    """With dropout on, the backward takes dropout(g2) / dropout(g1) (and the FFN-output bias gradient) out of the LayerNorm backward
+    that forms g2 / g1 (mxl_ln_residual_bwd_add_drop); MXL_RF_NO_LN_DROP=1 runs the separate mxl_dropout_bf16 /
+    mxl_dropout_colsum_bf16 passes instead.  Same seed and step: the two backward passes must leave the same gradients.  Only the
+    order of the fp32 atomics of the column sums differs, so the comparison is to float rounding, not to a model tolerance."""
+    from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
+    cfg = MyReformerConfig('debug-large', vocab_size=100, max_position_embeddings=256, axial_pos_shape=(16, 16), num_hashes=1,
+                           attn_layers=['local', 'lsh'] * 2)
+    torch.manual_seed(0)
+    ids = torch.randint(4, 100, (4, 256), device=dev)
+    grads = []
+    for no_fuse in ('0', '1'):
+        monkeypatch.setenv('MXL_RF_NO_LN_DROP', no_fuse)
+        m = MyReformerModelWithLMHead(cfg, device=dev, seed=3).train()
+        assert m.engine.cfg.hidden_dropout_prob > 0
+        m.zero_grad()
+        o = m(input_ids=ids, labels=ids)
+        m.backward()
+        torch.cuda.synchronize()
+        grads.append((o.loss.item(), m.engine.G.clone()))
+    assert grads[0][0] == grads[1][0]
+    a, b = grads[0][1].float(), grads[1][1].float()
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item(), ((a - b).abs().max().item(), a.abs().max().item())
+
+
 def test_single_chunk_forward_vs_hf_golden(dev):
     """T <= chunk length: HF's standard-attention path (no hashing, no look-back) -- the `debug` preset's shape"""
     blob = _load('single_chunk')
