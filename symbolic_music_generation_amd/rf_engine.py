@@ -177,6 +177,14 @@ class RFEngine:
                 if first:
                     self.WT[(l, key)] = torch.empty(i, o, device=self.dev, dtype=torch.bfloat16)
                 ops.transpose(w, self.WT[(l, key)], o, i)
+        nrow_p, d2 = self.layout.head_rows_padded, 2 * self.cfg.hidden_size
+        if 'head' not in self.WT:
+            self.WT['head'] = torch.zeros(d2, self._head_kp(), device=self.dev, dtype=torch.bfloat16)
+        off = self.layout.entries['lm_head.decoder.weight'][0]
+        ops.transpose(self.W[off:off + nrow_p * d2].view(nrow_p, d2), self.WT['head'], nrow_p, d2, ld_dst=self._head_kp())
+
+    def _head_kp(self):
+        return (self.layout.head_rows_padded + 63) // 64 * 64
 
     def state_dict(self):
         return OrderedDict((n, self.p32(n).detach().cpu().clone()) for n in self.layout.real_names())
@@ -240,7 +248,7 @@ class RFEngine:
         ws.hlse = torch.empty(N, 2, **f32)
         ws.acc = torch.zeros(2, **f32)
         if train:
-            ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
+            ws.dlogits = torch.empty(N, self._head_kp(), **bf)       # (row stride = K granule of the large-tile GEMM: see xl_engine)
             ws.dcat = torch.empty(N, 2 * d, **bf)
             ws.g1 = torch.empty(N, d, **bf); ws.g2 = torch.empty(N, d, **bf)
             ws.t1 = torch.empty(N, d, **bf); ws.t2 = torch.empty(N, d, **bf)
@@ -414,7 +422,7 @@ class RFEngine:
         g_head = G[off:off + nrow_p * 2 * d].view(nrow_p, 2 * d)
         ops.colsum(ws.dlogits, self.g32('lm_head.bias'), N, V)
         ops.gemm(ws.dlogits, ws.hid, g_head, nrow_p, 2 * d, N, trans_a=True, trans_b=True, flags=AT, ksplits=self._ks(nrow_p, 2 * d))
-        ops.gemm(ws.dlogits, head_w, ws.dcat, N, 2 * d, nrow_p, trans_b=True)
+        ops.gemm(ws.dlogits, self.WT['head'], ws.dcat, N, 2 * d, self._head_kp())
         if p > 0:
             ops.dropout(ws.dcat, ws.dcat, p, seed=seed, site=self.SITE_FINAL)
         ops.ln_residual_bwd(ws.dcat, None, ws.cat, ws.stf[0], ws.stf[1], self.p32('reformer.encoder.layer_norm.weight'),

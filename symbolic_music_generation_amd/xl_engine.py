@@ -165,9 +165,17 @@ class XLEngine:
             stride = (self.layout.entries[f'transformer.layers.1.{kind}'][0] - off0) if L > 1 else 0
             assert all(self.layout.entries[f'transformer.layers.{l}.{kind}'][0] == off0 + l * stride for l in range(L))
             ops.transpose(self.W[off0:], self.WT[kind], o, i, batch=L, src_bstride=stride, dst_bstride=i * o)
+        if not self.bucketed_head:       # the head's rows as [in][out], zero beyond the last row (K of the input-gradient product)
+            nrow_p, d = self.layout.head_rows_padded, self.cfg.d_model
+            if 'head' not in self.WT:
+                self.WT['head'] = torch.zeros(d, self._head_kp(), device=self.dev, dtype=torch.bfloat16)
+            ops.transpose(self.W[:nrow_p * d].view(nrow_p, d), self.WT['head'], nrow_p, d, ld_dst=self._head_kp())
 
     def _lwt(self, l, kind):
         return self.WT[kind][l]
+
+    def _head_kp(self):
+        return (self.layout.head_rows_padded + 63) // 64 * 64
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         sd = OrderedDict()
@@ -259,8 +267,10 @@ class XLEngine:
             ws.d_rd16 = torch.empty(M, d, **bf)
             ws.phi_c = torch.empty(M, d, **bf)
             if not self.bucketed_head:
-                ws.dlogits = torch.empty(N, self.layout.head_rows_padded, **bf)
-                ws.dlogits_lo = torch.empty(N, self.layout.head_rows_padded, **bf)
+                # row stride rounded up to the K granule of the large-tile GEMM (the pad columns are written as zeros by
+                # mxl_adaptive_nll_bwd*): the input gradient dlogits . W is then an NT product against the [in][out] head copy
+                ws.dlogits = torch.empty(N, self._head_kp(), **bf)
+                ws.dlogits_lo = torch.empty(N, self._head_kp(), **bf)
         ws.logits = torch.empty(N, self.layout.head_rows_padded, **f32) if not self.bucketed_head else None
         ws.nll = torch.empty(B, max(T - 1, 1), **f32)
         ws.hlse = torch.empty(N, 2, **f32)
@@ -579,8 +589,8 @@ class XLEngine:
                 ops.colsum(term, G[boff:boff + nrow], N, nrow)
                 ops.gemm(term, ws.hid, g_head_w, nrow_p, d, N, trans_a=True, trans_b=True, flags=AT,
                          ksplits=self._ks(nrow_p, d, N))
-            ops.gemm(ws.dlogits_lo, head_w, dy, N, d, nrow_p, trans_b=True)
-            ops.gemm(ws.dlogits, head_w, dy, N, d, nrow_p, trans_b=True, flags=F.GEMM_ADD_AUX, aux=dy)
+            ops.gemm(ws.dlogits_lo, self.WT['head'], dy, N, d, self._head_kp())
+            ops.gemm(ws.dlogits, self.WT['head'], dy, N, d, self._head_kp(), flags=F.GEMM_ADD_AUX, aux=dy)
         if p > 0:
             ops.dropout(dy, dy, p, seed=seed, site=self.SITE_FINAL)
         st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d,

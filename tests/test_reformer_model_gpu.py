@@ -97,7 +97,7 @@ def test_masked_branch_gradients_from_the_layernorm_backward_equal_the_separate_
     """With dropout on, the backward takes dropout(g2) / dropout(g1) (and the FFN-output bias gradient) out of the LayerNorm backward
     that forms g2 / g1 (mxl_ln_residual_bwd_add_drop); MXL_RF_NO_LN_DROP=1 runs the separate mxl_dropout_bf16 /
     mxl_dropout_colsum_bf16 passes instead.  Same seed and step: the two backward passes must leave the same gradients.  Only the
-    order of the fp32 atomics of the column sums differs, so the comparison is to float rounding, not to a model tolerance."""
+    order of fp32 atomic additions differs, so the comparison is to float rounding, not to a model tolerance."""
     from symbolic_music_generation_amd.reformer import MyReformerConfig, MyReformerModelWithLMHead
     cfg = MyReformerConfig('debug-large', vocab_size=100, max_position_embeddings=256, axial_pos_shape=(16, 16), num_hashes=1,
                            attn_layers=['local', 'lsh'] * 2)
@@ -113,10 +113,13 @@ def test_masked_branch_gradients_from_the_layernorm_backward_equal_the_separate_
         m.backward()
         torch.cuda.synchronize()
         grads.append((o.loss.item(), m.engine.G.clone()))
-    assert grads[0][0] == grads[1][0]
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])       # (the loss is an atomic sum: last-bit differences run to run)
     a, b = grads[0][1].float(), grads[1][1].float()
     assert torch.isfinite(a).all() and a.abs().max() > 0
+    # (fp32 atomics land in a different order from run to run: a wrong mask or site would be an O(1) difference, not 1e-4)
+    # measured: 1e-7 of the gradient norm, the same as two runs of either path against each other
     assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item(), ((a - b).abs().max().item(), a.abs().max().item())
+    assert ((a - b).norm() / a.norm()).item() < 1e-5
 
 
 def test_single_chunk_forward_vs_hf_golden(dev):
