@@ -144,6 +144,19 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
                 const uint32_t i0 = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
                 const uint32_t mix = mxl_hash32((uint32_t)p.seed ^ (p.site * 0x9E3779B9U)) + (uint32_t)(p.seed >> 32);
                 const uint32_t h0 = i0 * 0x9E3779B1U;
+                if (flags & MXL_GEMM_RELU) {
+                    // relu + dropout = the FFN's hidden activations: nobody regenerates this mask (the backward reads it from the saved
+                    // bits, or from the zeros of the activations themselves), so it need not be dropout_keep's -- one hash per PAIR of
+                    // elements of the quad, a 16-bit decision each (drop probability quantised to 2^-16): 5 quarter-rate multiplies
+                    // per quad instead of 9
+                    const uint32_t t16 = p.thresh >> 16;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t h = mxl_hash32((h0 + (uint32_t)(2 * k) * 0x9E3779B1U) ^ mix);
+                        v[2 * k] = ((h & 0xffffu) >= t16) ? v[2 * k] * p.drop_scale : 0.f;
+                        v[2 * k + 1] = ((h >> 16) >= t16) ? v[2 * k + 1] * p.drop_scale : 0.f;
+                    }
+                } else
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     v[r] = (mxl_hash32((h0 + (uint32_t)r * 0x9E3779B1U) ^ mix) >= p.thresh) ? v[r] * p.drop_scale : 0.f;
