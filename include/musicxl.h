@@ -241,7 +241,8 @@ int mxl_ln_residual_bwd_add(const void* dy, const void* dy2, const void* z, cons
 /* same, and in the same pass dx = dropout(dres) (mask of (seed, site), element index row * d + column: the mask mxl_dropout_bf16
  * applies to a compact (N, d) matrix) and, if dxsum != NULL, dxsum[c] += sum_rows dx[row][c] -- what mxl_dropout_bf16 /
  * mxl_dropout_colsum_bf16 over dres would produce, bit for bit, without the extra pass (the Reformer backward's
- * y = x + dropout(f(.)) chains: HF modeling_reformer.py:1462-1533 ReformerLayer.backward_pass).  dx may alias dy; d <= 1024 */
+ * y = x + dropout(f(.)) chains of HF ReformerLayer / _ReversibleFunction, modeling_reformer.py:1535-1757 as cited in SURVEY.md;
+ * here with stored activations instead of the reversible recompute).  dx may alias dy; d <= 1024 */
 int mxl_ln_residual_bwd_add_drop(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                                  const float* gamma, const void* dadd, void* dres, void* dx, float* dxsum, float* dgamma,
                                  float* dbeta, int N, int d, float drop_p, unsigned long long seed, unsigned site, void* stream);
