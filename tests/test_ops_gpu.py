@@ -587,6 +587,41 @@ def test_ln_residual_bwd_with_fused_column_sums(dev, N, d, p):
     assert (a[4] - want).abs().max().item() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize('N,d,alias', [(4096, 512, False), (3001, 512, True), (1000, 1024, True)])
+def test_ln_residual_bwd_add_with_fused_dropout_of_the_sum(dev, N, d, alias):
+    """mxl_ln_residual_bwd_add_drop == mxl_ln_residual_bwd_add, then mxl_dropout_bf16 (or mxl_dropout_colsum_bf16) over its output:
+    dres and dx bit for bit (dx may be the dy buffer itself), the column sums and dgamma / dbeta up to the order of fp32 additions"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(22)
+    p, seed, site = 0.1, 1234567, 9
+    dy = torch.randn(N, d, device=dev).bfloat16()
+    z = (torch.randn(N, d, device=dev) * 1.5 + 0.2).bfloat16()
+    dadd = torch.randn(N, d, device=dev).bfloat16()
+    mean = z.float().mean(-1); rstd = (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+    gamma = torch.rand(d, device=dev) + 0.5
+    # separate passes
+    dres0 = torch.empty_like(z); dx0 = torch.empty_like(z); dx0b = torch.empty_like(z)
+    dg0 = torch.zeros(d, device=dev); db0 = torch.zeros(d, device=dev); cs0 = torch.full((d,), 2.0, device=dev)
+    ops.ln_bwd_add(dy, None, z, mean, rstd, gamma, dadd, dres0, dg0, db0)
+    ops.dropout(dres0, dx0, p, seed=seed, site=site)
+    ops.dropout_colsum(dres0, dx0b, cs0, N, d, p, seed, site)
+    assert torch.equal(dx0, dx0b)
+    # one pass, with and without the column sums
+    for with_sums in (False, True):
+        dyb = dy.clone()
+        dres1 = torch.empty_like(z); dx1 = dyb if alias else torch.empty_like(z)
+        dg1 = torch.zeros(d, device=dev); db1 = torch.zeros(d, device=dev); cs1 = torch.full((d,), 2.0, device=dev)
+        ops.ln_bwd_add_drop(dyb, None, z, mean, rstd, gamma, dadd, dres1, dx1, cs1 if with_sums else None, dg1, db1, p, seed, site)
+        assert torch.equal(dres1, dres0) and torch.equal(dx1, dx0)
+        assert (dg1 - dg0).abs().max().item() <= 1e-3 * dg0.abs().max().item()
+        assert (db1 - db0).abs().max().item() <= 1e-3 * db0.abs().max().item()
+        if with_sums:
+            scale = dx0.float().abs().sum(0).max().item()
+            assert (cs1 - cs0).abs().max().item() <= 1e-5 * scale
+    frac = (dx0 == 0).float().mean().item()
+    assert 0.08 < frac < 0.12
+
+
 @pytest.mark.parametrize('M,N,K', [(2048, 3072, 768), (1024, 512, 256), (1000, 3072, 768)])
 def test_gemm_relu_bwd_with_fused_column_sums(dev, M, N, K):
     """mxl_gemm_bf16_colsum with MXL_GEMM_RELU_BWD (dF = mask(dD W) and, in the same launch, the bias gradient colsum(dF)): the
