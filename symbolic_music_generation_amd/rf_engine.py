@@ -171,12 +171,31 @@ class RFEngine:
         first = self.WT is None
         if first:
             self.WT = {}
-        for l in range(len(self.cfg.attn_layers)):
-            for key, w in self._wt_sources(l).items():
-                o, i = w.shape
-                if first:
-                    self.WT[(l, key)] = torch.empty(i, o, device=self.dev, dtype=torch.bfloat16)
-                ops.transpose(w, self.WT[(l, key)], o, i)
+            self._wt_groups = []
+            # layers whose copy of one weight has the same shape and sits at a constant stride in the flat buffer (every other layer
+            # when local and LSH layers alternate) are transposed by ONE batched launch: 8 launches per step instead of 24 at C4
+            L = len(self.cfg.attn_layers)
+            srcs = [self._wt_sources(l) for l in range(L)]
+            base = self.W.data_ptr()
+            for key in srcs[0]:
+                by_shape: Dict = {}
+                for l in range(L):
+                    by_shape.setdefault(tuple(srcs[l][key].shape), []).append(l)
+                for (o, i), layers in by_shape.items():
+                    offs = [(srcs[l][key].data_ptr() - base) // 2 for l in layers]
+                    stride = offs[1] - offs[0] if len(layers) > 1 else 0
+                    if len(layers) > 1 and all(offs[j + 1] - offs[j] == stride for j in range(len(layers) - 1)) and stride > 0:
+                        runs = [layers]
+                    else:
+                        runs, stride = [[l] for l in layers], 0
+                    for run in runs:
+                        stack = torch.empty(len(run), i, o, device=self.dev, dtype=torch.bfloat16)
+                        for j, l in enumerate(run):
+                            self.WT[(l, key)] = stack[j]
+                        self._wt_groups.append((key, run[0], stack, o, i, len(run), stride))
+        for key, l0, stack, o, i, n, stride in self._wt_groups:
+            w = self._wt_sources(l0)[key]
+            ops.transpose(w, stack, o, i, batch=n, src_bstride=stride, dst_bstride=i * o)
         nrow_p, d2 = self.layout.head_rows_padded, 2 * self.cfg.hidden_size
         if 'head' not in self.WT:
             self.WT['head'] = torch.zeros(d2, self._head_kp(), device=self.dev, dtype=torch.bfloat16)
