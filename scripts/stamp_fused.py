@@ -34,10 +34,10 @@ for it in range(3):
                           d_rd, a, c, ws, qr, dq_bs=Kc*3*d, dq_rs=3*d, dkv_bs=Kc*3*d, dkv_rs=3*d, oph=oph, mph=mph, **st)
 torch.cuda.synchronize()
 raw.mxl_debug_fused_stamps(buf)
-names = ['0 tile top: next tile loads issued', '1 C init + S / dP chains', '2 skew read (G) + wait', '3 exp, dS, pack, X / Y writes',
-         '4 dV / dK MFMAs (or zero writes)', '5 store next Q set / Rd block (vmcnt wait)', '6 barrier 1', '7 dq piece: key steps',
-         '8 dq piece: distance steps', '9 slab store', '10 dRd block (+ flush)', '11 next tile G blocks', '12 barrier 2', '13 final flush',
-         '14 -', '15 prologue']
+names = ['0 tile top: stage next rows, request the rows after, park read', '1 S / dP chains issued, skew reads issued', '2 wait for chains + skew reads',
+         '3 exp, dS, pack, tr fragments requested, X / Y writes, parked atomics', '4 barrier 1', '5 first units requested + dV / dK MFMAs',
+         '6 dq piece: 17 pipelined units', '7 next G operands requested + slab stores', '8 dRd block MFMAs', '9 next tile G block(s)',
+         '10 dRd park (one wave per tile) + new block', '11 -', '12 barrier 2', '13 final flush', '14 wait for the staged rows (vmcnt)', '15 prologue']
 tot = sum(buf)
 print(f'relattn_bwd_fused_kernel stamps, B={B} T={T} M={M} Kc={Kc}')
 for i, n in enumerate(names):

@@ -45,8 +45,25 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#ifndef MXL_FUSED_NSUB_DEFAULT
-#define MXL_FUSED_NSUB_DEFAULT 1
+// ---- compile-time knobs of the fused kernel (A/B builds: scripts/ab_build.sh relattn_bwd_fused <tag> -D...)
+#ifndef FUSED_PF
+#define FUSED_PF 3                              // phase B: units of operand reads in flight ahead of the MFMA that consumes them
+#endif
+#ifndef FUSED_VF_RELOAD
+#define FUSED_VF_RELOAD 0
+#endif
+#ifndef FUSED_PARK
+#define FUSED_PARK 0                            // the leaving dRd block through an LDS park buffer (1) or straight from each wave's registers (0)
+#endif
+#ifndef FUSED_SB
+#define FUSED_SB 1                              // scheduling fences between the units of phase B
+#endif
+#define UNIT_FENCE() do { if (FUSED_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef FUSED_DVDK_LATE
+#define FUSED_DVDK_LATE 1                       // dV / dK MFMAs behind barrier 1 (1) or in front of it, as in round 4 (0)
+#endif
+#ifndef FUSED_TRF_EARLY
+#define FUSED_TRF_EARLY 1                       // transposed dO / Qw fragments requested ahead of barrier 1 (1) or behind it (0)
 #endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KBLK = 256;                       // keys per workgroup
@@ -61,10 +78,13 @@ constexpr int QSET = 3 * QIMG + 2 * QT * 4;     // Qw, Qr, dO images + -lse (log
 constexpr int GP = 584;                         // fp16 skew buffer pitch (bytes): 288 columns + pad; 146 dwords = 2 mod 16
 constexpr int G_BYTES = QT * GP;
 constexpr int X_BYTES = KBLK * 64;              // X[key][32 queries] bf16
-constexpr int YP = 592;                         // Y[query][288 columns + pad] bf16: 148 dwords = 20 mod 64 (16-byte row reads conflict-free)
+constexpr int YP = 608;                         // Y[query][288 columns + pad] bf16: 152 dwords = 24 mod 64: the 16-byte row reads of the dq piece
+                                                // (lane groups {0-3, 12-15, 20-27} ..: MI355X_MICROARCH.md, LDS) are conflict-free; at 592
+                                                // (rounds 4) each was a two-way conflict (scripts/lds_conflicts.py)
 constexpr int Y_BYTES = QT * YP;
 constexpr int BIAS_BYTES = 2 * 64 * 4;
-constexpr int SMEM = K_BYTES + RING_BYTES + 2 * QSET + G_BYTES + X_BYTES + Y_BYTES + BIAS_BYTES;   // 153 344 B: one workgroup per CU
+constexpr int PARK_BYTES = FUSED_PARK ? 32 * 64 * 4 : 0;   // (FUSED_PARK) the dRd block that left the window in the previous tile: [32 distances][64] fp32
+constexpr int SMEM = K_BYTES + RING_BYTES + 2 * QSET + G_BYTES + X_BYTES + Y_BYTES + BIAS_BYTES + PARK_BYTES;   // 153 856 B (+ 8 KB with FUSED_PARK): one workgroup per CU
 constexpr int RING_OFF = 10240;                 // multiple of RING_BLKS added to (possibly negative) block indices before the modulo
 
 // In-kernel stamps (diagnostic builds only: scripts/ab_build.sh relattn_bwd_fused stamp -DMXL_STAMP; the shipped library has none).
@@ -106,8 +126,13 @@ struct FusedP {
     float scale, scale_log2e;
 };
 
-// Q-set images: [32][64] bf16, 16-byte chunk c of row at (c ^ ((row >> 1) & 7)) -- the layout of relattn_bwd.hip's key-owner kernel
-__device__ __forceinline__ int qoff(int row, int ch) { return row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4); }
+// Q-set images: [32][64] bf16, 16-byte chunk c of row at c ^ qswz(row), qswz = (bit 1, bit 2, bit 3) of the row index as chunk bits
+// (2, 1, 0) -- the image of the phantom-cell dRd kernel's records (relattn_drd_phantom.hip, ph_swz).  Row reads (32x32x16 A operand:
+// ds_read_b128 lane groups of 16 rows) cover the 64 banks once, and so does each 32-lane half of the transposed reads (4 rows x 64
+// bytes: rows q, q + 2 land in different 64-byte halves).  Until round 5 the swizzle was (row >> 1) & 7, under which every
+// transposed read of these images was a two-way bank conflict (scripts/lds_conflicts.py; 24 of them per wave and tile).
+__device__ __forceinline__ int qswz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int qoff(int row, int ch) { return row * ROWB + ((ch ^ qswz(row)) << 4); }
 __device__ __forceinline__ int qeoff(int row, int e) { return qoff(row, e >> 3) + ((e & 7) << 1); }
 // K image and Rd ring: chunk c of a row at c ^ s(row), s = (bit 3, bit 1, bit 2) of the row index.  A bijection of bits 1..3, so
 // 16-byte row reads by 16 different rows hit 64 different banks; and for the transposed 8-byte reads of a 16x16x32 B fragment
@@ -149,16 +174,16 @@ __device__ __forceinline__ void gskew_read16(uint32_t base, uint32_t (&u)[16]) {
 }
 // the mirror image for dS into Y: w[m] holds (value 2m, value 2m + 1) as a bf16 pair; lane base + pat(j) * (YP + 2)
 __device__ __forceinline__ void yskew_write16(uint32_t base, const uint32_t (&w)[8]) {
-    static_assert(YP == 592, "offsets below are pat(j) * (YP + 2)");
+    static_assert(YP == 608, "offsets below are pat(j) * (YP + 2)");
     asm volatile(
-        "ds_write_b16 %8, %0\n\t"               "ds_write_b16_d16_hi %8, %0 offset:594\n\t"
-        "ds_write_b16 %8, %1 offset:1188\n\t"   "ds_write_b16_d16_hi %8, %1 offset:1782\n\t"
-        "ds_write_b16 %8, %2 offset:4752\n\t"   "ds_write_b16_d16_hi %8, %2 offset:5346\n\t"
-        "ds_write_b16 %8, %3 offset:5940\n\t"   "ds_write_b16_d16_hi %8, %3 offset:6534\n\t"
-        "ds_write_b16 %8, %4 offset:9504\n\t"   "ds_write_b16_d16_hi %8, %4 offset:10098\n\t"
-        "ds_write_b16 %8, %5 offset:10692\n\t"  "ds_write_b16_d16_hi %8, %5 offset:11286\n\t"
-        "ds_write_b16 %8, %6 offset:14256\n\t"  "ds_write_b16_d16_hi %8, %6 offset:14850\n\t"
-        "ds_write_b16 %8, %7 offset:15444\n\t"  "ds_write_b16_d16_hi %8, %7 offset:16038"
+        "ds_write_b16 %8, %0\n\t"               "ds_write_b16_d16_hi %8, %0 offset:610\n\t"
+        "ds_write_b16 %8, %1 offset:1220\n\t"   "ds_write_b16_d16_hi %8, %1 offset:1830\n\t"
+        "ds_write_b16 %8, %2 offset:4880\n\t"   "ds_write_b16_d16_hi %8, %2 offset:5490\n\t"
+        "ds_write_b16 %8, %3 offset:6100\n\t"   "ds_write_b16_d16_hi %8, %3 offset:6710\n\t"
+        "ds_write_b16 %8, %4 offset:9760\n\t"   "ds_write_b16_d16_hi %8, %4 offset:10370\n\t"
+        "ds_write_b16 %8, %5 offset:10980\n\t"   "ds_write_b16_d16_hi %8, %5 offset:11590\n\t"
+        "ds_write_b16 %8, %6 offset:14640\n\t"   "ds_write_b16_d16_hi %8, %6 offset:15250\n\t"
+        "ds_write_b16 %8, %7 offset:15860\n\t"   "ds_write_b16_d16_hi %8, %7 offset:16470"
         :
         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(base)
         : "memory");
@@ -179,6 +204,17 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
+
+// Vector-memory traffic of the tile loop and hipcc's s_waitcnt pass.  The vmcnt counter is in order, and hipcc places the wait for
+// the rows staged a tile ahead from what it can PROVE is younger than them on every path.  Until round 5 one wave per tile issued the
+// 32 float atomics of the dRd block that left the window, the staging loads sat behind `if` conditions, and the loop was entered
+// with the first rows just requested: the wait came out as s_waitcnt vmcnt(0) at the top of every tile -- a drain of the tile's slab
+// stores and, on the wave that had just flushed, of 32 atomics (~3 k cycles each with every CU adding), the other seven waves
+// waiting at barrier 1: 0.5 ms of the 4.0 ms kernel (ablation: profiles/r05_fused_bwd_notes.txt).  Now every wave issues the same
+// operations on every path of the loop -- its staging loads, four atomics of the block parked in LDS, two slab stores -- also on the
+// last tiles (clamped tile index, stores into the image nobody reads any more) and in front of the loop (VM_PER_TILE dummy
+// atomics of 0.0), so the wait hipcc computes leaves the younger six in flight.
+constexpr int VM_PER_TILE = 6;                  // vector-memory operations a wave issues per tile behind its staging loads: 4 atomics + 2 slab stores
 
 // delta[b,h,i] = sum_e dO[b,i,h,e] * O[b,i,h,e]   (dh = 64: 8 lanes per head, one wave per token row per sweep of 8 heads)
 __global__ __launch_bounds__(256) void fused_delta_kernel(const bf16_t* o, const bf16_t* dout, float* delta, int B, int T, int H,
@@ -204,17 +240,23 @@ __global__ __launch_bounds__(256) void fused_delta_kernel(const bf16_t* o, const
     }
 }
 
-// Four waves (one per SIMD, the whole 512-register file each), wave w = keys 64w .. 64w + 63 as two 32-key sub-blocks.  At 8 waves x
-// 32 keys (256 registers) the first version spilled and every phase was a serial LDS -> wait -> MFMA chain (12.7 k cycles per
-// tile for 1.1 k of MFMA per wave, profiles/r04_fused_stamp_anatomy.txt): with two sub-blocks a wave has four independent score
-// chains, every LDS operand read (query rows, transposed query / dO fragments, K / Rd fragments of the dq piece) feeds two MFMAs,
-// and the scheduler has the registers to run the reads of one product under the MFMAs of another.
-// NSUB = 32-key sub-blocks per wave: 2 -> four waves x 64 keys (one wave per SIMD, 512 registers), 1 -> eight waves x 32 keys (two waves
-// per SIMD, 256 registers).
-template <int NSUB>
-__global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP p) {
-    constexpr int NW = 8 / NSUB, NT = 64 * NW;       // waves, threads
-    constexpr int NIH = NSUB;                        // 16-row halves of the dq piece a wave forms (all 32 queries at four waves)
+// Eight waves, two per SIMD, 256 registers each: wave w = keys 32 w .. 32 w + 31.  (Round 4 also carried a four-wave form -- one wave
+// per SIMD, 512 registers, 64 keys per wave: 5.07 ms against 4.08 ms with every refinement applied, profiles/r04_experiments_not_kept.txt
+// -- one wave per SIMD exposes every LDS round trip.  Removed in round 5.)
+//
+// A tile (round 5 order):
+//   top      the rows of tile it + 1 (requested a tile ago) go into their LDS images, the rows of tile it + 2 are requested
+//   phase A  S and dP chains (8 MFMAs), exponentials, dS -> X / Y; the transposed dO / Qw fragments of the dV / dK products are requested
+//   barrier 1
+//   phase B  one software-pipelined stream of (operand reads -> MFMA) units, three units of reads in flight ahead of the MFMA that
+//            consumes them: the first three units' reads, then the eight dV / dK MFMAs (operands in registers since phase A: they fill
+//            the LDS latency behind the barrier), the 8 key units and 9 distance units of the dq piece, the slab stores, the dRd
+//            block, the next tile's G block(s)
+//   barrier 2
+// Until round 5 phase B was three rounds "all reads of the round, wait, all MFMAs of the round" (256 registers hold one round), each
+// of which exposed a full LDS round trip with all eight waves reading at once, and dV / dK sat in front of barrier 1.
+__global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
+    constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sR = sK + K_BYTES;
@@ -223,6 +265,7 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     char* sX = sG + G_BYTES;
     char* sY = sX + X_BYTES;
     float* sBias = reinterpret_cast<float*>(sY + Y_BYTES);       // r_w_bias[64], r_r_bias[64] of this head
+    float* sPark = sBias + BIAS_BYTES / 4;                       // the parked dRd block
 
     STAMP_DECL
     const int tid = threadIdx.x;
@@ -233,8 +276,8 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     const int T = p.T, M = p.M;
     const int p0 = T - p.Kc;                    // lowest stored key position (a multiple of 32)
     const int P0 = p0 + KBLK * bx_;             // first key position of the workgroup
-    const int Pw = P0 + 32 * NSUB * w;          // first key position of the wave (sub-block kb: + 32 kb)
-    const int kloc0 = 32 * NSUB * w + r;        // this lane's key inside the workgroup, sub-block 0 (sub-block 1: + 32)
+    const int Pw = P0 + 32 * w;                 // first key position of the wave
+    const int kloc0 = 32 * w + r;               // this lane's key inside the workgroup
     const int MB = M >> 5;
 
     const bf16_t* qbase = p.q + (size_t)b * p.q_bs + (size_t)h * 64;
@@ -245,29 +288,34 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
 
     // ---- lane constants.  gq / q4 / pp: the decomposition the transposed 8-byte reads use (16 lanes read 4 rows x 16 columns)
     const int gq = l >> 4, q4 = (l & 15) >> 2, pp = l & 3;
-    const int rowq = qoff(r, hh);                                  // Q-set row fragment, k-step ks: rowq ^ (ks << 5)
-    const int rows = r * ROWB + ((hh ^ sswz(r)) << 4);             // ring row fragment,   k-step ks: rows ^ (ks << 5)
-    const int tk0 = qeoff(4 * hh + q4, 16 * (gq & 1) + 4 * pp);    // Q-set transposed pattern (relattn_bwd.hip, tk0)
-    // skew buffers: sub-block kb sits 32 keys higher = 32 columns lower = 64 bytes lower
+    int rowq = qoff(r, hh);                                  // Q-set row fragment, k-step ks: rowq ^ (ks << 5)
+    int rows = r * ROWB + ((hh ^ sswz(r)) << 4);             // ring row fragment,   k-step ks: rows ^ (ks << 5)
+    // Q-set transposed pattern: rows 4 hh + q4 (+ 8: chunk bit 0 flips, + 16: nothing), elements 16 (gq & 1) + 4 pp .. + 3 (+ 32 e: chunk bit 2 flips)
+    int tkb = qeoff(4 * hh + q4, 16 * (gq & 1) + 4 * pp);
+    // skew buffers
     const uint32_t gRb = lds_addr(sG) + 4 * hh * (GP + 2) + (256 - kloc0) * 2;
     const uint32_t yWb = lds_addr(sY) + 4 * hh * (YP + 2) + (256 - kloc0) * 2;
-    // X[key][query]: 8-byte granule g of row p at g ^ ((p >> 1) & 7): this lane's group `grp` (queries 8 grp + 4 hh ..) at xw ^ (grp << 4);
-    // sub-block 1 is 32 rows further ((p >> 1) & 7 is the same: 32 rows = 16 steps of it)
+    // X[key][query]: 8-byte granule g of row p at g ^ ((p >> 1) & 7): this lane's group `grp` (queries 8 grp + 4 hh ..) at xw ^ (grp << 4)
     const int xf = (kloc0 >> 1) & 7;
-    const int xw = kloc0 * 64 + ((((hh ^ (xf & 1)) | (xf & 6))) << 3);
-    const int ya0 = (4 * hh + q4) * YP + (16 * (gq & 1) + 4 * pp) * 2;          // Y transposed pattern (32x32x16 A fragment of dRd)
-    // dq piece of this wave: elements 16 eq .. 16 eq + 15 of the 16-row halves ih0 .. ih0 + NIH - 1 of the tile's queries
-    const int eq = NSUB == 2 ? w : (w >> 1), ih0 = NSUB == 2 ? 0 : (w & 1);
+    int xw = kloc0 * 64 + ((((hh ^ (xf & 1)) | (xf & 6))) << 3);
+    // dRd operands (16x16x32, this wave's slice: distances 16 (w & 1) .. + 15 of a block, elements 16 (w >> 1) .. + 15): transposed reads
+    // with the contraction index (the query) permuted -- lane group g reads image rows 4 g .. 4 g + 3 and 16 + 4 g .. 19 + 4 g, in Y and
+    // in the Qr image alike -- so that the eight rows a 32-lane half touches are consecutive (conflict-free at this pitch)
+    int yt0 = (4 * (l >> 4) + ((l & 15) >> 2)) * YP + (16 * (w & 1) + 4 * pp) * 2;       // second read: + 16 YP; block v: + 64 v
+    int qb0 = qeoff(4 * (l >> 4) + ((l & 15) >> 2), 16 * (w >> 1) + 4 * pp);             // second read: + 2048 (sixteen rows on)
+    // dq piece of this wave: elements 16 eq .. 16 eq + 15 of the 16-row half ih0 of the tile's queries
+    const int eq = w >> 1, ih0 = w & 1;
     const int g16 = l >> 4, q16 = (l & 15) >> 2;                   // 16x16x32 transposed pattern: rows 8 g16 + q16 (+4), 4 columns at 4 pp
-    const int xa0 = ((8 * g16 + q16) * 64 + ((pp ^ ((4 * g16 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);          // next half: ^ 32
-    const int xa1 = ((8 * g16 + q16 + 4) * 64 + ((pp ^ ((4 * g16 + 2 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);
+    int xa0 = ((8 * g16 + q16) * 64 + ((pp ^ ((4 * g16 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);
+    int xa1 = ((8 * g16 + q16 + 4) * 64 + ((pp ^ ((4 * g16 + 2 + (q16 >> 1)) & 7)) << 3)) ^ (ih0 << 5);
     const int kch = 2 * eq + (pp >> 1);
     const int ksw = ((g16 & 1) << 2) | (((q16 >> 1) & 1) << 1);
-    const int ka0 = (8 * g16 + q16) * ROWB + ((kch ^ ksw) << 4) + ((pp & 1) << 3);
-    const int ka1 = (8 * g16 + q16 + 4) * ROWB + ((kch ^ (ksw | 1)) << 4) + ((pp & 1) << 3);
-    const int yq0 = (16 * ih0 + (l & 15)) * YP + 16 * g16;         // Y row fragment (16x16x32 A): row = query (next half: + 16 YP)
+    int ka0 = (8 * g16 + q16) * ROWB + ((kch ^ ksw) << 4) + ((pp & 1) << 3);
+    int ka1 = (8 * g16 + q16 + 4) * ROWB + ((kch ^ (ksw | 1)) << 4) + ((pp & 1) << 3);
+    int yq0 = (16 * ih0 + (l & 15)) * YP + 16 * g16;         // Y row fragment (16x16x32 A): row = query
+    int krow = kloc0 * ROWB + ((hh ^ sswz(kloc0)) << 4);           // K image row fragment of the lane's key (B operand of S), k-step ks: krow ^ (ks << 5)
 
-    // ---- prologue: biases, K image, Y zeroed, K / V fragments (B operands: lane = key, k = 16 ks + 8 hh + j)
+    // ---- prologue: biases, K image, Y zeroed, V fragments (B operand of dP: lane = key, k = 16 ks + 8 hh + j)
     if (tid < 128) sBias[tid] = (tid < 64) ? p.rwb[h * 64 + tid] : p.rrb[h * 64 + tid - 64];
 #pragma unroll
     for (int n = 0; n < 2048 / NT; n++) {
@@ -279,21 +327,16 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         *reinterpret_cast<u32x4*>(sK + soff(row, ch)) = val;
     }
     for (int i = tid; i < Y_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(sY)[i] = u32x4{0u, 0u, 0u, 0u};
-    bf16x8 kf[NSUB][4], vf[NSUB][4];
-    bool kok[NSUB];
-#pragma unroll
-    for (int kb = 0; kb < NSUB; kb++) {
-        const int pk = Pw + 32 * kb + r;
-        kok[kb] = pk < T;
-        const size_t srow = (size_t)(kok[kb] ? pk - p0 : 0);
-        const bf16_t* kp = kbase + srow * p.kv_rs;
+    bf16x8 vf[4];
+    const bool kok = Pw + r < T;
+    {
+        const size_t srow = (size_t)(kok ? Pw + r - p0 : 0);
         const bf16_t* vp = vbase + srow * p.kv_rs;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * hh);
             const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
 #pragma unroll
-            for (int j = 0; j < 8; j++) { kf[kb][ks][j] = kok[kb] ? kv[j] : (short)0; vf[kb][ks][j] = kok[kb] ? vv[j] : (short)0; }
+            for (int j = 0; j < 8; j++) vf[ks][j] = kok ? vv[j] : (short)0;
         }
     }
 
@@ -301,97 +344,73 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
     const int i_lo = max(P0, 0), i_hi = min(P0 + KBLK - 1 + M - 1, T - 1);
     const int it_lo = i_lo >> 5, it_hi = i_hi >> 5;
 
-    // ---- staging: every thread owns one 16-byte chunk of a tile's q rows, of its dO rows and of the new Rd block.
-    // Every global access of the tile loop goes through a buffer descriptor (wave-uniform base in scalar registers) with a 32-bit
-    // lane offset and a scalar tile offset: with flat 64-bit lane pointers hipcc kept the per-lane bases in registers across the
-    // loop, spilled them, and the reload's s_waitcnt vmcnt(0) at the top of every tile drained the previous tile's slab stores and
-    // atomics before the next tile's rows were even requested (1.4 k of 13.8 k cycles per tile in the stamps).
-    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    // ---- staging: every thread owns one 16-byte chunk (row (tid & 255) >> 3, chunk tid & 7) of two of the four 4 KB images a tile
+    // needs: waves 0-3 the Qw image (from the q rows) and the new Rd block, waves 4-7 the Qr image (from the same q rows) and the dO
+    // image -- two 16-byte loads, one or two conversions and two 16-byte LDS stores per thread on every wave.  (Until round 5 waves 0-3
+    // formed Qw AND Qr and waves 4-7 dO + Rd: the first four waves carried 2.5 x the conversion work at the top of every tile, with the
+    // others waiting for them at barrier 1.)  Every global access of the tile loop goes through a buffer descriptor (wave-uniform base
+    // in scalar registers) with a 32-bit lane offset and a scalar tile offset.
+    const bool st_q = w < 4;                    // (wave-uniform: `w` is a scalar)
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_rd = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, -1, 0x00020000);
+    // the second chunk: Rd rows (waves 0-3) or dO rows (waves 4-7) -- one descriptor, selected once with scalar selects (a
+    // lane-dependent select of two descriptors makes hipcc wrap the load in a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rs_2 = __builtin_amdgcn_make_buffer_rsrc((void*)(st_q ? rbase : dobase), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + ((size_t)b * p.H + h) * T), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + ((size_t)b * p.H + h) * T), 0, -1, 0x00020000);
-    u32x4 tq = {0u, 0u, 0u, 0u}, tdo = {0u, 0u, 0u, 0u}, rr = {0u, 0u, 0u, 0u};
+    u32x4 tq = {0u, 0u, 0u, 0u}, t2 = {0u, 0u, 0u, 0u};
     float tl = 0.f, tdl = 0.f;
-    // four waves: every thread takes a chunk of each; eight waves: waves 0-3 the q rows, waves 4-7 the dO rows and the Rd block
-    const bool st_q = NSUB == 2 || tid < 256, st_do = NSUB == 2 || tid >= 256;
     // The staging indices are recomputed from the thread id at every use (the id goes through an empty asm, so hipcc cannot hoist what
-    // is derived from it): held across the tile loop, their registers were what the kernel spilled, and the reload of a spilled
-    // address at the top of every tile is a scratch load, i.e. an s_waitcnt vmcnt(0) that drains the previous tile's slab stores.
-#ifdef MXL_FUSED_HOIST_STAGING
-#define STG_IDS const int srow_ = (tid & 255) >> 3, sch_ = tid & 7;
-#else
+    // is derived from it): held across the tile loop, their registers were what the kernel spilled.
 #define STG_IDS int tid_o = tid; asm volatile("" : "+v"(tid_o)); const int srow_ = (tid_o & 255) >> 3, sch_ = tid_o & 7;
-#endif
-    auto load_q = [&](int it) {                 // T % 32 == 0: every row of a tile exists
+    auto load_stage = [&](int it, int nblk) {   // the rows of tile `it` (T % 32 == 0: every row exists) and distance block `nblk`
         STG_IDS
-        const int vo_q = (srow_ * p.q_rs + sch_ * 8) * 2, vo_do = (srow_ * p.o_rs + sch_ * 8) * 2;     // byte offsets inside a tile
         const int I = it * QT;
-        if (NSUB == 2) {
-            tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q, I * p.q_rs * 2, 0));
-            tdo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_do, vo_do, I * p.o_rs * 2, 0));
-        } else {                                // one staging register: the q chunk (waves 0-3) or the dO chunk (waves 4-7)
-            if (st_q) tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q, I * p.q_rs * 2, 0));
-            else tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_do, vo_do, I * p.o_rs * 2, 0));
-        }
-        // (every thread, no branch: behind a lane-dependent branch hipcc loaded into a scratch register and moved the value at
-        // once, i.e. waited s_waitcnt vmcnt(0) at the top of every tile)
+        tq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, (srow_ * p.q_rs + sch_ * 8) * 2, I * p.q_rs * 2, 0));
+        int d = 32 * nblk + srow_;              // (row index clamped: out-of-range cells are masked)
+        d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
+        const int vo2 = st_q ? (d * p.rd_rs + sch_ * 8) * 2 : (srow_ * p.o_rs + sch_ * 8) * 2;
+        const int so2 = st_q ? 0 : I * p.o_rs * 2;
+        t2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_2, vo2, so2, 0));
         tl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lse, (tid & 31) * 4, I * 4, 0));
         tdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dl, (tid & 31) * 4, I * 4, 0));
     };
-    auto store_q = [&](int buf) {
+    auto store_stage = [&](int buf, int slot) { // -> Q set `buf`, ring slot `slot`
         STG_IDS
         char* sQw = sQ + buf * QSET;
         char* sQr = sQw + QIMG;
         char* sDO = sQr + QIMG;
         float* sLse = reinterpret_cast<float*>(sDO + QIMG);
-        const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);
-        const bf16_t* sdo = reinterpret_cast<const bf16_t*>(NSUB == 2 ? &tdo : &tq);
-        if (st_q) {
-            u32x4 ww, wr;
-            bf16_t* dw = reinterpret_cast<bf16_t*>(&ww);
-            bf16_t* dr = reinterpret_cast<bf16_t*>(&wr);
-            const f32x4 bw0 = *reinterpret_cast<const f32x4*>(sBias + sch_ * 8), bw1 = *reinterpret_cast<const f32x4*>(sBias + sch_ * 8 + 4);
-            const f32x4 br0 = *reinterpret_cast<const f32x4*>(sBias + 64 + sch_ * 8), br1 = *reinterpret_cast<const f32x4*>(sBias + 64 + sch_ * 8 + 4);
+        {                                       // Qw (r_w_bias) or Qr (r_r_bias): operand scaling as in relattn_fwd.hip, so the recomputed
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(&tq);          // scores match its LSE bit for bit
+            const float* bb = sBias + (st_q ? 0 : 64) + sch_ * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bb), b1 = *reinterpret_cast<const f32x4*>(bb + 4);
+            u32x4 wq;
+            bf16_t* dq_ = reinterpret_cast<bf16_t*>(&wq);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {     // operand scaling as in relattn_fwd.hip: the recomputed scores match its LSE bit for bit
-                const float qf = bf2f(src[j]);
-                const float bw = j < 4 ? bw0[j & 3] : bw1[j & 3], br = j < 4 ? br0[j & 3] : br1[j & 3];
-                dw[j] = f2bf((qf + bw) * p.scale_log2e);
-                dr[j] = f2bf((qf + br) * p.scale_log2e);
-            }
-            *reinterpret_cast<u32x4*>(sQw + qoff(srow_, sch_)) = ww;
-            *reinterpret_cast<u32x4*>(sQr + qoff(srow_, sch_)) = wr;
+            for (int j = 0; j < 8; j++) dq_[j] = f2bf((bf2f(src[j]) + (j < 4 ? b0[j & 3] : b1[j & 3])) * p.scale_log2e);
+            *reinterpret_cast<u32x4*>((st_q ? sQw : sQr) + qoff(srow_, sch_)) = wq;
         }
-        if (st_do) {
+        if (st_q) {
+            *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = t2;
+        } else {
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(&t2);
             u32x4 wd;
             bf16_t* dd = reinterpret_cast<bf16_t*>(&wd);
 #pragma unroll
-            for (int j = 0; j < 8; j++) dd[j] = f2bf(bf2f(sdo[j]) * p.scale);
+            for (int j = 0; j < 8; j++) dd[j] = f2bf(bf2f(src[j]) * p.scale);
             *reinterpret_cast<u32x4*>(sDO + qoff(srow_, sch_)) = wd;
         }
         if (tid < 32) { sLse[tid] = -tl * LOG2E; sLse[QT + tid] = -p.scale * tdl; }
     };
-    auto load_r = [&](int n) {                  // 32 Rd rows of distance block n (row index clamped: out-of-range cells are masked)
-        if (!st_do) return;
-        STG_IDS
-        int d = 32 * n + srow_;
-        d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
-        rr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rd, (d * p.rd_rs + sch_ * 8) * 2, 0, 0));
-    };
-    auto store_r = [&](int n) {
-        if (!st_do) return;
-        STG_IDS
-        const int slot = (n + RING_OFF) % RING_BLKS;
-        *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff(srow_, sch_)) = rr;
-    };
-    // G^T block j of the window whose first block index is n0 (lane = query, registers = distances) -> fp16 skew buffer
-    auto gblock = [&](int j, int n0, const bf16x8 (&bq)[4]) {
+    // ring slots: block n sits in slot (n + RING_OFF) mod RING_BLKS.  rs0 = slot of the first block n0 of the current tile's window,
+    // advanced by one per tile; the slots of the window's other blocks by add / compare / select (no division in the loop)
+    auto slot_add = [&](int s, int k) { const int x = s + k; return x >= RING_BLKS ? x - RING_BLKS : x; };
+    // G^T block j of the window whose first block sits in ring slot s0 (lane = query, registers = distances) -> fp16 skew buffer
+    auto gblock = [&](int j, int s0, const bf16x8 (&bq)[4]) {
         f32x16 g;
 #pragma unroll
         for (int t = 0; t < 16; t++) g[t] = 0.f;
-        const char* rb = sR + ((n0 + j + RING_OFF) % RING_BLKS) * RBLK_BYTES;
+        const char* rb = sR + slot_add(s0, j) * RBLK_BYTES;
         bf16x8 a[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) a[ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
@@ -404,21 +423,14 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
         }
     };
-    auto gblocks = [&](int I, const char* sQr) {        // the nine blocks of the tile at I: wave w takes blocks w and w + 4, wave 0 also 8
-        const int n0 = (I - P0 - KBLK) >> 5;
-        bf16x8 bq[4];                                   // the tile's Qr rows (B operand), shared by the wave's blocks
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) bq[ks] = *reinterpret_cast<const bf16x8*>(sQr + (rowq ^ (ks << 5)));
-#pragma unroll
-        for (int c = 0; c < NSUB; c++) gblock(w + NW * c, n0, bq);
-        if (w == 0) gblock(8, n0, bq);
-    };
 
+    int rs0;                                    // ring slot of the current tile's first distance block
     {
         const int n0 = (it_lo * QT - P0 - KBLK) >> 5;
-        load_q(it_lo);
+        rs0 = (n0 + RING_OFF) % RING_BLKS;
+        load_stage(it_lo, n0 + 8);
         __syncthreads();                        // biases in LDS
-        store_q(0);
+        store_stage(0, slot_add(rs0, 8));       // (block n0 + 8 is one of the nine loaded below: the same bytes twice)
         // the nine Rd blocks of the first window: 9 x 256 sixteen-byte chunks, loads first
         constexpr int NPR = (9 * 256 + NT - 1) / NT;
         u32x4 pr_[NPR];
@@ -433,391 +445,336 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
         for (int n = 0; n < NPR; n++) {
             const int c = tid + n * NT;
             if (c < 9 * 256) {
-                const int slot = (n0 + (c >> 8) + RING_OFF) % RING_BLKS;
+                const int slot = slot_add(rs0, c >> 8);
                 *reinterpret_cast<u32x4*>(sR + slot * RBLK_BYTES + soff((c >> 3) & 31, c & 7)) = pr_[n];
             }
         }
     }
     __syncthreads();
-    gblocks(it_lo * QT, sQ + QIMG);
-    if (it_lo < it_hi) { load_q(it_lo + 1); load_r(((it_lo * QT - P0 - KBLK) >> 5) + 9); }      // stored at the top of the first tile
+    {                                           // the nine G blocks of the first tile: wave w takes block w, wave 0 also block 8
+        bf16x8 bq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bq[ks] = *reinterpret_cast<const bf16x8*>(sQ + QIMG + (rowq ^ (ks << 5)));
+        gblock(w, rs0, bq);
+        if (w == 0) gblock(8, rs0, bq);
+    }
+    load_stage(min(it_lo + 1, it_hi), ((it_lo * QT - P0 - KBLK) >> 5) + 9);                      // stored at the top of the first tile
     __syncthreads();
 
-    f32x16 ak[NSUB][2], av[NSUB][2];            // dK^T, dV^T : [sub-block][e half][e][key]
-    f32x16 rd_acc[NSUB][2];                     // dRd blocks of the wave's residue classes (w + NW c mod 8): [class][e half][distance][e]
+    f32x16 ak[2], av[2];                        // dK^T, dV^T : [e half][e][key]
 #pragma unroll
-    for (int a = 0; a < NSUB; a++)
+    for (int e = 0; e < 2; e++)
 #pragma unroll
-        for (int e = 0; e < 2; e++)
+        for (int j = 0; j < 16; j++) { ak[e][j] = 0.f; av[e][j] = 0.f; }
+    // dRd: racc[v] = this wave's 16 x 16 slice of the fp32 sum of the distance block at window position v.  The window slides by one
+    // block per tile, so the MFMA of position v writes the registers of position v - 1 (an MFMA's destination need not be its C
+    // operand): no register moves; position 0 leaves the window with the tile and goes to the park buffer, position 8 starts at zero.
+    // Until round 5 a whole block lived in ONE wave (32 registers) for the nine tiles it stayed in the window, and that wave alone
+    // wrote it out -- thirty-two memory operations at the end of its phase B once per tile, with seven waves waiting at barrier 2.
+    f32x4 racc[9];
 #pragma unroll
-            for (int j = 0; j < 16; j++) { ak[a][e][j] = 0.f; av[a][e][j] = 0.f; rd_acc[a][e][j] = 0.f; }
-    int acc_n[NSUB];                            // distance block whose sum rd_acc[c] holds (none yet)
-#pragma unroll
-    for (int a = 0; a < NSUB; a++) acc_n[a] = -1000000;
+    for (int v = 0; v < 9; v++) racc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cw = 0.f, cr = 0.f;                   // running column sums of this wave's dQw / dQr pieces (d r_w_bias / d r_r_bias)
 
-    auto drd_flush = [&](int c) {
+    // dRd flush.  A block leaves the window once per tile, in the registers of ONE wave.  Thirty-two atomics from that wave stalled it
+    // (issue stalls beyond 16 outstanding) and sat in its in-order vmcnt queue in front of the next tile's staged rows; parked in LDS
+    // instead (32 ds_write_b32), every wave adds four rows of it in the next tile: the same four atomics per wave and tile on every path.
+    const __amdgpu_buffer_rsrc_t rs_drd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.drd + h * 64), 0, -1, 0x00020000);
+    const int ld4 = p.drd_ld * 4;
+    auto drd_park = [&](const f32x4& leave) {   // this wave's slice of the block that leaves the window -> sPark[distance][e]
+#pragma unroll
+        for (int t = 0; t < 4; t++) sPark[(16 * (w & 1) + 4 * (l >> 4) + t) * 64 + 16 * (w >> 1) + (l & 15)] = leave[t];
+    };
+    // the slice straight from the registers: one atomic instruction covers 4 distances x 16 elements = four 64-byte segments -- the
+    // granule the memory-side atomic unit works on (MI355X_MICROARCH.md, Global float atomics: a 256-byte instruction leaves L2 as
+    // four 64-byte requests) -- and every wave issues the same four per tile
+    auto drd_add = [&](const f32x4& leave, int nL) {
+        const bool ok = nL >= 0 && nL < MB;
+        const float f = ok ? 1.f / p.scale_log2e : 0.f;     // the Qr image carries scale * log2(e); out of range: zeros onto block 0
+        const int so = (ok ? 32 * nL : 0) + 16 * (w & 1);
+        const int vo = 4 * (l >> 4) * ld4 + (16 * (w >> 1) + (l & 15)) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
 #ifndef MXL_ABL_NO_ATOMICS
-        if (acc_n[c] >= 0 && acc_n[c] < MB) {
-            const float f = 1.f / p.scale_log2e;            // the Qr image carries scale * log2(e)
-            float* dst = p.drd + (size_t)(32 * acc_n[c] + 4 * hh) * p.drd_ld + h * 64 + r;
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(leave[t] * f, rs_drd, vo, (so + t) * ld4, 0);
+#else
+            asm volatile("" :: "v"(leave[t]));
+#endif
+    };
+    float pk[4];                                // this wave's four rows of the parked block (row 4 w + i, column l)
+    auto park_read = [&]() {
 #pragma unroll
-            for (int e = 0; e < 2; e++)
+        for (int i = 0; i < 4; i++) pk[i] = sPark[(4 * w + i) * 64 + l];
+    };
+    auto park_add = [&](int nL) {               // block nL (out of range: zeros onto block 0 -- the operation count stays the same)
+        const bool ok = nL >= 0 && nL < MB;
+        const int so = ok ? 32 * nL * ld4 : 0;
+        const float f = ok ? 1.f / p.scale_log2e : 0.f;     // the Qr image carries scale * log2(e)
 #pragma unroll
-                for (int j = 0; j < 16; j++)
-                    atomicAdd(dst + (size_t)((j & 3) + 8 * (j >> 2)) * p.drd_ld + 32 * e, rd_acc[c][e][j] * f);
+        for (int i = 0; i < 4; i++)
+#ifndef MXL_ABL_NO_ATOMICS
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pk[i] * f, rs_drd, l * 4, so + (4 * w + i) * ld4, 0);
+#else
+            asm volatile("" :: "v"(pk[i]));
+#endif
+    };
+    auto drd_flush_direct = [&](int nfirst) {   // after the sweep: the eight blocks still in registers (positions 0 .. 7 = blocks nfirst ..)
+#ifndef MXL_ABL_NO_ATOMICS
+        const float f = 1.f / p.scale_log2e;
+        const int vo = 4 * (l >> 4) * ld4 + (16 * (w >> 1) + (l & 15)) * 4;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const int nb = nfirst + v;
+            if (nb >= 0 && nb < MB) {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(racc[v][t] * f, rs_drd, vo, (32 * nb + 16 * (w & 1) + t) * ld4, 0);
+            }
         }
 #endif
-#pragma unroll
-        for (int e = 0; e < 2; e++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) rd_acc[c][e][j] = 0.f;
     };
+    // (the park buffer starts as zeros: the first tile adds them)
+    if (FUSED_PARK) {
+        for (int i = tid; i < PARK_BYTES / 4; i += NT) sPark[i] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < VM_PER_TILE; i++)       // the loop is entered with as many operations behind the first staged rows as every later tile has
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(0.f, rs_drd, l * 4, i * ld4, 0);
 
-    // The score phase's operand reads (query / dO rows as A fragments, the per-query constants) do not depend on anything the
-    // other waves write during a tile: a tile's Q set is complete at barrier 1 of the tile before.  They are requested at the END
-    // of the previous tile, ahead of barrier 2, and are in registers when the chains start.
-    bf16x8 aq[4], ad[4];
-    f32x4 cl[4], cd[4];
-    auto read_rows = [&](int buf) {
-        const char* sQw_ = sQ + buf * QSET;
-        const char* sDO_ = sQw_ + 2 * QIMG;
-        const float* sLse_ = reinterpret_cast<const float*>(sDO_ + QIMG);
-#pragma unroll
-        for (int grp = 0; grp < 4; grp++) {
-            cl[grp] = *reinterpret_cast<const f32x4*>(sLse_ + 8 * grp + 4 * hh);
-            cd[grp] = *reinterpret_cast<const f32x4*>(sLse_ + QT + 8 * grp + 4 * hh);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            aq[ks] = *reinterpret_cast<const bf16x8*>(sQw_ + (rowq ^ (ks << 5)));
-            ad[ks] = *reinterpret_cast<const bf16x8*>(sDO_ + (rowq ^ (ks << 5)));
-        }
-    };
     int cur = 0;
     STAMP(15)
 #pragma unroll 1
     for (int it = it_lo; it <= it_hi; it++) {
         const int I = it * QT;
         const bool more = it < it_hi;
+        // The lane constants are "redefined" by an empty asm at the top of every tile: what hipcc derives from them (rowq ^ (ks << 5),
+        // tkb ^ 64, ka0 + slot offsets ...) then cannot be hoisted out of the loop -- hoisted, each derived address was one more
+        // register live across the whole tile, and the kernel spilled (the V fragments, the staged rows) to hold them.
+        asm volatile("" : "+v"(rowq), "+v"(rows), "+v"(tkb), "+v"(xw), "+v"(yt0), "+v"(qb0), "+v"(xa0), "+v"(xa1), "+v"(ka0), "+v"(ka1), "+v"(yq0), "+v"(krow));
         const char* sQw = sQ + cur * QSET;
         const char* sQr = sQw + QIMG;
         const char* sDO = sQr + QIMG;
         const float* sLse = reinterpret_cast<const float*>(sDO + QIMG);
-        const float* sDl = sLse + QT;
         const int n0 = (I - P0 - KBLK) >> 5;    // first distance block of this tile's window: column c = distance - 32 n0
         // The rows of tile it + 1 were requested a whole tile ago: their LDS images (into the Q set and the ring slot that phase
-        // B of tile it - 1 was the last to read) go in now, and the rows of tile it + 2 are requested.  (Requested at the top of
-        // the tile that stores them, the loads were still in flight at the end of its score phase: 23 % of the wave time of
-        // the eight-wave form was that wait, profiles/r04_fused_stamp_anatomy.txt.)
-        if (more) { store_q(cur ^ 1); store_r(n0 + 9); }
-        if (it + 1 < it_hi) { load_q(it + 2); load_r(n0 + 10); }
+        // B of tile it - 1 was the last to read) go in now, and the rows of tile it + 2 are requested.
+#ifndef MXL_ABL_NO_STAGING
+#ifdef MXL_STAMP
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (diagnostic build: the wait for the staged rows as a segment of its own)
+        STAMP(14)
+#endif
+        // (unconditional: on the last tile the rows of tile it_hi go, once more, into the image and the ring slot nobody reads again)
+        store_stage(cur ^ 1, slot_add(rs0, 9));
+#ifdef MXL_ABL_HOT_LOADS
+        load_stage(it_lo, n0 + 10);
+#else
+        load_stage(min(it + 2, it_hi), n0 + 10);
+#endif
+#endif
+        if (FUSED_PARK) park_read();            // the block parked by the previous tile (read before barrier 1, rewritten behind it)
         STAMP(0)
 
-        // =============================== phase A: scores, dV, dK, dS -> X / Y ===============================
-        bool active[NSUB], full[NSUB], any = false;
-#pragma unroll
-        for (int kb = 0; kb < NSUB; kb++) {
-            const int Pk = Pw + 32 * kb;
-            const int dmin_w = I - Pk - 31, dmax_w = I + 31 - Pk;
-            active[kb] = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pk < T);
-            full[kb] = (dmin_w >= 0) && (dmax_w <= M - 1) && (Pk + 31 < T);
-            any = any || active[kb];
-        }
-        if (any) {
-            // every LDS read of the score phase first, then the four chains
-            uint32_t bdu[NSUB][16];
-#pragma unroll
-            for (int kb = 0; kb < NSUB; kb++) gskew_read16(gRb - 64 * kb, bdu[kb]);
-            read_rows(cur);
-            // K as the B operand of S (lane = key, k = 16 ks + 8 hh ..): registers for the whole sweep at four waves; at eight
-            // waves (256 registers) re-read per tile from the LDS image, whose swizzle makes the row reads conflict-free
-            bf16x8 kfl[4];
-            if (NSUB == 1) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++)
-                    kfl[ks] = *reinterpret_cast<const bf16x8*>(sK + kloc0 * ROWB + ((((2 * ks + hh) ^ sswz(kloc0))) << 4));
-            }
-#define KF(kb_, ks_) (NSUB == 2 ? kf[kb_][ks_] : kfl[ks_])
-            // -lse and -scale * delta of the tile's queries as ONE start tuple per chain kind (an MFMA's C operand need not be its
-            // destination): shared by the sub-blocks
-            f32x16 s[NSUB], dp[NSUB];
-            if (NSUB == 2) {
-                f32x16 c_s, c_dp;
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { c_s[4 * grp + t] = cl[grp][t]; c_dp[4 * grp + t] = cd[grp][t]; }
-#pragma unroll
-                for (int kb = 0; kb < NSUB; kb++) { s[kb] = mfma32(aq[0], KF(kb, 0), c_s); dp[kb] = mfma32(ad[0], vf[kb][0], c_dp); }
-            } else {
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { s[0][4 * grp + t] = cl[grp][t]; dp[0][4 * grp + t] = cd[grp][t]; }
-                s[0] = mfma32(aq[0], KF(0, 0), s[0]);
-                dp[0] = mfma32(ad[0], vf[0][0], dp[0]);
-            }
-#pragma unroll
-            for (int ks = 1; ks < 4; ks++) {
-#pragma unroll
-                for (int kb = 0; kb < NSUB; kb++) s[kb] = mfma32(aq[ks], KF(kb, ks), s[kb]);
-#pragma unroll
-                for (int kb = 0; kb < NSUB; kb++) dp[kb] = mfma32(ad[ks], vf[kb][ks], dp[kb]);
-            }
-#undef KF
-            STAMP(1)
-            gskew_wait();
-            STAMP(2)
-            // the transposed dO / Qw fragments of the dV / dK products: at four waves requested now, so that they land under the
-            // exponentials (at eight waves there are no 32 registers to park them in: requested behind the exponentials)
-            bf16x8 tdo_[2][2], tqw_[2][2];
-            auto tr_frags = [&]() {
-#pragma unroll
-                for (int st = 0; st < 2; st++)
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const char* a0 = sDO + 16 * st * ROWB + tk0;
-                        tdo_[st][e] = tr_pair(a0 + 64 * e, a0 + 8 * ROWB + 64 * (1 - e));
-                        const char* c0 = sQw + 16 * st * ROWB + tk0;
-                        tqw_[st][e] = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
-                    }
-            };
-            if (NSUB == 2) tr_frags();
-            uint32_t dsw[NSUB][8], prw[NSUB][8];    // dS and P as bf16 pairs (2m, 2m + 1)
-#pragma unroll
-            for (int kb = 0; kb < NSUB; kb++) {
-                const bool fl = __builtin_amdgcn_readfirstlane((int)full[kb]) != 0;
-                f32x16 pr;
-                if (fl) {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const float pv = __builtin_amdgcn_exp2f(add_f16(s[kb][j], bdu[kb][j]));
-                        pr[j] = pv;
-                        s[kb][j] = pv * dp[kb][j];
-                    }
-                } else {
-                    const int pk = Pw + 32 * kb + r;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                        const int d = I + ii - pk;
-                        const bool valid = (d >= 0) && (d <= M - 1) && kok[kb] && active[kb];
-                        // (the exponent is replaced, not the result: with `valid ? exp2(x) : 0` hipcc branches around every
-                        // exponential -- sixteen exec-masked blocks on the tiles that cross the causal diagonal)
-                        const float x = add_f16(s[kb][j], bdu[kb][j]);
-                        const float pv = __builtin_amdgcn_exp2f(valid ? x : -1.0e30f);
-                        pr[j] = pv;
-                        s[kb][j] = pv * (valid ? dp[kb][j] : 0.f);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 8; m++) { dsw[kb][m] = pack2bf(s[kb][2 * m], s[kb][2 * m + 1]); prw[kb][m] = pack2bf(pr[2 * m], pr[2 * m + 1]); }
-                if (NSUB == 1) tr_frags();      // the score registers are free now: requested ahead of the twenty LDS writes below
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++)
-                    *reinterpret_cast<u32x2*>(sX + kb * 2048 + (xw ^ (grp << 4))) = u32x2{dsw[kb][2 * grp], dsw[kb][2 * grp + 1]};
-                yskew_write16(yWb - 64 * kb, dsw[kb]);
-            }
-            STAMP(3)
-            // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order; shared by the sub-blocks)
-#pragma unroll
-            for (int st = 0; st < 2; st++) {
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
+        // =============================== phase A: scores, dS -> X / Y ===============================
+        const int dmin_w = I - Pw - 31, dmax_w = I + 31 - Pw;
+        const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (Pw < T);
+        const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (Pw + 31 < T);
+        uint32_t dsw[8], prw[8];                // dS and P as bf16 pairs (2m, 2m + 1): live across barrier 1 (dV / dK run behind it)
+        bf16x8 tdo_[2][2], tqw_[2][2];          // transposed dO / Qw fragments (A operands of dV^T / dK^T)
+        // dV^T += dO^T . P ; dK^T += Qw^T . dS   (A through transposed reads, accumulator-permuted k order)
+        auto dvdk = [&]() {
 #ifndef MXL_ABL_NO_DVDK
 #pragma unroll
-                    for (int kb = 0; kb < NSUB; kb++) {
-                        const u32x4 pw = {prw[kb][4 * st], prw[kb][4 * st + 1], prw[kb][4 * st + 2], prw[kb][4 * st + 3]};
-                        const u32x4 dw = {dsw[kb][4 * st], dsw[kb][4 * st + 1], dsw[kb][4 * st + 2], dsw[kb][4 * st + 3]};
-                        av[kb][e] = mfma32(tdo_[st][e], __builtin_bit_cast(bf16x8, pw), av[kb][e]);
-                        ak[kb][e] = mfma32(tqw_[st][e], __builtin_bit_cast(bf16x8, dw), ak[kb][e]);
-                    }
+            for (int st = 0; st < 2; st++) {
+                const u32x4 pw = {prw[4 * st], prw[4 * st + 1], prw[4 * st + 2], prw[4 * st + 3]};
+                const u32x4 dw = {dsw[4 * st], dsw[4 * st + 1], dsw[4 * st + 2], dsw[4 * st + 3]};
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    av[e] = mfma32(tdo_[st][e], __builtin_bit_cast(bf16x8, pw), av[e]);
+                    ak[e] = mfma32(tqw_[st][e], __builtin_bit_cast(bf16x8, dw), ak[e]);
+                }
+            }
 #endif
-                }
-            }
-        } else {
-            // no valid cell for this wave's keys in this tile: its rows of X and its cells of Y still have to read as zero
-            const uint32_t z[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int kb = 0; kb < NSUB; kb++) {
-#pragma unroll
-                for (int grp = 0; grp < 4; grp++) *reinterpret_cast<u32x2*>(sX + kb * 2048 + (xw ^ (grp << 4))) = u32x2{0u, 0u};
-                yskew_write16(yWb - 64 * kb, z);
-            }
-        }
-        STAMP(4)
-        STAMP(5)
-        lds_barrier();
-        STAMP(6)
-
-        // =============================== phase B: dq piece, dRd blocks, next tile's G ===============================
-        // Two rounds, each "every LDS read of the round, then its MFMAs" with a scheduling fence between: left to itself hipcc
-        // issues four reads, waits, issues one MFMA, 40 times per tile (profiles/r04_fused_stamp_anatomy.txt) -- a wave that is
-        // alone or nearly alone on its SIMD then sits out an LDS round trip per MFMA.  Round 1: the key half of the dq piece and
-        // the next tile's G blocks (neither needs Y); round 2: the distance half of the dq piece and the dRd blocks.
-        {
-            f32x4 aw4[NIH], ar4[NIH];
-            f32x4 aw4b = {0.f, 0.f, 0.f, 0.f}, ar4b = {0.f, 0.f, 0.f, 0.f};      // eight waves: a second chain per product
-#pragma unroll
-            for (int ih = 0; ih < NIH; ih++) { aw4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; ar4[ih] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            const char* sQrN = sQ + (cur ^ 1) * QSET + QIMG;       // the next tile's Qr image (stored before barrier 1)
-            const int n0N = n0 + 1;
-            // ---- round 1 reads
-            bf16x8 bk[8], xa[8][NIH], gq_[4], ga[NSUB][4];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                bk[u] = tr_pair(sK + u * 4096 + ka0, sK + u * 4096 + ka1);
-#pragma unroll
-                for (int ih = 0; ih < NIH; ih++) xa[u][ih] = tr_pair(sX + u * 2048 + (xa0 ^ (ih << 5)), sX + u * 2048 + (xa1 ^ (ih << 5)));
-            }
-            auto g_reads = [&]() {
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) gq_[ks] = *reinterpret_cast<const bf16x8*>(sQrN + (rowq ^ (ks << 5)));
-#pragma unroll
-                for (int c = 0; c < NSUB; c++) {
-                    const char* rb = sR + ((n0N + w + NW * c + RING_OFF) % RING_BLKS) * RBLK_BYTES;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) ga[c][ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
-                }
-            };
-            if (NSUB == 2) g_reads();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- round 1 MFMAs
-            if (NSUB == 2) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-    #pragma unroll
-                    for (int ih = 0; ih < NIH; ih++) aw4[ih] = mfma16(xa[u][ih], bk[u], aw4[ih]);
-                }
-            } else {                    // one 16-row half per wave: two independent chains instead of one of eight dependent MFMAs
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                        if (u & 1) aw4b = mfma16(xa[u][0], bk[u], aw4b); else aw4[0] = mfma16(xa[u][0], bk[u], aw4[0]);
-                }
-            }
-            if (NSUB == 1) {            // (256 registers: the G operands get a round of their own)
-                __builtin_amdgcn_sched_barrier(0);
-                g_reads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) {
-#pragma unroll
-                for (int c = 0; c < NSUB; c++) {
-                    f32x16 g;
-#pragma unroll
-                    for (int t = 0; t < 16; t++) g[t] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) g = mfma32(ga[c][ks], gq_[ks], g);
-                    char* gw = sG + r * GP + (32 * (w + NW * c) + 4 * hh) * 2;
-#pragma unroll
-                    for (int grp = 0; grp < 4; grp++) {
-                        const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
-                        *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
-                    }
-                }
-                if (w == 0) {           // the ninth block of the window: its four row fragments in one batch (the registers of block w's)
-                    const char* rb = sR + ((n0N + 8 + RING_OFF) % RING_BLKS) * RBLK_BYTES;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) ga[0][ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x16 g;
-#pragma unroll
-                    for (int t = 0; t < 16; t++) g[t] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) g = mfma32(ga[0][ks], gq_[ks], g);
-                    char* gw = sG + r * GP + (32 * 8 + 4 * hh) * 2;
-#pragma unroll
-                    for (int grp = 0; grp < 4; grp++) {
-                        const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
-                        *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
-                    }
-                }
-            }
-            STAMP(7)
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- round 2a reads: distance blocks 0 - 4 of the dq piece, the dRd operands
-            bf16x8 br[5], ya[5][NIH], tqr[2][2], da[NSUB][2];
-            int jA[NSUB];
-            int slot = (n0 + RING_OFF) % RING_BLKS;
-#pragma unroll
-            for (int v = 0; v < 5; v++) {
-                const char* rb = sR + slot * RBLK_BYTES;
-                br[v] = tr_pair(rb + ka0, rb + ka1);
-#pragma unroll
-                for (int ih = 0; ih < NIH; ih++) ya[v][ih] = *reinterpret_cast<const bf16x8*>(sY + yq0 + 16 * ih * YP + v * 64);
-                slot = (slot == RING_BLKS - 1) ? 0 : slot + 1;
-            }
+        };
+        auto tr_frags = [&]() {
 #pragma unroll
             for (int st = 0; st < 2; st++)
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const char* c0 = sQr + 16 * st * ROWB + tk0;
-                    tqr[st][e] = tr_pair(c0 + 64 * e, c0 + 8 * ROWB + 64 * (1 - e));
+                    const int lo = 2048 * st + (tkb ^ (e << 6)), hi = 2048 * st + 1024 + (tkb ^ 16 ^ (e << 6));
+                    tdo_[st][e] = tr_pair(sDO + lo, sDO + hi);
+                    tqw_[st][e] = tr_pair(sQw + lo, sQw + hi);
                 }
+        };
+        if (active) {
+            // every LDS read of the score phase first, then the chains
+            // S chain first (operands: the Qw rows and the wave's K rows), then the dP chain (dO rows; V in registers): one chain's
+            // operands at a time -- 32 registers instead of 48 beside the two accumulators -- and a single accumulation chain of this
+            // MFMA runs at the issue rate (MI355X_MICROARCH.md, cycle constants).  The dO rows are requested ahead of the S MFMAs.
+            bf16x8 aq[4], ad[4], kfl[4];
+            f32x16 s, dp;
 #pragma unroll
-            for (int c = 0; c < NSUB; c++) {
-                jA[c] = (w + NW * c - n0) & 7;          // window position of the class's block (0: its last tile)
+            for (int grp = 0; grp < 4; grp++) {     // -lse of the tile's queries: the chain's start value
+                const f32x4 cl = *reinterpret_cast<const f32x4*>(sLse + 8 * grp + 4 * hh);
 #pragma unroll
-                for (int st = 0; st < 2; st++) {
-                    const char* ya_ = sY + ya0 + 16 * st * YP + 64 * jA[c];
-                    da[c][st] = tr_pair(ya_, ya_ + 8 * YP);
-                }
+                for (int t = 0; t < 4; t++) s[4 * grp + t] = cl[t];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                aq[ks] = *reinterpret_cast<const bf16x8*>(sQw + (rowq ^ (ks << 5)));
+                // K as the B operand of S (lane = key, k = 16 ks + 8 hh ..): re-read per tile from the LDS image (no 16 registers to
+                // hold it for the sweep), whose swizzle makes the row reads conflict-free
+                kfl[ks] = *reinterpret_cast<const bf16x8*>(sK + (krow ^ (ks << 5)));
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- round 2a MFMAs
-            if (NSUB == 2) {
 #pragma unroll
-                for (int v = 0; v < 5; v++) {
+            for (int grp = 0; grp < 4; grp++) {     // -scale * delta
+                const f32x4 cd = *reinterpret_cast<const f32x4*>(sLse + QT + 8 * grp + 4 * hh);
 #pragma unroll
-                    for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya[v][ih], br[v], ar4[ih]);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 5; v++) {
-                    if (v & 1) ar4b = mfma16(ya[v][0], br[v], ar4b); else ar4[0] = mfma16(ya[v][0], br[v], ar4[0]);
-                }
+                for (int t = 0; t < 4; t++) dp[4 * grp + t] = cd[t];
             }
 #pragma unroll
-            for (int c = 0; c < NSUB; c++) {
-                const int nA = n0 + jA[c];
-                acc_n[c] = nA;                  // (at the wave's first tile the accumulator is still empty)
-                if (nA >= 0 && nA < MB) {
+            for (int ks = 0; ks < 4; ks++) ad[ks] = *reinterpret_cast<const bf16x8*>(sDO + (rowq ^ (ks << 5)));
 #pragma unroll
-                    for (int st = 0; st < 2; st++)
-#pragma unroll
-                        for (int e = 0; e < 2; e++) rd_acc[c][e] = mfma32(da[c][st], tqr[st][e], rd_acc[c][e]);
-                }
-            }
+            for (int ks = 0; ks < 4; ks++) s = mfma32(aq[ks], kfl[ks], s);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- round 2b reads: distance blocks 5 - 8, and the NEXT tile's score-phase operand rows (ahead of barrier 2)
-            bf16x8 br2[4], ya2[4][NIH];
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const char* rb = sR + slot * RBLK_BYTES;
-                br2[v] = tr_pair(rb + ka0, rb + ka1);
-#pragma unroll
-                for (int ih = 0; ih < NIH; ih++) ya2[v][ih] = *reinterpret_cast<const bf16x8*>(sY + yq0 + 16 * ih * YP + (v + 5) * 64);
-                slot = (slot == RING_BLKS - 1) ? 0 : slot + 1;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (NSUB == 2) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-#pragma unroll
-                    for (int ih = 0; ih < NIH; ih++) ar4[ih] = mfma16(ya2[v][ih], br2[v], ar4[ih]);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    if (v & 1) ar4b = mfma16(ya2[v][0], br2[v], ar4b); else ar4[0] = mfma16(ya2[v][0], br2[v], ar4[0]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; t++) { aw4[0][t] += aw4b[t]; ar4[0][t] += ar4b[t]; }
-            }
-            STAMP(8)
-            // this tile's partial dq -> slab of this key block (rows = queries 16 ih + 4 (l >> 4) + t, column = element 16 eq + (l & 15))
+#if FUSED_VF_RELOAD
+            bf16x8 vfl[4];
             {
+                const bf16_t* vp = vbase + (size_t)(kok ? Pw + r - p0 : 0) * p.kv_rs;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) vfl[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * hh);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) dp = mfma32(ad[ks], vfl[ks], dp);
+#else
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) dp = mfma32(ad[ks], vf[ks], dp);
+#endif
+            // the positional term of the wave's cells: sixteen 16-bit reads of the skew buffer, issued behind the chains' MFMAs (their
+            // 256 cycles cover the reads; ahead of the chains' operand reads the sixteen result registers were live beside the 48 operand
+            // registers -- the kernel's peak)
+            uint32_t bdu[16];
+            gskew_read16(gRb, bdu);
+            STAMP(1)
+            gskew_wait();
+            STAMP(2)
+            f32x16 pr;
+            const bool fl = __builtin_amdgcn_readfirstlane((int)full) != 0;
+            if (fl) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float pv = __builtin_amdgcn_exp2f(add_f16(s[j], bdu[j]));
+                    pr[j] = pv;
+                    s[j] = pv * dp[j];
+                }
+            } else {
+                const int pk = Pw + r;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int ii = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const int d = I + ii - pk;
+                    const bool valid = (d >= 0) && (d <= M - 1) && kok;
+                    // (the exponent is replaced, not the result: with `valid ? exp2(x) : 0` hipcc branches around every
+                    // exponential -- sixteen exec-masked blocks on the tiles that cross the causal diagonal)
+                    const float x = add_f16(s[j], bdu[j]);
+                    const float pv = __builtin_amdgcn_exp2f(valid ? x : -1.0e30f);
+                    pr[j] = pv;
+                    s[j] = pv * (valid ? dp[j] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) { dsw[m] = pack2bf(s[2 * m], s[2 * m + 1]); prw[m] = pack2bf(pr[2 * m], pr[2 * m + 1]); }
+            // the transposed dO / Qw fragments: requested ahead of the twenty LDS writes below, consumed behind barrier 1
+            if (FUSED_TRF_EARLY || !FUSED_DVDK_LATE) tr_frags();
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++)
+                *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{dsw[2 * grp], dsw[2 * grp + 1]};
+            yskew_write16(yWb, dsw);
+            if (!FUSED_DVDK_LATE) dvdk();
+        } else {
+            // no valid cell for this wave's keys in this tile: its rows of X and its cells of Y still have to read as zero
+            const uint32_t z[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) *reinterpret_cast<u32x2*>(sX + (xw ^ (grp << 4))) = u32x2{0u, 0u};
+            yskew_write16(yWb, z);
+            if (FUSED_DVDK_LATE) {
+                // "define" what the products behind barrier 1 read (they are skipped on this path): left undefined here, the 48
+                // registers count as live around the whole loop.  No instruction is emitted.
+#pragma unroll
+                for (int m = 0; m < 8; m++) asm volatile("" : "=v"(dsw[m]), "=v"(prw[m]));
+#pragma unroll
+                for (int st = 0; st < 2; st++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) asm volatile("" : "=v"(tdo_[st][e]), "=v"(tqw_[st][e]));
+            }
+        }
+        if (FUSED_PARK) park_add(n0 - 1);       // the block that left the window with the previous tile
+        STAMP(3)
+        lds_barrier();
+        STAMP(4)
+
+        // =============================== phase B: dV / dK, dq piece, dRd block, next tile's G ===============================
+        {
+            // unit n = one 16x16x32 MFMA of the dq piece with its two operand fragments: n < 8 key block n (A = X^T rows, B = K^T),
+            // n >= 8 distance block n - 8 of the window (A = Y rows, B = Rd^T from ring slot rs0 + n - 8)
+            bf16x8 ua[26], ub[17], qrb;
+            int sl = rs0;
+            auto rd_unit = [&](int n) {
+                if (n < 8) {
+                    ub[n] = tr_pair(sK + n * 4096 + ka0, sK + n * 4096 + ka1);
+                    ua[n] = tr_pair(sX + n * 2048 + xa0, sX + n * 2048 + xa1);
+                } else if (n < 17) {
+                    const char* rb = sR + sl * RBLK_BYTES;
+                    ub[n] = tr_pair(rb + ka0, rb + ka1);
+                    ua[n] = *reinterpret_cast<const bf16x8*>(sY + yq0 + (n - 8) * 64);
+                    sl = (sl == RING_BLKS - 1) ? 0 : sl + 1;
+                } else {                        // n >= 17: dRd, window position n - 17 (A = Y^T fragment; B = Qr^T, shared)
+                    if (n == 17) qrb = tr_pair(sQr + qb0, sQr + qb0 + 2048);
+                    ua[n] = tr_pair(sY + yt0 + (n - 17) * 64, sY + yt0 + 16 * YP + (n - 17) * 64);
+                }
+            };
+            if (FUSED_DVDK_LATE && !FUSED_TRF_EARLY && active) tr_frags();
+#pragma unroll
+            for (int n = 0; n < FUSED_PF; n++) rd_unit(n);
+            UNIT_FENCE();
+            if (FUSED_DVDK_LATE && active) dvdk();
+            UNIT_FENCE();
+            STAMP(5)
+            f32x4 aw4[2], ar4[2];               // two independent accumulator chains per half of the contraction
+#pragma unroll
+            for (int c = 0; c < 2; c++) { aw4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ar4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            f32x4 leave;
+#pragma unroll
+            for (int n = 0; n < 26; n++) {
+                if (n < 8) aw4[n & 1] = mfma16(ua[n], ub[n], aw4[n & 1]);
+                else if (n < 17) ar4[n & 1] = mfma16(ua[n], ub[n], ar4[n & 1]);
+                else if (n == 17) leave = mfma16(ua[n], qrb, racc[0]);
+                else racc[n - 18] = mfma16(ua[n], qrb, racc[n - 17]);
+                if (n + FUSED_PF < 26) rd_unit(n + FUSED_PF);
+                UNIT_FENCE();
+            }
+            racc[8] = f32x4{0.f, 0.f, 0.f, 0.f};
+            STAMP(6)
+            // the next tile's G operands (its Qr image was stored before barrier 1; its window starts one ring slot further)
+            const char* sQrN = sQ + (cur ^ 1) * QSET + QIMG;
+            const int rs1 = slot_add(rs0, 1);
+            // (read on the last tile too, where nothing uses them: defined under `if (more)` and used under a second `if (more)` the
+            // 32 registers count as live on the path around the definition, i.e. across the whole loop)
+            bf16x8 gq_[4], ga[4];
+            {
+                const char* rb = sR + slot_add(rs1, w) * RBLK_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    gq_[ks] = *reinterpret_cast<const bf16x8*>(sQrN + (rowq ^ (ks << 5)));
+                    ga[ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+                }
+            }
+            UNIT_FENCE();
+            // this tile's partial dq -> slab of this key block (rows = queries 16 ih0 + 4 (l >> 4) + t, column = element 16 eq + (l & 15))
+            {
+#pragma unroll
+                for (int t = 0; t < 4; t++) { aw4[0][t] += aw4[1][t]; ar4[0][t] += ar4[1][t]; }
                 const int x = I - M - 254 - p0;
                 const int kb_lo = x <= 0 ? 0 : (x + 255) >> 8;
                 // The slabs are bf16 (half the bytes of the round trip through the finish kernel, which sums them in fp32): a lane owns one
@@ -829,62 +786,74 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
 #if MXL_SLAB_BF16
                 const bool odd = (l & 1) != 0;
                 const int vo = (4 * g16 + (odd ? 2 : 0)) * rowb + ((l & 15) >> 1) * 4;
+                float v[4], nb[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    v[t] = aw4[0][t] + ar4[0][t];
+                    nb[t] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[t]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {       // even lanes: rows 0, 1 (own column first); odd lanes: rows 2, 3 (the neighbour's first)
+                    const float lo = odd ? nb[2 + u] : v[u], hi = odd ? v[2 + u] : nb[u];
+                    __builtin_amdgcn_raw_buffer_store_b32((int)pack2bf(lo, hi), rs_sl, vo, u * rowb, 0);
+                }
 #else
                 const int vo = 4 * g16 * rowb + (l & 15) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, aw4[0][t] + ar4[0][t]), rs_sl, vo, t * rowb, 0);
 #endif
+                cw += (aw4[0][0] + aw4[0][1]) + (aw4[0][2] + aw4[0][3]);
+                cr += (ar4[0][0] + ar4[0][1]) + (ar4[0][2] + ar4[0][3]);
+            }
+            STAMP(7)
+            if (FUSED_PARK) drd_park(leave); else drd_add(leave, n0);
+            STAMP(8)
+            // the next tile's G block(s): wave w block w of its window, one wave also block 8
+            if (more) {
+                f32x16 g;
 #pragma unroll
-                for (int ih = 0; ih < NIH; ih++) {
-#if MXL_SLAB_BF16
-                    float v[4], nb[4];
+                for (int t = 0; t < 16; t++) g[t] = 0.f;
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        v[t] = aw4[ih][t] + ar4[ih][t];
-                        nb[t] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[t]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                for (int ks = 0; ks < 4; ks++) g = mfma32(ga[ks], gq_[ks], g);
+                char* gw = sG + r * GP + (32 * w + 4 * hh) * 2;
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    const f32x4v v4 = {g[4 * grp], g[4 * grp + 1], g[4 * grp + 2], g[4 * grp + 3]};
+                    *reinterpret_cast<f16x4*>(gw + 16 * grp) = __builtin_convertvector(v4, f16x4);
+                }
+                if (w == ((n0 + 4) & 7)) {      // the ninth block of the window, on the wave four places from the one that parks this tile
+                    const char* rb = sR + slot_add(rs1, 8) * RBLK_BYTES;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) ga[ks] = *reinterpret_cast<const bf16x8*>(rb + (rows ^ (ks << 5)));
+                    UNIT_FENCE();
+                    f32x16 g8;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) g8[t] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) g8 = mfma32(ga[ks], gq_[ks], g8);
+                    char* gw8 = sG + r * GP + (32 * 8 + 4 * hh) * 2;
+#pragma unroll
+                    for (int grp = 0; grp < 4; grp++) {
+                        const f32x4v v4 = {g8[4 * grp], g8[4 * grp + 1], g8[4 * grp + 2], g8[4 * grp + 3]};
+                        *reinterpret_cast<f16x4*>(gw8 + 16 * grp) = __builtin_convertvector(v4, f16x4);
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {       // even lanes: rows 0, 1 (own column first); odd lanes: rows 2, 3 (the neighbour's first)
-                        const float lo = odd ? nb[2 + u] : v[u], hi = odd ? v[2 + u] : nb[u];
-                        __builtin_amdgcn_raw_buffer_store_b32((int)pack2bf(lo, hi), rs_sl, vo, (16 * ih + u) * rowb, 0);
-                    }
-#else
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, aw4[ih][t] + ar4[ih][t]), rs_sl, vo, (16 * ih + t) * rowb, 0);
-#endif
-                    cw += (aw4[ih][0] + aw4[ih][1]) + (aw4[ih][2] + aw4[ih][3]);
-                    cr += (ar4[ih][0] + ar4[ih][1]) + (ar4[ih][2] + ar4[ih][3]);
                 }
             }
             STAMP(9)
-            // dRd: a block at window position 0 leaves the window after this tile (flush) and the class's next block enters at 8
-#pragma unroll
-            for (int c = 0; c < NSUB; c++) {
-                if (jA[c] == 0) {
-                    drd_flush(c);
-                    acc_n[c] = n0 + 8;
-                    if (n0 + 8 >= 0 && n0 + 8 < MB) {
-                        bf16x8 d8[2];
-#pragma unroll
-                        for (int st = 0; st < 2; st++) {
-                            const char* ya_ = sY + ya0 + 16 * st * YP + 64 * 8;
-                            d8[st] = tr_pair(ya_, ya_ + 8 * YP);
-                        }
-#pragma unroll
-                        for (int st = 0; st < 2; st++)
-#pragma unroll
-                            for (int e = 0; e < 2; e++) rd_acc[c][e] = mfma32(d8[st], tqr[st][e], rd_acc[c][e]);
-                    }
-                }
-            }
             STAMP(10)
-            STAMP(11)
         }
         lds_barrier();
         STAMP(12)
         cur ^= 1;
+        rs0 = (rs0 == RING_BLKS - 1) ? 0 : rs0 + 1;
     }
-#pragma unroll
-    for (int c = 0; c < NSUB; c++) drd_flush(c);
+    // the block parked by the last tile, then the blocks still in registers
+    {
+        const int n0_end = ((it_hi + 1) * QT - P0 - KBLK) >> 5;
+        if (FUSED_PARK && it_lo <= it_hi) { park_read(); park_add(n0_end - 1); }
+    }
+    drd_flush_direct(((it_hi + 1) * QT - P0 - KBLK) >> 5);
     STAMP(13)
     STAMP_FLUSH
 
@@ -898,27 +867,20 @@ __global__ __launch_bounds__(512 / NSUB, 1) void relattn_bwd_fused_kernel(FusedP
             atomicAdd(p.d_rrb + h * 64 + 16 * eq + l, c);
         }
     }
-    {
+    if (kok) {
         const float fk = 1.f / p.scale_log2e, fv = 1.f / p.scale;      // dK was accumulated against scale*log2(e)*Qw, dV against scale*dO
+        const size_t srow = (size_t)(Pw + r - p0);
+        bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
+        bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
 #pragma unroll
-        for (int kb = 0; kb < NSUB; kb++) {
-            if (kok[kb]) {
-                const size_t srow = (size_t)(Pw + 32 * kb + r - p0);
-                bf16_t* dkp = p.dk + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
-                bf16_t* dvp = p.dv + (size_t)b * p.dkv_bs + srow * p.dkv_rs + (size_t)h * 64;
+        for (int e = 0; e < 2; e++) {
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-#pragma unroll
-                    for (int grp = 0; grp < 4; grp++) {
-                        const int e0 = 32 * e + 8 * grp + 4 * hh;
-                        const u32x2 wk = {pack2bf(ak[kb][e][4 * grp] * fk, ak[kb][e][4 * grp + 1] * fk),
-                                          pack2bf(ak[kb][e][4 * grp + 2] * fk, ak[kb][e][4 * grp + 3] * fk)};
-                        const u32x2 wv = {pack2bf(av[kb][e][4 * grp] * fv, av[kb][e][4 * grp + 1] * fv),
-                                          pack2bf(av[kb][e][4 * grp + 2] * fv, av[kb][e][4 * grp + 3] * fv)};
-                        *reinterpret_cast<u32x2*>(dkp + e0) = wk;
-                        *reinterpret_cast<u32x2*>(dvp + e0) = wv;
-                    }
-                }
+            for (int grp = 0; grp < 4; grp++) {
+                const int e0 = 32 * e + 8 * grp + 4 * hh;
+                const u32x2 wk = {pack2bf(ak[e][4 * grp] * fk, ak[e][4 * grp + 1] * fk), pack2bf(ak[e][4 * grp + 2] * fk, ak[e][4 * grp + 3] * fk)};
+                const u32x2 wv = {pack2bf(av[e][4 * grp] * fv, av[e][4 * grp + 1] * fv), pack2bf(av[e][4 * grp + 2] * fv, av[e][4 * grp + 3] * fv)};
+                *reinterpret_cast<u32x2*>(dkp + e0) = wk;
+                *reinterpret_cast<u32x2*>(dvp + e0) = wv;
             }
         }
     }
@@ -1085,9 +1047,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&relattn_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -1106,9 +1066,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     p.scale = scale; p.scale_log2e = scale * LOG2E;
     {
         mxl_kt::Scope kt(MXL_KT_RELATTN_FUSED, s);
-        static const int nsub = getenv("MXL_FUSED_NSUB") ? atoi(getenv("MXL_FUSED_NSUB")) : MXL_FUSED_NSUB_DEFAULT;
-        if (nsub == 2) hipLaunchKernelGGL(relattn_bwd_fused_kernel<2>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(256), SMEM, s, p);
-        else hipLaunchKernelGGL(relattn_bwd_fused_kernel<1>, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
+        hipLaunchKernelGGL(relattn_bwd_fused_kernel, dim3((Kc + KBLK - 1) / KBLK, H, B), dim3(512), SMEM, s, p);
     }
     MXL_LAUNCH_CHECK();
     if (defer_finish) return MXL_OK;
