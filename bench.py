@@ -652,10 +652,23 @@ def cpu_baseline_train(wl, T, M):
     t1 = _timed_cpu_steps(one, 3, CPU_BUDGET_S)
     a, b = sum(t0) / len(t0), sum(t1) / len(t1)
     t_full = a + L_full * max(b - a, 1e-9)
-    return {'value': T / t_full, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'B=1 x T={T} (M={M}) fp32 train steps (fwd+bwd+clip+AdamW) after 1 warm-up: {len(t1)} steps of a 1-layer '
-                      f'model ({b:.2f} s each) and {len(t0)} of its embedding+head part alone ({a:.2f} s); full step = '
-                      f't0 + {L_full} x (t1 - t0) = {t_full:.1f} s'}
+    out = {'value': T / t_full, 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'extrapolated': True, 'layers_timed': 1, 'layers_full': L_full,
+           'sample': f'B=1 x T={T} (M={M}) fp32 train steps (fwd+bwd+clip+AdamW) after 1 warm-up: {len(t1)} steps of a 1-layer '
+                     f'model ({b:.2f} s each) and {len(t0)} of its embedding+head part alone ({a:.2f} s); full step = '
+                     f't0 + {L_full} x (t1 - t0) = {t_full:.1f} s'}
+    if L_full > 1:
+        # the extrapolation's one assumption -- every layer costs the same -- checked once: the second layer of a 2-layer model against
+        # the first (one timed step after a warm-up; a 12-layer step is ~80 s and would not fit the bench's time budget)
+        del one, m, opt
+        two, m2, opt2 = make(2)
+        t2 = _timed_cpu_steps(two, 1, 2.5 * CPU_BUDGET_S)
+        c = sum(t2) / len(t2)
+        out['layers_timed'] = 2
+        out['per_layer_s'] = [round(b - a, 3), round(c - b, 3)]
+        out['second_layer_over_first'] = round((c - b) / max(b - a, 1e-9), 3)
+        out['sample'] += f'; 2-layer model {c:.2f} s: second layer {c - b:.2f} s against {b - a:.2f} s for the first'
+    return out
 
 
 def cpu_baseline_decode(Tp, M):

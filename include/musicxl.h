@@ -37,9 +37,20 @@ const char* mxl_error_string(int code);
 #define MXL_GEMM_OUT_F32_ATOMIC 0x02  /* C is f32, atomicAdd (required when ksplits > 1)         */
 #define MXL_GEMM_BIAS           0x04  /* + bias[n]                                               */
 #define MXL_GEMM_RELU           0x08  /* max(.,0)            (CoreNet.1)                         */
-#define MXL_GEMM_DROPOUT        0x10  /* inverted dropout with the (seed, site, m*N+n) keep-mask */
+#define MXL_GEMM_DROPOUT        0x10  /* inverted dropout.  Alone or with BIAS: the (seed, site, m*N+n) keep-mask of mxl_dropout_bf16
+                                         (dropout_keep: a backward pass may regenerate it).  Together with MXL_GEMM_RELU (the FFN's
+                                         hidden activations) a DIFFERENT mask: one hash per pair of elements (m, n), (m, n + 1),
+                                         n even, a 16-bit decision each, the drop probability quantised to 2^-16.  Nothing may
+                                         regenerate that one: the backward takes it from the saved bits (MXL_GEMM_SAVE_RELU_MASK)
+                                         or from the zeros of the stored activations */
 #define MXL_GEMM_RELU_BWD       0x20  /* C = aux[m][n] > 0 ? acc : 0  (backward through relu+dropout) */
 #define MXL_GEMM_ADD_AUX        0x40  /* C = epilogue(acc) + aux[m][n]  (residual add after bias/dropout)  */
+/* Compute units to leave free of the persistent GEMM grids (0 .. 128; default 0): they launch one workgroup per remaining CU.  For
+ * data-parallel training: RCCL's reduction kernels run beside the backward on another stream, and a grid that occupies every CU for its
+ * whole duration leaves them nowhere to start until it ends (symbolic_music_generation_amd/dist.py sets it from MXL_RESERVE_CUS when
+ * the process group has more than one rank).  Process-wide, not stream-ordered: set it between steps. */
+int mxl_set_reserved_cus(int k);
+
 /* The relu (+dropout) mask of C as bits instead of the bf16 activations, for the backward through CoreNet.1 / CoreNet.2:
  *   MXL_GEMM_SAVE_RELU_MASK  (with BIAS | RELU [| DROPOUT]): also writes, through `aux`, one bit per output element (> 0)
  *   MXL_GEMM_RELU_BWD_BITS   C = bit ? alpha * acc : 0, bits read through `aux` (the buffer a SAVE call of the same M, N filled)
@@ -160,8 +171,11 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
  * Round 4: the attention backward as ONE pass over the score cells (dh = 64, T % 32 == 0, M % 256 == 0, Kc % 32 == 0;
  * MXL_EUNSUPPORTED otherwise -- use mxl_relattn_bwd + mxl_relattn_drd).  Same gradients as that pair, no dg tensor:
  *   a workgroup owns 256 keys of one (sequence, head): dk, dv written once; d_rd accumulated on chip per 32-distance block and
- *   added with float atomics (d_rd (M, drd_ld) f32, +=); the partial dq of every (query tile, key block) pair goes to an fp32
- *   slab in `ws` (mxl_relattn_bwd_fused_ws_bytes) and a finishing kernel sums a query's slabs and rounds dq to bf16 once.
+ *   added with float atomics (d_rd (M, drd_ld) f32, +=); the partial dq of every (query tile, key block) pair goes to a
+ *   slab in `ws` (mxl_relattn_bwd_fused_ws_bytes bytes, opaque) and a finishing kernel sums a query's slabs in fp32 and rounds dq
+ *   to bf16 once.  The slabs are bf16 in the shipped build: each (query, key block) partial is rounded to bf16 before that sum,
+ *   at most M / 256 + 1 roundings per dq element (fp32 slabs: build with -DMXL_SLAB_BF16=0; the 12-layer gradient errors are the
+ *   same to four digits either way).
  *   d_r_w_bias, d_r_r_bias (H, 64) f32 are accumulated (+=), each with its own gradient (no fix-up pass).
  * Zero memories (Kc < M + T; musicnlp/models/transformer_xl.py:163-171 calls the model without mems, so upstream init_mems
  * supplies zeros): the key positions below the first stored one have k = v = 0 and exist only as distances.  Their part of dq
@@ -169,17 +183,16 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
  * (required then), and their part of d_rd is owed by the caller: mxl_relattn_drd_phantom.  With Kc == M + T oph / mph are unused.
  * `delta` (B,H,T) f32 scratch is written.  dq_rs, dq_bs multiples of 8.
  * defer_finish != 0: the slab sum is left to the caller (mxl_relattn_dq_finish, same ws / oph / mph / lse / delta / dq / d_r_r_bias
- * arguments: with oph it also adds the phantom cells' part of d_r_r_bias, the column sums of their dq term; d_r_r_bias may be NULL) --
- * it depends on nothing but this call and is HBM-bound, so the caller may run it on another stream beside
- * mxl_relattn_drd_phantom. */
+ * arguments: with oph it also adds the phantom cells' part of d_r_r_bias, the column sums of their dq term; d_r_r_bias may be NULL).
+ * dq and d_r_r_bias are complete only after it. */
 size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M);
 int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                           const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
-                          const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
+                          const void* oph, const float* mph, void* ws, int B, int T, int H, int dh, int M, int Kc,
                           long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
                           long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, int defer_finish, void* stream);
-int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
+int mxl_relattn_dq_finish(const void* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
                           float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs, long long dq_bs,
                           int dq_rs, float scale, void* stream);
 /* mxl_relattn_fwd_phantom with a choice of which phantom cells enter oph: oph_all = 0 is mxl_relattn_fwd_phantom (the

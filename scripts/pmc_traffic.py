@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the translation units that hold the kernels of bench.py's roofline group: their hash goes into the record, and bench.py reports
 # the recorded traffic only while it still matches the sources (a changed kernel must be re-measured)
-GROUP_SOURCES = {'train': ['relattn_bwd_fused.hip', 'relattn_drd_phantom.hip'], 'reformer': ['gemm.hip'], 'decode': ['decode.hip']}
+GROUP_SOURCES = {'train': ['relattn_bwd_fused.hip', 'relattn_drd_phantom.hip', 'relattn_fwd.hip'], 'reformer': ['gemm.hip'], 'decode': ['decode.hip']}
 
 
 def sources_sha16(kind):

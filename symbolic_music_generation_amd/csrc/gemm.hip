@@ -137,8 +137,9 @@ __device__ __forceinline__ void epilogue_vals(const GemmP& p, const int flags, c
                 for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
             }
             if (flags & MXL_GEMM_DROPOUT) {
-                // 32-bit element index (host check: M * N <= 2^32): the same decisions as dropout_keep's 64-bit form, which the
-                // stand-alone dropout / LayerNorm kernels use when they regenerate a mask
+                // 32-bit element index (host check: M * N <= 2^32).  WITHOUT relu: the same decisions as dropout_keep's 64-bit form,
+                // which the stand-alone dropout / LayerNorm kernels use when they regenerate a mask.  WITH relu: a mask of its own
+                // (below; include/musicxl.h, MXL_GEMM_DROPOUT) that nothing regenerates
                 // dropout_keep32(seed, site, i0 + r) with the index spread of the quad's four elements formed from ONE multiply:
                 // (i0 + r) * C = i0 * C + r * C (mod 2^32) -- the same masks, 9 quarter-rate integer multiplies per quad instead of 12
                 const uint32_t i0 = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
@@ -865,6 +866,11 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(GemmP p) {
 
 }  // namespace
 
+// Compute units the persistent GEMM grids (gemm_nt256_kernel, gemm_tt256_kernel: one 512-thread workgroup holding most of a CU's LDS
+// for the whole launch) may occupy: all of them, minus what the caller set aside with mxl_set_reserved_cus -- under data parallelism
+// RCCL's reduction kernels run on another stream beside the backward, and a grid that holds every CU for its whole duration leaves
+// them nowhere to start until it ends.
+static int g_reserved_cus = 0;
 static int gemm_n_cu() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -872,7 +878,13 @@ static int gemm_n_cu() {
         n_cu = (hipGetDevice(&dev) == hipSuccess &&
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
     }
-    return n_cu;
+    const int left = n_cu - g_reserved_cus;
+    return left >= 8 ? left : 8;
+}
+extern "C" int mxl_set_reserved_cus(int k) {
+    MXL_CHECK_ARG(k >= 0 && k <= 128);
+    g_reserved_cus = k;
+    return MXL_OK;
 }
 // BN = 256 or 192 for the large-tile NT kernel: whichever wastes less of the chip (rounds of one tile per CU x tile width)
 static bool nt256_use192(int M, int N) {
@@ -1006,16 +1018,13 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         K >= 8192 && (long long)K * lda < (1ll << 31) && (long long)K * ldb < (1ll << 31) && ((uintptr_t)C % 16) == 0 &&
         !getenv("MXL_GEMM_NO_TT256")) {
         static bool attr_tt = false;
-        static int n_cu_tt = 256;
         if (!attr_tt) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tt256_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
             if (e != hipSuccess) return (int)e;
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) == hipSuccess &&
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu_tt = cus;
             attr_tt = true;
         }
+        const int n_cu_tt = gemm_n_cu();
         p.tiles_m = M / 256; p.tiles_n = N / 256;
         const int ntile = p.tiles_m * p.tiles_n;
         int ks = n_cu_tt / ntile;

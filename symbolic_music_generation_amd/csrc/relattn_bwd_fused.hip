@@ -976,7 +976,9 @@ __global__ __launch_bounds__(256) void relattn_dq_finish_kernel(FinP p) {
                     const int i = i_[k];
                     if (p.oph) {
                         const size_t sidx = ((size_t)b * p.H + (c >> 3)) * p.T + i;
-                        const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(p.mph[sidx] - p.lse[sidx] * LOG2E);
+                        // (exponent clamped: a query with no phantom cell has oph = 0, mph = 0, and with lse below about -88 the
+                        // factor would overflow to inf -- inf * 0 = NaN in dq and, through the column sums, in d r_r_bias)
+                        const float f = -p.scale * p.delta[sidx] * __builtin_amdgcn_exp2f(fminf(p.mph[sidx] - p.lse[sidx] * LOG2E, 126.f));
                         const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.oph + (size_t)b * p.o_bs + (size_t)i * p.o_rs + c * 8);
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
@@ -1027,7 +1029,7 @@ extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, in
 extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                                      const float* r_r_bias, const void* out, const void* dout, const float* lse, float* delta,
                                      void* dq, void* dk, void* dv, float* d_rd, int drd_ld, float* d_r_w_bias, float* d_r_r_bias,
-                                     const void* oph, const float* mph, float* ws, int B, int T, int H, int dh, int M, int Kc,
+                                     const void* oph, const float* mph, void* ws, int B, int T, int H, int dh, int M, int Kc,
                                      long long q_bs, int q_rs, long long kv_bs, int kv_rs, int rd_rs, long long o_bs, int o_rs,
                                      long long dq_bs, int dq_rs, long long dkv_bs, int dkv_rs, float scale, int defer_finish,
                                      void* stream) {
@@ -1073,7 +1075,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
     return mxl_relattn_dq_finish(ws, oph, mph, lse, delta, dq, d_r_r_bias, B, T, H, dh, M, Kc, o_bs, o_rs, dq_bs, dq_rs, scale, stream);
 }
 
-extern "C" int mxl_relattn_dq_finish(const float* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
+extern "C" int mxl_relattn_dq_finish(const void* ws, const void* oph, const float* mph, const float* lse, const float* delta, void* dq,
                                      float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs,
                                      long long dq_bs, int dq_rs, float scale, void* stream) {
     MXL_CHECK_ARG(ws && lse && delta && dq && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);

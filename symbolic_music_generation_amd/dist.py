@@ -8,6 +8,8 @@ overlaps the backward of layers l-1..0.  xGMI is point-to-point (7 links/GPU): a
 hence no finer bucketing.  Averaging (1/world) is folded into the fused AdamW kernel (grad_scale).
 """
 import os
+import sys
+import time
 from typing import List, Optional, Tuple
 
 import torch
@@ -15,6 +17,7 @@ import torch.distributed as dist
 
 
 _FORCE = os.environ.get('MXL_DIST_FORCE') == '1'      # exercise the collective path on a single rank (hardware smoke test)
+_TRACE = os.environ.get('MXL_DIST_TRACE') == '1'      # print the host time spent issuing / waiting for the all-reduces
 
 
 def is_dist() -> bool:
@@ -93,6 +96,14 @@ class GradSync:
         if self.dtype not in ('bf16', 'fp32'):
             raise ValueError(f'gradient exchange dtype {self.dtype!r}: bf16 or fp32')
         self._stage = {}
+        self.host_s = {'issue': 0.0, 'wait': 0.0, 'calls': 0, 'steps': 0}
+        # Compute units left free of the persistent GEMM grids while a collective may be in flight (MXL_RESERVE_CUS, default 0): those
+        # grids hold every CU for a whole launch (~0.2-0.7 ms), so RCCL's reduction kernels -- issued on their own stream right after
+        # a layer's backward is enqueued -- could not start beside them.  Only when there is a collective to overlap.
+        self.reserved_cus = int(os.environ.get('MXL_RESERVE_CUS', '0') or 0)
+        if self.reserved_cus and is_dist() and torch.cuda.is_available() and getattr(engine, 'dev', torch.device('cpu')).type == 'cuda':
+            from . import ops
+            ops.set_reserved_cus(self.reserved_cus)
 
     def _issue(self, lo: int, hi: int):
         G = self.engine.G
@@ -109,17 +120,32 @@ class GradSync:
     def layer_done(self, l: int):
         if not is_dist():
             return
+        t = time.perf_counter() if _TRACE else 0.0
         for lo, hi in self.per_layer[l]:
             self._issue(lo, hi)
+        if _TRACE:
+            self.host_s['issue'] += time.perf_counter() - t
+            self.host_s['calls'] += len(self.per_layer[l])
 
     def finish(self):
         if not is_dist():
             return
+        t = time.perf_counter() if _TRACE else 0.0
         for lo, hi in self.rest:
             self._issue(lo, hi)
+        t1 = time.perf_counter() if _TRACE else 0.0
         for work, buf, lo, hi in self.pending:
             work.wait()
             if buf is not None:
                 from . import ops
                 ops.cast_f32(buf, self.engine.G[lo:hi])
+        if _TRACE:
+            self.host_s['issue'] += t1 - t
+            self.host_s['calls'] += len(self.rest)
+            self.host_s['wait'] += time.perf_counter() - t1
+            self.host_s['steps'] += 1
+            if self.host_s['steps'] % 5 == 0 and rank() == 0:
+                n = self.host_s['steps']
+                print(f"[GradSync] host time per step: issue {1e3 * self.host_s['issue'] / n:.2f} ms over {self.host_s['calls'] / n:.0f} "
+                      f"all-reduce calls, wait {1e3 * self.host_s['wait'] / n:.2f} ms", file=sys.stderr, flush=True)
         self.pending = []

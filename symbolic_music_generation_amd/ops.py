@@ -241,6 +241,11 @@ def phantom_sum_applies(*, T, dh, M, Kc) -> bool:
             and os.environ.get('MXL_DG_RECOMPUTE', '1') != '0' and os.environ.get('MXL_NO_OPH') != '1')
 
 
+def set_reserved_cus(k: int) -> None:
+    """compute units the persistent GEMM grids leave free (mxl_set_reserved_cus; dist.GradSync sets it from MXL_RESERVE_CUS)"""
+    check(lib().mxl_set_reserved_cus(int(k)), 'mxl_set_reserved_cus')
+
+
 def fused_bwd_applies(*, T, dh, M, Kc, B=None, H=None) -> bool:
     """the shapes mxl_relattn_bwd_fused (and, with zero memories, mxl_relattn_drd_phantom) take -- one pass over the score cells, no
     dG tensor: the training shapes of every BASELINE config; anything else stays on relattn_bwd's three kernels.  B, H (optional):
@@ -460,16 +465,6 @@ def relattn_bwd(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, 
     return (lambda: None) if defer_drd else None
 
 
-_SIDE = {}
-
-
-def _side_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
-
-
 def relattn_bwd_fused_ws_numel(B, T, H, dh, M) -> int:
     """fp32 elements of the partial-dq slabs mxl_relattn_bwd_fused needs"""
     return int(lib().mxl_relattn_bwd_fused_ws_bytes(B, T, H, dh, M)) // 4
@@ -500,23 +495,12 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
     their part of d_rrb comes out of the dq finishing kernel."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     d = H * dh
-    # the slab sum (HBM-bound, 44 registers) and the phantom cells' dRd (MFMA / latency-bound) depend only on the fused pass, not on
-    # each other; run on two streams they did not overlap usefully (7.16 ms against 7.12 ms for the layer: the slab sum fills the
-    # chip by itself and the dRd kernel's small q + r_r_bias launch queued behind it), so the side stream is opt-in
-    overlap = Kc < M + T and os.environ.get('MXL_DQFIN_OVERLAP') == '1' and not torch.cuda.is_current_stream_capturing()
+    # (the slab sum on a side stream beside the phantom cells' dRd kernel measured 7.16 ms against 7.12 ms in sequence -- the HBM-bound
+    # sum fills the chip by itself -- and left dq / d_rrb incomplete until the deferred call: removed in round 5)
     check(lib().mxl_relattn_bwd_fused(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse), _p(delta),
                                       _p(dq), _p(dk), _p(dv), _p(d_rd), d_rd.stride(0), _p(d_rwb), _p(d_rrb), _p(oph), _p(mph), _p(ws),
                                       B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                                      float(scale), int(overlap), _stream()), 'mxl_relattn_bwd_fused')
-    done = None
-    if overlap:
-        main, side = torch.cuda.current_stream(), _side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            check(lib().mxl_relattn_dq_finish(_p(ws), _p(oph), _p(mph), _p(lse), _p(delta), _p(dq), _p(d_rrb), B, T, H, dh, M, Kc,
-                                              o_bs, o_rs, dq_bs, dq_rs, float(scale), _stream()), 'mxl_relattn_dq_finish')
-            done = torch.cuda.Event()
-            done.record(side)
+                                      float(scale), 0, _stream()), 'mxl_relattn_bwd_fused')
 
     def phantom():
         if Kc < M + T:
@@ -526,8 +510,6 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
                                                          _stream()), 'mxl_relattn_drd_phantom_prep')
             check(lib().mxl_relattn_drd_phantom(_p(ph), _p(delta), _p(d_rd), B, T, H, dh, M, d_rd.stride(0), _p(rd), int(rd_rs), Kc,
                                                 _stream()), 'mxl_relattn_drd_phantom')
-        if done is not None:
-            torch.cuda.current_stream().wait_event(done)
     if defer_drd:
         return phantom
     phantom()

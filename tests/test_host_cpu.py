@@ -231,3 +231,23 @@ def test_recorded_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
     (prof / 'r99_c3_pmc_traffic.json').write_text(json.dumps(rec))
     got, src = bench.pmc_traffic('c3', 64)
     assert got is None and 'STALE' in src
+
+
+def test_no_backward_path_regenerates_the_ffn_hidden_dropout_mask():
+    """MXL_GEMM_RELU | MXL_GEMM_DROPOUT (the FFN's hidden activations) draws a mask of its own -- one hash per element pair, 16-bit
+    decisions (include/musicxl.h, MXL_GEMM_DROPOUT) -- not mxl_dropout_bf16's keep-mask.  That is only sound while nothing regenerates
+    the mask of that site: the backward must take it from the saved bits or from the zeros of the stored activations.  Pin it: in the
+    engines the hidden-activation site (_site(l, 1) / the Reformer's ffn site) appears in exactly one call, the forward GEMM."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1] / 'symbolic_music_generation_amd'
+    xl = (root / 'xl_engine.py').read_text()
+    uses = [m.start() for m in re.finditer(r'self\._site\(l, 1\)', xl)]
+    assert len(uses) == 1, 'the FFN-hidden dropout site must be used by the forward GEMM only'
+    call = xl[xl.rfind('ops.', 0, uses[0]):uses[0]]
+    assert call.startswith('ops.gemm('), call[:40]
+    # the regenerating kernels (stand-alone dropout, LayerNorm backward, embedding backward) never name that site
+    for m in re.finditer(r'ops\.(dropout|ln_residual_bwd\w*|embed_bwd)\(', xl):
+        stmt = xl[m.start():xl.find('\n\n', m.start())]
+        assert '_site(l, 1)' not in stmt.split(')\n')[0]
+
