@@ -88,26 +88,34 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // 16 skewed fp16 reads of one 32-key block as genuine ds_read_u16 (the compiler would fuse the constant-offset reads into
 // ds_read_b64 at lane-dependent, mis-aligned addresses: 64-cycle replays each, SQ_LDS_UNALIGNED_STALL).  `base` is the LDS
 // byte address of column (r - 4*hh + 64 - 32*kb - 27) of this lane's row; register j reads column offset 27 - pat(j),
-// pat(j) = (j & 3) + 8 * (j >> 2).  Loads and their wait sit in ONE asm statement (hipcc does not count asm loads).
-__device__ __forceinline__ void skew_read16(uint32_t base, uint32_t (&u)[16]) {
-    asm volatile(
-        "ds_read_u16 %0, %16 offset:54\n\t"  "ds_read_u16 %1, %16 offset:52\n\t"  "ds_read_u16 %2, %16 offset:50\n\t"
-        "ds_read_u16 %3, %16 offset:48\n\t"  "ds_read_u16 %4, %16 offset:38\n\t"  "ds_read_u16 %5, %16 offset:36\n\t"
-        "ds_read_u16 %6, %16 offset:34\n\t"  "ds_read_u16 %7, %16 offset:32\n\t"  "ds_read_u16 %8, %16 offset:22\n\t"
-        "ds_read_u16 %9, %16 offset:20\n\t"  "ds_read_u16 %10, %16 offset:18\n\t" "ds_read_u16 %11, %16 offset:16\n\t"
-        "ds_read_u16 %12, %16 offset:6\n\t"  "ds_read_u16 %13, %16 offset:4\n\t"  "ds_read_u16 %14, %16 offset:2\n\t"
+// pat(j) = (j & 3) + 8 * (j >> 2).  hipcc does not count asm loads, so the waits are written here as well: both key blocks of a
+// tile are issued back to back (skew_issue16 for block 0, skew_issue16_w15 for block 1, which then waits for block 0's sixteen --
+// LDS returns in order), the second wait is lgkm_wait0().  Everything that consumes the registers is `asm volatile` (add_f16v), so
+// it stays behind the waits; compiler-issued LDS or scalar loads in between only make the counts more conservative.
+#define MXL_SKEW_READS                                                                                                        \
+        "ds_read_u16 %0, %16 offset:54\n\t"  "ds_read_u16 %1, %16 offset:52\n\t"  "ds_read_u16 %2, %16 offset:50\n\t"           \
+        "ds_read_u16 %3, %16 offset:48\n\t"  "ds_read_u16 %4, %16 offset:38\n\t"  "ds_read_u16 %5, %16 offset:36\n\t"           \
+        "ds_read_u16 %6, %16 offset:34\n\t"  "ds_read_u16 %7, %16 offset:32\n\t"  "ds_read_u16 %8, %16 offset:22\n\t"           \
+        "ds_read_u16 %9, %16 offset:20\n\t"  "ds_read_u16 %10, %16 offset:18\n\t" "ds_read_u16 %11, %16 offset:16\n\t"          \
+        "ds_read_u16 %12, %16 offset:6\n\t"  "ds_read_u16 %13, %16 offset:4\n\t"  "ds_read_u16 %14, %16 offset:2\n\t"           \
         "ds_read_u16 %15, %16\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
-          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
-        : "v"(base)
-        : "memory");
+#define MXL_SKEW_OPERANDS                                                                                                     \
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),               \
+          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])          \
+        : "v"(base)                                                                                                           \
+        : "memory"
+__device__ __forceinline__ void skew_issue16(uint32_t base, uint32_t (&u)[16]) {
+    asm volatile(MXL_SKEW_READS "s_nop 0" MXL_SKEW_OPERANDS);
 }
+__device__ __forceinline__ void skew_issue16_w15(uint32_t base, uint32_t (&u)[16]) {
+    asm volatile(MXL_SKEW_READS "s_waitcnt lgkmcnt(15)" MXL_SKEW_OPERANDS);
+}
+__device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // s + (float)h in ONE VALU issue (v_fma_mix_f32: f32 * 1.0 + f16 taken from the low half of `h16`)
-__device__ __forceinline__ float add_f16(float s, uint32_t h16) {
+__device__ __forceinline__ float add_f16v(float s, uint32_t h16) {
     float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(h16));
+    asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(h16));
     return r;
 }
 
@@ -119,7 +127,29 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return r;
 }
 
+// In-kernel stamps (diagnostic builds only: scripts/ab_build.sh relattn_fwd stamp -DMXL_STAMP; the shipped library has none).
+// Per wave, shader cycles between consecutive stamps are summed per segment and added to g_fwd_stamps at the end (scripts/stamp_fwd.py).
+#ifdef MXL_STAMP
+__device__ unsigned long long g_fwd_stamps[16];
+#define STAMP_DECL unsigned long long st_last, st_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; \
+    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); st_acc[i] += t_ - st_last; st_last = t_; }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_fwd_stamps[i_], st_acc[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 constexpr float RESCALE_THRESH = 8.0f;   // log2 units: accumulators are re-based when a score exceeds the reference by 2^8
+// The common path does not look for the maximum at all.  It exponentiates against the reference as it stands and keeps the block
+// when every row's sum of the new terms is at most 2^13 (no term is then more than 2^13 above the reference; fp32 sums and bf16
+// probabilities are scale-free, the range is what matters).  Otherwise -- an overflow to inf included -- and for as long as some
+// lane of the wave has no reference yet, the scores are computed again and take the path with the maximum, which moves the
+// reference exactly as before.  Per 64-key tile that removes 16 v_max3, the cross-half exchange (an LDS round trip) and the
+// per-lane decision: ~10 % of the tile's vector issues (round 5).
+constexpr float FAST_SUM_MAX = 8192.0f;
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
@@ -131,8 +161,12 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     char* sR = sV + G::V_BYTES;               // ring [256][DH]
     _Float16* sG = reinterpret_cast<_Float16*>(sR + G::R_BYTES);  // [4][32][GS] fp16
 
+    STAMP_DECL
     const int tid = threadIdx.x;
-    const int wid = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    // the wave index in a scalar register: everything derived from it (the wave's query range, which tiles it takes part in, which
+    // of its blocks need the mask) is then scalar arithmetic and scalar branches, not per-lane compares and exec juggling
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, r = l & 31, hh = l >> 5;
     int bx_, h, b;
     xcd_block(bx_, h, b);
     // longest-first: late query blocks see the most real keys (early ones mostly phantom distances), and they are dispatched
@@ -145,13 +179,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     // plus immediates: writes land at column 32*gb + 8*grp + 4*hh, the read of score (kb, j) at column r - jj + 64.
     _Float16* gW = sG + wid * 32 * GS + r * GS + 4 * hh;
     const _Float16* gR = sG + wid * 32 * GS + r * GS + r + 64 - 4 * hh;
-    // LDS byte address of column (r - 4hh + 64 - 27) for skew_read16 (key block kb subtracts 32 columns = 64 bytes)
+    // LDS byte address of column (r - 4hh + 64 - 27) for the skew reads (key block kb subtracts 32 columns = 64 bytes)
     const uint32_t gRb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)(gR - 27);
     f16x4 carry[4];   // block 0 of the previous tile (= block 2 of this one), kept in registers
-    // Rd ring fragments: slot = (16-aligned window base + r) & 255, so the XOR-swizzle term of its row depends on the lane only
-    int rswz[KS];
+    // Rd ring fragments: a 32-distance block starts at a multiple of 32, so its rows are slots (block & 255) + r without a wrap:
+    // lane constant (row r, swizzled chunk of k-step ks) + a scalar block offset
+    int rfr[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) rswz[ks] = (DH == 64) ? (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4) : ((2 * ks + hh) << 4);
+    for (int ks = 0; ks < KS; ks++)
+        rfr[ks] = r * G::ROWB + ((DH == 64) ? (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4) : ((2 * ks + hh) << 4));
 
     const bf16_t* kbase = p.k + (size_t)b * p.kv_bs + (size_t)h * DH;
     const bf16_t* vbase = p.v + (size_t)b * p.kv_bs + (size_t)h * DH;
@@ -190,65 +226,70 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     const int kt_lo = floordiv(p_lo, KT), kt_hi = floordiv(p_hi, KT);
 
     // ---- staging helpers -----------------------------------------------------------------------------------
-    u32x4 rk[G::NLD_K], rv[G::NLD_V], rr[G::NLD_K];
+    // The tile loop keeps one register set per image: the rows of tile t + 1 are requested at the top of tile t and stored behind
+    // its first barrier.  (A second set -- requests two tiles ahead -- moved the wait from the stores to the requests and cost 2 %:
+    // profiles/r05_fwd_notes.txt.)  The phantom loop, which needs Rd rows only, alternates rr[0] / rr[1].
+    typedef u32x4 stage_t[G::NLD_K];
+    stage_t rk, rv, rr[2];
     // K / V / Rd rows through buffer descriptors (wave-uniform base in scalar registers, 32-bit lane offset): rows below the first
-    // stored key (negative offset = huge unsigned) and past the last one fall outside num_records and read as zero -- upstream's zero
-    // memories -- without a branch, a select or 64-bit lane address arithmetic per load (the flat-pointer form spent ~15
-    // instructions and an exec-masked branch on each of the six loads at the top of every tile)
+    // stored key (negative offset = huge unsigned), past the last one, and Rd rows outside [0, M) fall outside num_records and read
+    // as zero -- upstream's zero memories for K / V, distances the mask removes for Rd -- without a branch, a select or a clamp.
+    // A thread's chunks never change: its global offsets are lane constants plus a scalar (tile start x row stride), its LDS
+    // addresses lane constants (the ring adds a scalar 64-row offset: a 64-distance chunk starts at a multiple of 64 and does not
+    // wrap, and the swizzle term depends on the row's low bits only) -- one vector add per load, none per store (round 5; the
+    // first form rebuilt row, chunk, clamp and swizzle for each of the six loads and six stores of every tile)
     const unsigned kv_bytes = (unsigned)(((long long)(p.Kc - 1) * p.kv_rs + DH) * 2);
+    const unsigned rd_bytes = (unsigned)(((long long)(M - 1) * p.rd_rs + DH) * 2);
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)kv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)kv_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, -1, 0x00020000);
-    auto load_kv = [&](int kt) {
-        const int P = kt * KT;
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, (int)rd_bytes, 0x00020000);
+    constexpr bool STG_ALL = (KT * G::CH) % 256 == 0;     // every thread has a chunk in every round
+    int kvo[G::NLD_K], rdo[G::NLD_K], kst[G::NLD_K], vst[G::NLD_K];
+#pragma unroll
+    for (int n = 0; n < G::NLD_K; n++) {
+        const int c = tid + n * 256;
+        const int row = c / G::CH, ch = c % G::CH;
+        kvo[n] = ((row - p0) * p.kv_rs + ch * 8) * 2;
+        rdo[n] = (row * p.rd_rs + ch * 8) * 2;
+        kst[n] = G::koff(row & (KT - 1), ch);
+        vst[n] = G::voff(row & (KT - 1), ch * 16);
+    }
+    auto load_kv = [&](stage_t& dk, stage_t& dv, int P) __attribute__((always_inline)) {      // the 64 key rows from position P
+        const int so = P * p.kv_rs * 2;
 #pragma unroll
         for (int n = 0; n < G::NLD_K; n++) {
-            const int c = tid + n * 256;
-            const int row = c / G::CH, ch = c % G::CH;
-            const int srow = P + row - p0;
-            if (KT * G::CH % 256 == 0 || c < KT * G::CH) {
-                const int off = (srow * p.kv_rs + ch * 8) * 2;
-                rk[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, off, 0, 0));
-                rv[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0));
+            if (STG_ALL || tid + n * 256 < KT * G::CH) {
+                dk[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, kvo[n] + so, 0, 0));
+                dv[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, kvo[n] + so, 0, 0));
             } else {
-                rk[n] = u32x4{0u, 0u, 0u, 0u}; rv[n] = u32x4{0u, 0u, 0u, 0u};
+                dk[n] = u32x4{0u, 0u, 0u, 0u}; dv[n] = u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](const stage_t& sk, const stage_t& sv) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < G::NLD_K; n++) {
-            const int c = tid + n * 256;
-            if (c < KT * G::CH) {
-                const int row = c / G::CH, ch = c % G::CH;
-                *reinterpret_cast<u32x4*>(sK + G::koff(row, ch)) = rk[n];
-                *reinterpret_cast<u32x4*>(sV + G::voff(row, ch * 16)) = rv[n];
+            if (STG_ALL || tid + n * 256 < KT * G::CH) {
+                *reinterpret_cast<u32x4*>(sK + kst[n]) = sk[n];
+                *reinterpret_cast<u32x4*>(sV + vst[n]) = sv[n];
             }
         }
     };
-    // 64 Rd rows d in [dbase, dbase+64) -> registers / ring slots (d & 255); row index clamped (masked anyway)
-    auto load_r = [&](int dbase) {
+    // 64 Rd rows d in [dbase, dbase+64), dbase a multiple of 64 -> registers / ring slots (d & 255)
+    auto load_r = [&](stage_t& dst, int dbase) __attribute__((always_inline)) {
+        const int so = dbase * p.rd_rs * 2;
 #pragma unroll
         for (int n = 0; n < G::NLD_K; n++) {
-            const int c = tid + n * 256;
-            const int row = c / G::CH, ch = c % G::CH;
-            int d = dbase + row;
-            d = d < 0 ? 0 : (d > M - 1 ? M - 1 : d);
-            if (KT * G::CH % 256 == 0 || c < KT * G::CH)
-                rr[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (d * p.rd_rs + ch * 8) * 2, 0, 0));
-            else rr[n] = u32x4{0u, 0u, 0u, 0u};
+            if (STG_ALL || tid + n * 256 < KT * G::CH)
+                dst[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, rdo[n] + so, 0, 0));
+            else dst[n] = u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto store_r = [&](int dbase) {
+    auto store_r = [&](const stage_t& src, int dbase) __attribute__((always_inline)) {
+        char* ring = sR + (dbase & 255) * G::ROWB;
 #pragma unroll
-        for (int n = 0; n < G::NLD_K; n++) {
-            const int c = tid + n * 256;
-            if (c < KT * G::CH) {
-                const int row = c / G::CH, ch = c % G::CH;
-                const int slot = (dbase + row) & 255;
-                *reinterpret_cast<u32x4*>(sR + G::koff(slot, ch)) = rr[n];
-            }
-        }
+        for (int n = 0; n < G::NLD_K; n++)
+            if (STG_ALL || tid + n * 256 < KT * G::CH) *reinterpret_cast<u32x4*>(ring + kst[n]) = src[n];
     };
 
     // zero the V pad columns once (DH < 32): tr-reads of O^T rows >= DH must see zeros
@@ -260,12 +301,56 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     // Online softmax with a LAZY reference: every accumulated quantity is relative to m_run (log2 units), which is only
     // moved when a new score exceeds it by RESCALE_THRESH (or when it is still unset = NEG_BIG).  -m_run is kept in 16
     // registers (`cinit`) and enters the score for free as the C operand of the first MFMA of each chain, so a score costs
-    // one v_fma_mix (S + BD), half a v_max3, one v_exp and one add.  Both lanes of a query (hh = 0/1) see the same merged
-    // maximum and therefore take identical decisions.
+    // one v_fma_mix (S + BD), one v_exp and one add (FAST_SUM_MAX above; half a v_max3 more on the path that moves the
+    // reference).  Both lanes of a query (hh = 0/1) see the same merged maximum there and therefore take identical decisions.
     float m_run = NEG_BIG, l_run = 0.f;
+    bool all_set = false;            // wave-uniform: every lane has a reference
     f32x16 cinit;
 #pragma unroll
     for (int j = 0; j < 16; j++) cinit[j] = 0.f;
+    f32x16 o[EB];          // O^T accumulators; during the phantom loop they hold oph (v = 0 there: O itself stays 0)
+#pragma unroll
+    for (int e = 0; e < EB; e++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
+
+    // the path with the maximum, shared by both loops: x[0], x[1] hold the relative scores of two 32-cell blocks (masked cells
+    // NEG_BIG); moves the reference where a lane needs it, leaves x re-based, and `rescale_acc(alpha)` applied to the accumulators
+    // A lane's decision must depend on its own row only (changing a later token must leave earlier positions bit-identical, and
+    // a query shares its wave with later ones): after a failed first attempt the lanes that caused it (`bad`) move, the others
+    // pass through unchanged; without a first attempt (a lane of the wave still unset -- a matter of positions, not of data) the
+    // RESCALE_THRESH rule applies.
+    auto rebase = [&](f32x16 (&x)[2], auto&& rescale_acc, bool after_attempt, float rs_attempt) __attribute__((always_inline)) {
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) mx = max3(mx, x[kb][j], x[kb][j + 1]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bool unset = m_run == NEG_BIG;
+        const float rs_other = __shfl_xor(rs_attempt, 32, 64);               // the two lanes of a query decide together
+        const bool bad_q = !(rs_attempt <= FAST_SUM_MAX) || !(rs_other <= FAST_SUM_MAX);
+        const bool need = unset ? (mx > 0.5f * NEG_BIG) : (after_attempt ? bad_q : (mx > RESCALE_THRESH));
+        if (__any(need)) {               // rare after the first block: move the reference, re-base the accumulators, l and the scores
+            const float delta = need ? mx : 0.f;
+            const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+            if (need) m_run = (unset ? 0.f : m_run) + delta;
+            const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
+            l_run *= alpha;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { x[0][j] -= delta; x[1][j] -= delta; cinit[j] = neg; }
+            rescale_acc(alpha);
+        }
+        all_set = !__any(m_run == NEG_BIG);
+    };
+    auto exp_sum = [&](f32x16 (&x)[2]) __attribute__((always_inline)) {
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) { x[kb][j] = __builtin_amdgcn_exp2f(x[kb][j]); rs += x[kb][j]; }   // masked cells: exp2(NEG_BIG) = 0
+        return rs;
+    };
 
     // ---- phantom keys.  Key positions below the first stored tile (pz) are upstream's zero mems: k = v = 0, so such a key
     // contributes exp(BD) to the softmax denominator and nothing else, and BD depends only on the distance.  Instead of
@@ -274,11 +359,6 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     const int pz = floordiv(p0, KT) * KT;
     int kt_start = kt_lo;
     const int tk0 = G::eoff(4 * hh + ((l & 15) >> 2), 16 * ((l >> 4) & 1) + 4 * (l & 3));
-    f32x16 o[EB];          // O^T accumulators; during the phantom loop they hold oph (v = 0 there: O itself stays 0)
-#pragma unroll
-    for (int e = 0; e < EB; e++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) o[e][j] = 0.f;
     if (kt_lo * KT < pz) {
         kt_start = pz / KT;
         const int qi = iw0 + r;
@@ -286,86 +366,90 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
         // Rd rows in 64-distance chunks through the 256-row ring: chunk c + 1 is stored (from registers loaded an iteration earlier)
         // while chunk c is read -- different ring slots -- so ONE barrier per chunk covers both "c + 1 is complete" and "everybody is
         // done with c" (the first form stored and read the same chunk between two barriers; an iteration is only 16 MFMAs per wave)
-        load_r(db0);
-        store_r(db0);
-        if (db0 + 64 <= M - 1) load_r(db0 + 64);
+        // Requests run three chunks ahead of the reads (two alternating register sets: chunk c + 3 is requested in iteration c into
+        // the set chunk c + 1 was just stored from).  Every iteration requests and stores -- chunks past M - 1 read
+        // as zeros through the descriptor and land in ring slots nobody reads any more -- so hipcc's counted waits stay exact.
+        load_r(rk, db0);
+        load_r(rr[1], db0 + 64);
+        load_r(rr[0], db0 + 128);
+        store_r(rk, db0);
         __syncthreads();
-#pragma unroll 1
-        for (int db = db0; db <= M - 1; db += 64) {
-            if (db + 64 <= M - 1) store_r(db + 64);
-            if (db + 128 <= M - 1) load_r(db + 128);
+        auto chunk = [&](auto par_, int db) __attribute__((always_inline)) {
+            constexpr int NXT = 1 - decltype(par_)::value;      // chunk c + 1's set when c has parity par
+            STAMP(15)
+            store_r(rr[NXT], db + 64);
+            load_r(rr[NXT], db + 192);
+            STAMP(10)
             // the chunk's two 32-distance blocks side by side: both G chains issued before either block's softmax work
-            bool on[2], fullb[2];
+            bool on[2], fl[2];
 #pragma unroll
             for (int gb = 0; gb < 2; gb++) {
                 const int dblk = db + 32 * gb;
-                on[gb] = (iw0 < T) && !(dblk + 31 <= iw0 - pz || dblk > M - 1);        // wave-uniform: a phantom cell in this block?
-                fullb[gb] = (dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T);   // every cell phantom and in range
+                on[gb] = (iw0 < T) && !(dblk + 31 <= iw0 - pz || dblk > M - 1);        // a phantom cell in this block?
+                fl[gb] = on[gb] && (dblk >= iw0 + 31 - pz + 1) && (dblk + 31 <= M - 1) && (iw0 + 31 < T);   // every cell phantom and in range
             }
             if (on[0] || on[1]) {
                 f32x16 g[2];
-                bf16x8 ra[2][KS];
-#pragma unroll
-                for (int gb = 0; gb < 2; gb++) {
-                    const int slot = (db + 32 * gb + r) & 255;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                g[0] = cinit; g[1] = cinit;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++)
+                const char* rb = sR + (db & 255) * G::ROWB;      // a multiple of 64 rows: + 0..63 does not wrap
+                auto ph_scores = [&]() __attribute__((always_inline)) {
+                    bf16x8 ra[2][KS];
 #pragma unroll
                     for (int gb = 0; gb < 2; gb++)
-                        g[gb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[gb][ks]),
-                                                                        __builtin_bit_cast(mfma_bf16x8, qr[ks]), g[gb], 0, 0, 0);
-                float mx = NEG_BIG;
 #pragma unroll
-                for (int gb = 0; gb < 2; gb++) {
-                    const int dblk = db + 32 * gb;
-                    const bool fl = __builtin_amdgcn_readfirstlane((int)(on[gb] && fullb[gb])) != 0;
-                    if (!fl) {          // (a block that is off altogether is masked out cell by cell: d <= qi - pz or d > M - 1)
+                        for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(rb + gb * 32 * G::ROWB + rfr[ks]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    g[0] = cinit; g[1] = cinit;
 #pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                            const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
-                            g[gb][j] = valid ? g[gb][j] : NEG_BIG;
+                    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                        for (int gb = 0; gb < 2; gb++)
+                            g[gb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[gb][ks]),
+                                                                            __builtin_bit_cast(mfma_bf16x8, qr[ks]), g[gb], 0, 0, 0);
+#pragma unroll
+                    for (int gb = 0; gb < 2; gb++) {
+                        if (!fl[gb]) {          // (a block that is off altogether is masked out cell by cell: d <= qi - pz or d > M - 1)
+                            const int dblk = db + 32 * gb;
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {
+                                const int d = dblk + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                                const bool valid = (d >= qi - pz + 1) && (d <= M - 1) && (qi < T);
+                                g[gb][j] = valid ? g[gb][j] : NEG_BIG;
+                            }
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 16; j += 2) mx = max3(mx, g[gb][j], g[gb][j + 1]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const bool unset = m_run == NEG_BIG;
-                const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
-                if (__any(need)) {
-                    const float delta = need ? mx : 0.f;
-                    const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
-                    l_run *= alpha;
-                    if (need) m_run = (unset ? 0.f : m_run) + delta;
-                    const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) { g[0][j] -= delta; g[1][j] -= delta; cinit[j] = neg; }
+                };
+                auto rescale_oph = [&](float alpha) __attribute__((always_inline)) {
                     if (p.oph) {
 #pragma unroll
                         for (int e = 0; e < EB; e++)
 #pragma unroll
                             for (int j = 0; j < 16; j++) o[e][j] *= alpha;
                     }
-                }
+                };
+                const bool attempt = all_set;
+                bool precise = !attempt, bad = false;
                 float rs = 0.f;
-#pragma unroll
-                for (int gb = 0; gb < 2; gb++)
-#pragma unroll
-                    for (int j = 0; j < 16; j++) { g[gb][j] = __builtin_amdgcn_exp2f(g[gb][j]); rs += g[gb][j]; }   // exp2(NEG_BIG) = 0
+                if (attempt) {
+                    ph_scores();
+                    STAMP(11)
+                    rs = exp_sum(g);
+                    bad = !(rs <= FAST_SUM_MAX);
+                    precise = __any(bad);
+                }
+                if (precise) {
+                    ph_scores();
+                    rebase(g, rescale_oph, attempt, rs);
+                    rs = exp_sum(g);
+                }
                 l_run += rs;
+                STAMP(12)
                 // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
 #pragma unroll
                 for (int gb = 0; gb < 2; gb++) {
                     const int dblk = db + 32 * gb;
                     if (p.oph && on[gb] && (p.oph_all || (dblk & ~255) > iw0 + 31 - pz)) {
                         const int gq = l >> 4, li = l & 15, q4 = li >> 2, pp = li & 3;
-                        const char* rb = sR + (dblk & 255) * G::ROWB;      // a multiple of 32 rows: + 0..31 does not wrap
+                        const char* rbb = rb + gb * 32 * G::ROWB;
 #pragma unroll
                         for (int st = 0; st < 2; st++) {
                             const u32x4 pw = {pack2bf(g[gb][8 * st], g[gb][8 * st + 1]), pack2bf(g[gb][8 * st + 2], g[gb][8 * st + 3]),
@@ -379,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                                 if (DH == 64) {
                                     // one per-lane constant + immediates (relattn_bwd.hip, tk0): the +8 row and the second
                                     // 32-column half flip swizzle bits that do not depend on the lane for this pattern
-                                    const char* a0 = rb + tk0 + 16 * st * G::ROWB;
+                                    const char* a0 = rbb + tk0 + 16 * st * G::ROWB;
                                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a0 + 64 * e));
                                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(a0 + 8 * G::ROWB + 64 * (1 - e)));
                                     a = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -395,7 +479,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     }
                 }
             }
+            STAMP(13)
             __syncthreads();
+            STAMP(14)
+        };
+#pragma unroll 1
+        for (int db = db0; db <= M - 1; db += 128) {
+            chunk(std::integral_constant<int, 0>{}, db);
+            if (db + 64 > M - 1) break;
+            chunk(std::integral_constant<int, 1>{}, db + 64);
         }
     }
 
@@ -423,66 +515,53 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
     }
 
     // ---- prologue: first tile + its distance window [i0-P0-64, i0-P0+127] (wave w: dlo_w = i0+32w-P0-64, 96 rows)
+    // (every request issued before the first store: one round trip, not four)
     {
         const int P0 = kt_start * KT;
-        load_kv(kt_start);
-        store_kv();
-#pragma unroll 1
-        for (int q4 = 0; q4 < 3; q4++) {
-            const int dbase = i0 - P0 - 64 + 64 * q4;
-            load_r(dbase);
-            store_r(dbase);
-        }
+        const int dbase = i0 - P0 - 64;
+        stage_t w2;
+        load_kv(rk, rv, P0);
+        load_r(rr[0], dbase);
+        load_r(rr[1], dbase + 64);
+        load_r(w2, dbase + 128);
+        store_kv(rk, rv);
+        store_r(rr[0], dbase);
+        store_r(rr[1], dbase + 64);
+        store_r(w2, dbase + 128);
     }
     __syncthreads();
 
     bool have_ring = false;
+    auto rescale_o = [&](float alpha) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < EB; e++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) o[e][j] *= alpha;
+    };
 
+    // Requests and stores are unconditional: past the last tile the descriptors return zeros and the images are not read again.
 #pragma unroll 1
     for (int kt = kt_start; kt <= kt_hi; kt++) {
         const int P = kt * KT;
-        const bool more = kt < kt_hi;
-        if (more) {
-            load_kv(kt + 1);
-            load_r(i0 - (P + KT) - 64);   // next step's 64 new (lowest) distances
-        }
+        STAMP(15)
+        load_kv(rk, rv, P + KT);
+        load_r(rr[0], i0 - (P + KT) - 64);   // the next tile's 64 new (lowest) distances
+        STAMP(0)
         const int dmin_w = iw0 - P - (KT - 1), dmax_w = iw0 + 31 - P;
         const bool active = (dmax_w >= 0) && (dmin_w <= M - 1) && (iw0 < T);
         if (active) {
             const char* cK = sK;
             const char* cV = sV;
-            const int dlo = iw0 - P - 64;
-            // ---- S^T = K . Qw^T : two 32-key blocks
-            // (round 4) every K fragment of the tile first, a scheduling fence, then the two chains: left alone hipcc emits
-            // [one or two reads, wait, one MFMA] sixteen times -- an LDS round trip per MFMA with two waves per SIMD to hide it
-            f32x16 s[2];
-            {
-                bf16x8 ka[2][KS];
-#pragma unroll
-                for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                    for (int ks = 0; ks < KS; ks++)
-                        ka[kb][ks] = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
-                __builtin_amdgcn_sched_barrier(0);
-                s[0] = cinit; s[1] = cinit;      // = -m_run: the scores come out relative to the softmax reference
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-                    for (int kb = 0; kb < 2; kb++)
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ka[kb][ks]),
-                                                                        __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const int dlo = iw0 - P - 64;       // a multiple of 32
             // ---- G^T = Rd . Qr^T for the new distance blocks -> lane-private skew buffer (fp16)
-            auto gblock = [&](int gb, f16x4 (&dst)[4]) {
+            auto gblock = [&](int gb, f16x4 (&dst)[4]) __attribute__((always_inline)) {
                 f32x16 g;
 #pragma unroll
                 for (int j = 0; j < 16; j++) g[j] = 0.f;
-                const int slot = (dlo + 32 * gb + r) & 255;
+                const char* rb = sR + ((dlo + 32 * gb) & 255) * G::ROWB;
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + rfr[ks]);
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
                                                                 __builtin_bit_cast(mfma_bf16x8, qr[ks]), g, 0, 0, 0);
                 }
@@ -498,9 +577,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 bf16x8 ra[2][KS];
 #pragma unroll
                 for (int gb = 0; gb < 2; gb++) {
-                    const int slot = (dlo + 32 * gb + r) & 255;
+                    const char* rb = sR + ((dlo + 32 * gb) & 255) * G::ROWB;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(sR + slot * G::ROWB + rswz[ks]);
+                    for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(rb + rfr[ks]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 g0, g1;
@@ -513,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[1][ks]),
                                                                  __builtin_bit_cast(mfma_bf16x8, qr[ks]), g1, 0, 0, 0);
                 }
+                STAMP(1)
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++) {
                     const f32x4v v0 = {g0[4 * grp], g0[4 * grp + 1], g0[4 * grp + 2], g0[4 * grp + 3]};
@@ -529,20 +609,45 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 carry[grp] = b0[grp];
             }
             have_ring = true;
-            // ---- scores: (AC + BD) * scale, band mask, online softmax (lane = query).  Two explicit code paths on a
-            // scalar (readfirstlane) flag: hipcc otherwise if-converts the mask into per-element compares on every tile.
-            const bool full = __builtin_amdgcn_readfirstlane((int)((dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T))) != 0;
+            STAMP(2)
+            // ---- scores: S^T = K . Qw^T (two 32-key blocks, every K fragment of the tile first, a scheduling fence, then the two
+            // chains -- left alone hipcc emits [one or two reads, wait, one MFMA] sixteen times) + BD from the skew buffer: the
+            // chains run behind the skew writes above, the 32 skew reads are issued behind the chains, so the write -> read round
+            // trip of the lane-private buffer passes under the MFMAs.  Band mask on a scalar flag (two code paths: hipcc otherwise
+            // if-converts the mask into per-element compares on every tile).
+            const bool full = (dmin_w >= 0) && (dmax_w <= M - 1) && (iw0 + 31 < T);
             const int qi = iw0 + r;
-            float mx = NEG_BIG;
-            auto scores = [&](auto masked) {
+            f32x16 s[2];
+            auto tile_scores = [&](auto masked) __attribute__((always_inline)) {
                 constexpr bool MASKED = decltype(masked)::value;
+                {
+                    bf16x8 ka[2][KS];
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ks++)
+                            ka[kb][ks] = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
+                    __builtin_amdgcn_sched_barrier(0);
+                    s[0] = cinit; s[1] = cinit;      // = -m_run: the scores come out relative to the softmax reference
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                        for (int kb = 0; kb < 2; kb++)
+                            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ka[kb][ks]),
+                                                                            __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                STAMP(3)
+                uint32_t u0[16], u1[16];
+                skew_issue16(gRb, u0);
+                skew_issue16_w15(gRb - 64, u1);
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
-                    uint32_t bdu[16];
-                    skew_read16(gRb - 64 * kb, bdu);
+                    if (kb == 1) lgkm_wait0();
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        float val = add_f16(s[kb][j], bdu[j]);
+                        float val = add_f16v(s[kb][j], kb == 0 ? u0[j] : u1[j]);
                         if (MASKED) {
                             const int d = qi - P - (32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh);
                             const bool valid = (d >= 0) && (d <= M - 1) && (qi < T);
@@ -550,40 +655,26 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                         }
                         s[kb][j] = val;
                     }
-#pragma unroll
-                    for (int j = 0; j < 16; j += 2) mx = max3(mx, s[kb][j], s[kb][j + 1]);
                 }
             };
-            if (full) scores(std::false_type{}); else scores(std::true_type{});
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            {
-                const bool unset = m_run == NEG_BIG;
-                const bool need = unset ? (mx > 0.5f * NEG_BIG) : (mx > RESCALE_THRESH);
-                if (__any(need)) {               // rare after the first tile: move the reference, re-base O, l and the scores
-                    const float delta = need ? mx : 0.f;
-                    const float alpha = (need && !unset) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
-                    if (need) m_run = (unset ? 0.f : m_run) + delta;
-                    const float neg = (m_run == NEG_BIG) ? 0.f : -m_run;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) { s[0][j] -= delta; s[1][j] -= delta; cinit[j] = neg; }
-#pragma unroll
-                    for (int e = 0; e < EB; e++)
-#pragma unroll
-                        for (int j = 0; j < 16; j++) o[e][j] *= alpha;
-                }
-            }
+            auto scores = [&]() __attribute__((always_inline)) { if (full) tile_scores(std::false_type{}); else tile_scores(std::true_type{}); };
+            const bool attempt = all_set;
+            bool precise = !attempt, bad = false;
             float rs = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kb][j]);     // masked cells: exp2(NEG_BIG) = 0
-                    s[kb][j] = pv;
-                    rs += pv;
-                }
+            if (attempt) {
+                scores();
+                STAMP(4)
+                rs = exp_sum(s);
+                bad = !(rs <= FAST_SUM_MAX);
+                precise = __any(bad);
+            }
+            if (precise) {
+                scores();
+                rebase(s, rescale_o, attempt, rs);
+                rs = exp_sum(s);
             }
             l_run += rs;
+            STAMP(5)
             // ---- O^T += V^T . P^T
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
@@ -608,13 +699,16 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 }
             }
         }
+        STAMP(6)
         __syncthreads();                     // every wave is done reading this tile
-        if (more) {
-            store_kv();
-            store_r(i0 - (P + KT) - 64);
-        }
+        STAMP(7)
+        store_kv(rk, rv);
+        store_r(rr[0], i0 - (P + KT) - 64);
+        STAMP(8)
         __syncthreads();
+        STAMP(9)
     }
+    STAMP(15)
 
     // ---- epilogue: normalise, store O (lane = query, 4 consecutive e per register group) and LSE
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -639,6 +733,8 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
         if (hh == 0 && p.ph_rec)
             reinterpret_cast<float*>(p.ph_rec + (((size_t)b * p.H + h) * (size_t)(T >> 5) + (iw0 >> 5)) * 4352 + 4096)[r] = -lse2;
     }
+    STAMP(15)
+    STAMP_FLUSH
 }
 
 template <int DH>
@@ -661,6 +757,16 @@ int launch_fwd(const RelAttnP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MXL_STAMP
+extern "C" int mxl_debug_fwd_stamps(unsigned long long* host_out16) {
+    hipError_t e = hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(g_fwd_stamps), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stamps), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 static int relattn_fwd_launch(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
                               const float* r_r_bias, void* out, float* lse, int B, int T, int H, int dh, int M, int Kc,

@@ -284,6 +284,57 @@ def test_relattn_fwd(dev, B, T, H, dh, M, Kc, name):
     assert lerr < 6e-2, f'{name}: lse err {lerr}'
 
 
+@pytest.mark.parametrize('kind,Kc', [('ramp', 512), ('jump', 512), ('ramp-mem', 512 + 256), ('phantom-jump', 512)])
+def test_relattn_fwd_moving_softmax_reference(dev, kind, Kc):
+    """The forward exponentiates against its running reference without looking for the maximum and only falls back to the path
+    with the maximum when a row's new terms sum to more than 2^13 (relattn_fwd.hip FAST_SUM_MAX).  Scores that climb by tens of
+    nats from one 64-key tile to the next ('ramp'), one tile 150 nats above everything before it ('jump': exp2 overflows to inf on
+    the first attempt) and the same jump among the phantom distances ('phantom-jump', the positional term alone) must give the
+    dense result.  Inputs are exact in bf16 (powers of two on one coordinate), biases zero."""
+    from symbolic_music_generation_amd import ops
+    from oracle.relattn_ref import relattn_dense
+    B, T, H, dh, M = 1, 512, 2, 64, 256
+    d = H * dh
+    torch.manual_seed(5)
+    q = torch.zeros(B, T, H, dh); k = torch.zeros(B, Kc, H, dh); v = bf(torch.randn(B, Kc, H, dh))
+    rd = torch.zeros(M, H, dh)
+    q[..., 0] = 8.0                                           # score = 8 * k[..., 0] / 8 = k[..., 0]
+    q[..., 1] = 8.0                                           # positional score = rd[d, :, 1]
+    pos = torch.arange(Kc, dtype=torch.float32)
+    if kind.startswith('ramp'):
+        k[0, :, :, 0] = (bf(pos * 0.25))[:, None]            # + 16 nats per 64-key tile
+        rd[:, :, 1] = bf(torch.randn(M, H))
+    elif kind == 'jump':
+        k[0, :, :, 0] = bf(torch.randn(Kc, H))
+        k[0, 320:384, :, 0] += 150.0                          # one tile far above the reference built from the earlier ones
+        k[0] = bf(k[0])
+        rd[:, :, 1] = bf(torch.randn(M, H))
+    else:
+        k[0, :, :, 0] = bf(torch.randn(Kc, H))
+        rd[:, :, 1] = bf(torch.randn(M, H))
+        rd[160:192, :, 1] += 150.0                            # distances the early queries only reach on zero memories
+        rd = bf(rd)
+    qkv = torch.cat([torch.zeros(B, Kc, d), k.reshape(B, Kc, d), v.reshape(B, Kc, d)], dim=2)
+    qkv[:, Kc - T:, :d] = q.reshape(B, T, d)
+    qkv_d = qkv.to(dev).bfloat16()
+    rd_d = rd.reshape(M, d).to(dev).bfloat16()
+    zb = torch.zeros(H, dh, device=dev)
+    out = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=dev)
+    oph = torch.zeros(B, T, d, device=dev, dtype=torch.bfloat16); mph = torch.zeros(B, H, T, device=dev)
+    st = dict(B=B, T=T, H=H, dh=dh, M=M, Kc=Kc, q_bs=Kc * 3 * d, q_rs=3 * d, kv_bs=Kc * 3 * d, kv_rs=3 * d, rd_rs=d, o_bs=T * d, o_rs=d)
+    extra = dict(oph=oph, mph=mph) if kind == 'phantom-jump' else {}
+    ops.relattn_fwd(qkv_d[:, Kc - T:, :d], qkv_d[:, :, d:2 * d], qkv_d[:, :, 2 * d:], rd_d, zb, zb, out, lse, **st, **extra)
+    torch.cuda.synchronize()
+    ref_out, ref_lse = relattn_dense(q, k, v, rd, torch.zeros(H, dh), torch.zeros(H, dh), M)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    # the kernel folds scale * log2(e) into the bf16 query operand: a relative 2^-9 on every score
+    lerr = ((lse.cpu() - ref_lse).abs() / (ref_lse.abs() * 4e-3 + 6e-2)).max().item()
+    err = (out.float().cpu().view(B, T, H, dh) - ref_out).abs().max().item()
+    assert lerr < 1.0, f'{kind}: lse err ratio {lerr}'
+    assert err < 6e-2, f'{kind}: out err {err}'
+
+
 BWD_CASES = [
     (2, 128, 2, 64, 128, 128, 'square-nomem'),
     (1, 256, 2, 64, 128, 256 + 128, 'with-mem'),
