@@ -282,6 +282,9 @@ def train_leg(args, ranks: Ranks):
                     kms = kt[key][0] / kt[key][1]
                     kernels[key] = {'kernel': kname, 'ms': kms, 'launches_timed': kt[key][1], 'alg_flop': kflop,
                                     'frac': kflop / (kms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+                    if key == 'fwd':      # on SURVEY 8(d)'s forward FLOPs alone (without the phantom dQr product it also forms)
+                        kernels[key]['alg_flop_survey'] = fwd_alg
+                        kernels[key]['frac_survey'] = fwd_alg / (kms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
             bwd_sum = sum(kernels[k]['ms'] for k in group if k in kernels)
             out['roofline'] = {'kernel': desc,
                                'bound': 'mfma', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -333,8 +336,14 @@ def reformer_leg(args, ranks: Ranks, steps: int, warmup: int):
             sync.finish()
             eng.optimizer_step(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / world)
 
-    dt = timed_steps(ranks, step, steps, warmup, on_timed=lambda on: setattr(br, 'on', on and not args.no_roofline))
+    def on_timed(on):
+        br.on = on and not args.no_roofline
+        if not args.no_roofline:
+            ops.ktime_enable(on)
+
+    dt = timed_steps(ranks, step, steps, warmup, on_timed=on_timed)
     ops.gemm = orig_gemm
+    kt = ops.ktime_collect() if not args.no_roofline else {}
     out = None
     if rank == 0:
         d = cfg.hidden_size
@@ -359,6 +368,27 @@ def reformer_leg(args, ranks: Ranks, steps: int, warmup: int):
                                'traffic_unit': 'HBM bytes per launch (PMC), mean over the weight-gradient launches',
                                'traffic_source': src, 'avg_launch_ms': ms_total / len(br.ev), 'launches_timed': len(br.ev),
                                'share_of_step': ms_total * 1e-3 / dt}
+        if kt.get('chunk_bwd_kv', (0, 0))[1]:
+            # The chunked-attention kernels are gather-bound, not MFMA-bound: each is priced against its HBM floor.  Algorithmic
+            # bytes per launch = every operand and result once, in units of one (B, T, d) bf16 tensor: forward q, k, v in + out;
+            # query-owner backward q, k, v, dO, out in + dq out; key-owner backward q, k, v, dO, out in + dk, dv out.  In the LSH
+            # layers q and k are one tensor (one unit less); three local and three LSH layers per step, so the mean is used.
+            unit = B * T * d * 2.0
+            units = {'chunk_fwd': ('chunk_attn_fwd_kernel', 3.5), 'chunk_bwd_q': ('chunk_attn_bwd_q_kernel', 5.5),
+                     'chunk_bwd_kv': ('chunk_attn_bwd_kv_kernel', 6.5)}
+            ck = {}
+            for key, (kname, u) in units.items():
+                if kt.get(key, (0, 0))[1]:
+                    kms = kt[key][0] / kt[key][1]
+                    ck[key] = {'kernel': kname, 'avg_launch_ms': kms, 'launches_timed': kt[key][1], 'algorithmic_bytes': u * unit,
+                               'achieved': u * unit / (kms * 1e-3) / 1e9, 'frac': u * unit / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               'share_of_step': kt[key][0] * 1e-3 / dt}
+            worst = min(ck, key=lambda k_: ck[k_]['frac'])
+            out['roofline_hbm'] = {'kernel': ck[worst]['kernel'] + ': the kernel of this step furthest below its own roofline',
+                                   'bound': 'hbm', 'achieved': ck[worst]['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': ck[worst]['frac'], 'traffic': None, 'avg_launch_ms': ck[worst]['avg_launch_ms'],
+                                   'launches_timed': ck[worst]['launches_timed'], 'share_of_step': ck[worst]['share_of_step'],
+                                   'algorithmic_bytes_per_launch': ck[worst]['algorithmic_bytes'], 'kernels': ck}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_reformer(T)
     del model, eng, sync

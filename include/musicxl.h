@@ -520,7 +520,10 @@ int mxl_find_token(const void* ids, int ld_ids, int B, int T, long long token, i
 #define MXL_KT_ROWBIAS       5   /* add_rowbias (the q + r_r_bias operand of the dRd contraction) */
 #define MXL_KT_RELATTN_FUSED 6   /* relattn_bwd_fused_kernel (mxl_relattn_bwd_fused)    */
 #define MXL_KT_RELATTN_DQFIN 7   /* relattn_dq_finish_kernel (mxl_relattn_bwd_fused)    */
-#define MXL_KT_COUNT         8
+#define MXL_KT_CHUNK_FWD     8   /* chunk_attn_fwd_kernel (mxl_chunk_attn_fwd, T > one chunk window)              */
+#define MXL_KT_CHUNK_BWD_Q   9   /* chunk_attn_bwd_q_kernel (mxl_chunk_attn_bwd)                                   */
+#define MXL_KT_CHUNK_BWD_KV  10  /* chunk_attn_bwd_kv_kernel (mxl_chunk_attn_bwd)                                  */
+#define MXL_KT_COUNT         11
 int mxl_ktime_enable(int on);
 /* waits for every recorded event, adds each kernel's elapsed milliseconds into ms_sum[id] and its launch count into
  * launches[id] (HOST arrays of n >= MXL_KT_COUNT entries, overwritten), and forgets the recorded events */

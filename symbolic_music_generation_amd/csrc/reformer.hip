@@ -1031,9 +1031,14 @@ int launch_chunk(const ChunkP& p, int mode, hipStream_t s) {
     }
     const int NC = p.S / 64;
     if (mode == 0) {
+        mxl_kt::Scope kt(MXL_KT_CHUNK_FWD, s);
         hipLaunchKernelGGL((chunk_attn_fwd_kernel<DH>), dim3((NC + 1) / 2, p.H, p.B), dim3(256), G::SMEM, s, p);
     } else {
-        hipLaunchKernelGGL((chunk_attn_bwd_q_kernel<DH>), dim3((NC + 1) / 2, p.H, p.B), dim3(256), G::SMEM, s, p);
+        {
+            mxl_kt::Scope kt(MXL_KT_CHUNK_BWD_Q, s);
+            hipLaunchKernelGGL((chunk_attn_bwd_q_kernel<DH>), dim3((NC + 1) / 2, p.H, p.B), dim3(256), G::SMEM, s, p);
+        }
+        mxl_kt::Scope kt(MXL_KT_CHUNK_BWD_KV, s);
         hipLaunchKernelGGL((chunk_attn_bwd_kv_kernel<DH>), dim3(NC, p.H, p.B), dim3(256), kv_smem, s, p);
     }
     MXL_LAUNCH_CHECK();

@@ -57,7 +57,7 @@ def _cut(cutoffs: Sequence[int]):
     return n, arr
 
 
-KT_NAMES = ('fwd', 'delta', 'dq8', 'dkv', 'drd', 'rowbias', 'fused', 'dqfin')      # MXL_KT_* ids of include/musicxl.h
+KT_NAMES = ('fwd', 'delta', 'dq8', 'dkv', 'drd', 'rowbias', 'fused', 'dqfin', 'chunk_fwd', 'chunk_bwd_q', 'chunk_bwd_kv')   # MXL_KT_* ids of include/musicxl.h
 
 
 def ktime_enable(on: bool):
