@@ -374,6 +374,16 @@ int mxl_decode_bd(const void* qr, const void* rd, float* bd, int B, int H, int d
  * positional term for the whole batch (one mxl_gemm_bf16_batched per layer over heads); out (B, H*dh) bf16 */
 int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
                        void* out, const int* t_dev, int B, int H, int dh, int M, float scale, void* stream);
+/* The same with every (sequence, head) ring cut into `pieces` (1..8) workgroups -- for launches whose B * H workgroups would
+ * not fill the CUs evenly (a CU streams HBM at a fixed rate however many workgroups it holds: 384 rings on 256 CUs take the
+ * time of two).  Each piece runs the softmax over its slots with its own reference; the piece that finishes last merges the
+ * (o, max, sum) partials in piece order, so the result is reproducible.  The probabilities are rounded to bf16 relative to the
+ * piece's own maximum: outputs differ from mxl_relattn_decode's in the last bf16 bit at most.  ws: mxl_relattn_decode_split_ws_bytes
+ * bytes; arrived: B * H ints, zero before the first call (the kernel leaves them zero).  pieces = 1 is mxl_relattn_decode. */
+size_t mxl_relattn_decode_split_ws_bytes(int B, int H, int dh, int pieces);
+int mxl_relattn_decode_split(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
+                             void* out, const int* t_dev, int B, int H, int dh, int M, float scale, int pieces, float* ws,
+                             int* arrived, void* stream);
 /* next token from log-probs (B, ldl): repetition penalty over the ids already in the row (positions 0..*t_dev; HF's
  * RepetitionPenaltyLogitsProcessor, 1.0 = off), then greedy argmax (do_sample=0) or temperature -> top-k -> top-p ->
  * typical-p (HF's TypicalLogitsWarper, 1.0 = off) -> renormalise -> multinomial (do_sample=1), as HF's logits warpers with

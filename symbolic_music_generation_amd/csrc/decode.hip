@@ -73,11 +73,18 @@ __global__ void kv_fill_kernel(const bf16_t* qkv, bf16_t* kc, bf16_t* vc, int B,
     *reinterpret_cast<u32x4*>(vc + o) = *reinterpret_cast<const u32x4*>(row + 2 * d + c * 8);
 }
 
-// one workgroup per (head, batch row); dh = 8 * LPK, LPK lanes share one key row, 64/LPK keys per wave instruction
+// one workgroup per (head, batch row, ring piece); dh = 8 * LPK, LPK lanes share one key row, 64/LPK keys per wave instruction.
+// gridDim.z = NS pieces of the ring (round 5).  A CU streams HBM at ~24 GB/s however many workgroups it holds, so a launch of
+// B * H workgroups that is not a multiple of the CU count is as slow as its fullest CU: 384 rings (a lane's 32 sequences x 12
+// heads) on 256 CUs take the time of two rings (1 MB: 40.6 us) where 768 half-rings take that of 1.5 (profiles/r05_decode_notes.txt).
+// With NS > 1 every piece runs the whole kernel on its slots with its own softmax reference and leaves (o, max, sum) in `ws`; the
+// piece that arrives last (one counter per (sequence, head), reset by that piece for the next launch) merges them in piece
+// order -- a fixed order, so the result does not depend on who is last.  NS = 1 is the single-workgroup form, bit for bit as before.
 template <int DH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* kc, const bf16_t* vc,
                                                           const float* bd, const float* rwb,
-                                                          bf16_t* out, const int* t_dev, int B, int H, int M, float scale) {
+                                                          bf16_t* out, const int* t_dev, int B, int H, int M, float scale,
+                                                          float* ws, int* arrived) {
     constexpr int LPK = DH / 8;          // lanes per key row
     constexpr int KPW = 64 / LPK;        // keys per wave per iteration
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,6 +101,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     // mems: k = v = 0, so their score is the positional term alone and they add nothing to the output -- no K / V bytes are
     // read for them
     const int nvalid = t + 1 < M ? t + 1 : M;
+    // this piece's written slots [lo, hi) and never-written slots [plo, phi)
+    const int NS = gridDim.z, zi = blockIdx.z;
+    const int piece = NS > 1 ? ((((nvalid + NS - 1) / NS) + 31) & ~31) : nvalid;
+    const int lo = min(zi * piece, nvalid), hi = min(lo + piece, nvalid);
+    const int ppiece = (M - nvalid + NS - 1) / NS;
+    const int plo = min(nvalid + zi * ppiece, M), phi = min(plo + ppiece, M);
 
     float qw[8];
     {
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
             for (int u = 0; u < U; u++) {
                 const int s = s0 + u * 4 * KPW + ksub;
                 const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                kv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH)) : z;
+                kv[u] = (s < hi) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kb + (size_t)s * DH)) : z;
                 int dist = tm - s;
                 if (dist < 0) dist += M;
                 bv[u] = (s < M && c8 == 0) ? bdrow[dist] : 0.f;
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
 #pragma unroll
                 for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o, 64);
                 acc *= scale;
-                if (s < nvalid) {
+                if (s < hi) {
                     if (c8 == 0) sc[s] = acc;
                     mx = fmaxf(mx, acc);
                 }
@@ -156,18 +169,18 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
         // (Until round 5 both passes walked all M slots whatever the sequence length: at 1153 written slots of 2048 -- the mean over
         // the C5 generation -- the kernel took 35.7 us against 40.3 us with a full ring, i.e. it was bound by that loop, not by HBM.)
         constexpr int ST = 4 * KPW * U;
-        int s0 = wid * KPW;
-        if (s0 < nvalid) load_k(s0, kA, bA);
-        for (; s0 < nvalid; s0 += 2 * ST) {
-            if (s0 + ST < nvalid) load_k(s0 + ST, kB, bB);
+        int s0 = lo + wid * KPW;
+        if (s0 < hi) load_k(s0, kA, bA);
+        for (; s0 < hi; s0 += 2 * ST) {
+            if (s0 + ST < hi) load_k(s0 + ST, kB, bB);
             use_k(s0, kA, bA);
-            if (s0 + ST < nvalid) {
-                if (s0 + 2 * ST < nvalid) load_k(s0 + 2 * ST, kA, bA);
+            if (s0 + ST < hi) {
+                if (s0 + 2 * ST < hi) load_k(s0 + 2 * ST, kA, bA);
                 use_k(s0 + ST, kB, bB);
             }
         }
     }
-    for (int sp = nvalid + tid; sp < M; sp += 256) {      // the never-written slots: score = scale * BD[distance]
+    for (int sp = plo + tid; sp < phi; sp += 256) {      // the never-written slots: score = scale * BD[distance]
         int dist = tm - sp;
         if (dist < 0) dist += M;
         const float a = bdrow[dist] * scale;
@@ -181,20 +194,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
         for (int u = 0; u < U; u++) {
             const int s = s0 + u * 4 * KPW + ksub;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            vv[u] = (s < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH)) : z;
+            vv[u] = (s < hi) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vb + (size_t)s * DH)) : z;
         }
     };
-    if (wid * KPW < nvalid) load_v(wid * KPW, vA);
+    if (lo + wid * KPW < hi) load_v(lo + wid * KPW, vA);
     mx = wave_max(mx);
     if (lane == 0) wred[wid] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
     float sum = 0.f;
-    for (int s = tid; s < M; s += 256) {
+    for (int s = lo + tid; s < hi; s += 256) {
         const float pv = __expf(sc[s] - mx);
         sc[s] = pv;
         sum += pv;
     }
+    for (int s = plo + tid; s < phi; s += 256) sum += __expf(sc[s] - mx);      // (v = 0 there: only the denominator)
     sum = wave_sum(sum);
     if (lane == 0) wred[4 + wid] = sum;
     __syncthreads();
@@ -209,18 +223,18 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int s = s0 + u * 4 * KPW + ksub;
-                const float pv = (s < nvalid) ? bf2f(f2bf(sc[s])) : 0.f;
+                const float pv = (s < hi) ? bf2f(f2bf(sc[s])) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; j++) o[j] += pv * bf2f((bf16_t)vv[u][j]);
             }
         };
         constexpr int ST = 4 * KPW * U;
-        int s0 = wid * KPW;
-        for (; s0 < nvalid; s0 += 2 * ST) {          // (the never-written slots hold v = 0: nothing to add)
-            if (s0 + ST < nvalid) load_v(s0 + ST, vB);
+        int s0 = lo + wid * KPW;
+        for (; s0 < hi; s0 += 2 * ST) {          // (the never-written slots hold v = 0: nothing to add)
+            if (s0 + ST < hi) load_v(s0 + ST, vB);
             use_v(s0, vA);
-            if (s0 + ST < nvalid) {
-                if (s0 + 2 * ST < nvalid) load_v(s0 + 2 * ST, vA);
+            if (s0 + ST < hi) {
+                if (s0 + 2 * ST < hi) load_v(s0 + 2 * ST, vA);
                 use_v(s0 + ST, vB);
             }
         }
@@ -235,10 +249,43 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
         for (int j = 0; j < 8; j++) red[wid * DH + c8 * 8 + j] = o[j];
     }
     __syncthreads();
-    if (tid < DH) {
-        const float v = (red[tid] + red[DH + tid] + red[2 * DH + tid] + red[3 * DH + tid]) * inv;
-        out[(size_t)b * d + h * DH + tid] = f2bf(v);
+    if (NS == 1) {
+        if (tid < DH) {
+            const float v = (red[tid] + red[DH + tid] + red[2 * DH + tid] + red[3 * DH + tid]) * inv;
+            out[(size_t)b * d + h * DH + tid] = f2bf(v);
+        }
+        return;
     }
+    // ---- ring pieces: leave (o unnormalised, max, sum), the last arrival merges.  The pieces of a ring may sit on different XCDs
+    // (one L2 each): the partials travel as agent-scope (sc1) stores and loads and the counter as a relaxed agent-scope atomic, the
+    // stores waited for (vmcnt) before the workgroup's arrival is counted -- the pattern scripts/ubench/grid_barrier.hip measured;
+    // the compiler's release / acquire fences (buffer_wbl2 / buffer_inv of the whole L2) made a 30 us launch take 90.
+    float* wsp = ws + ((size_t)b * H + h) * NS * (DH + 2);
+    if (tid < DH)
+        __hip_atomic_store(wsp + zi * (DH + 2) + tid, red[tid] + red[DH + tid] + red[2 * DH + tid] + red[3 * DH + tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(wsp + zi * (DH + 2) + DH, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wsp + zi * (DH + 2) + DH + 1, wred[4] + wred[5] + wred[6] + wred[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(arrived + (size_t)b * H + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < DH) {
+        float m = -1e30f;
+        for (int k = 0; k < NS; k++) m = fmaxf(m, __hip_atomic_load(wsp + k * (DH + 2) + DH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float num = 0.f, den = 0.f;
+        for (int k = 0; k < NS; k++) {
+            const float a = __expf(__hip_atomic_load(wsp + k * (DH + 2) + DH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - m);
+            num += a * __hip_atomic_load(wsp + k * (DH + 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            den += a * __hip_atomic_load(wsp + k * (DH + 2) + DH + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out[(size_t)b * d + h * DH + tid] = f2bf(num / den);
+    }
+    if (tid == 0) __hip_atomic_store(arrived + (size_t)b * H + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // BD of one decode step (mxl_decode_bd): workgroup = (256 distances, head), wave = 64 distances x all (<= 64) batch rows x dh = 64:
@@ -535,16 +582,39 @@ extern "C" int mxl_decode_bd(const void* qr, const void* rd, float* bd, int B, i
     return MXL_OK;
 }
 
+static int relattn_decode_launch(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
+                                 void* out, const int* t_dev, int B, int H, int dh, int M, float scale, int pieces, float* ws,
+                                 int* arrived, void* stream);
+
 extern "C" int mxl_relattn_decode(const void* qkv, const void* kcache, const void* vcache, const float* bd,
                                   const float* r_w_bias, void* out, const int* t_dev, int B, int H,
                                   int dh, int M, float scale, void* stream) {
+    return relattn_decode_launch(qkv, kcache, vcache, bd, r_w_bias, out, t_dev, B, H, dh, M, scale, 1, nullptr, nullptr, stream);
+}
+
+extern "C" size_t mxl_relattn_decode_split_ws_bytes(int B, int H, int dh, int pieces) {
+    if (B <= 0 || H <= 0 || dh <= 0 || pieces < 1) return 0;
+    return (size_t)B * H * pieces * (dh + 2) * sizeof(float);
+}
+
+extern "C" int mxl_relattn_decode_split(const void* qkv, const void* kcache, const void* vcache, const float* bd,
+                                        const float* r_w_bias, void* out, const int* t_dev, int B, int H, int dh, int M, float scale,
+                                        int pieces, float* ws, int* arrived, void* stream) {
+    MXL_CHECK_ARG(pieces >= 1 && pieces <= 8);
+    if (pieces > 1) MXL_CHECK_ARG(ws && arrived);
+    return relattn_decode_launch(qkv, kcache, vcache, bd, r_w_bias, out, t_dev, B, H, dh, M, scale, pieces, ws, arrived, stream);
+}
+
+static int relattn_decode_launch(const void* qkv, const void* kcache, const void* vcache, const float* bd, const float* r_w_bias,
+                                 void* out, const int* t_dev, int B, int H, int dh, int M, float scale, int pieces, float* ws,
+                                 int* arrived, void* stream) {
     MXL_CHECK_ARG(qkv && kcache && vcache && bd && r_w_bias && out && t_dev && B > 0 && H > 0 && M > 0);
     const size_t shm = (size_t)M * 4 + 4 * 64 * 4;
     MXL_CHECK_ARG(shm <= 64 * 1024);
-    dim3 grid(H, B);
+    dim3 grid(H, B, pieces);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(DH) hipLaunchKernelGGL((decode_attn_kernel<DH>), grid, dim3(256), shm, s, (const bf16_t*)qkv, (const bf16_t*)kcache, \
-                                      (const bf16_t*)vcache, bd, r_w_bias, (bf16_t*)out, t_dev, B, H, M, scale)
+                                      (const bf16_t*)vcache, bd, r_w_bias, (bf16_t*)out, t_dev, B, H, M, scale, ws, arrived)
     switch (dh) {
         case 16: LAUNCH(16); break;
         case 32: LAUNCH(32); break;

@@ -43,6 +43,9 @@ class XLDecoder:
         self.qr = torch.empty(batch, d, **bf)
         self.slabs = torch.zeros(4, 64, d, device=dev, dtype=torch.float32)   # K-slice partials of the FFN output projection
         self.bd = torch.empty(batch, H, M, device=dev, dtype=torch.float32)
+        # ring pieces per (sequence, head): the attention launch fills every CU with the same number of bytes (ops.decode_ring_pieces)
+        self.pieces = ops.decode_ring_pieces(batch, H, M)
+        self.split = ops.relattn_decode_split_scratch(batch, H, dh, self.pieces, dev)
         self.tmp = torch.empty(batch, d, **bf)
         self.h1 = torch.empty(batch, d, **bf)
         self.a = torch.empty(batch, Fi, **bf)
@@ -127,7 +130,7 @@ class XLDecoder:
                 G(h_in, e._lw(l, 'dec_attn.qkv_net.weight'), self.qkv, B, 3 * d, d)
                 ops.kv_append(self.qkv, self.kc[l], self.vc[l], self.t_dev, rrb=rrb.reshape(-1), qr_out=self.qr)
             ops.relattn_decode(self.qkv, self.kc[l], self.vc[l], self.rd[l], e._lw(l, 'dec_attn.r_w_bias', e.P),
-                               rrb, self.av, self.t_dev, H, dh, self.qr, self.bd, qr_ready=True)
+                               rrb, self.av, self.t_dev, H, dh, self.qr, self.bd, qr_ready=True, split=self.split, pieces=self.pieces)
             G(self.av, e._lw(l, 'dec_attn.o_net.weight'), self.tmp, B, d, d)
             ops.ln_residual_fwd(self.tmp, h_in, e._lw(l, 'dec_attn.layer_norm.weight', e.P),
                                 e._lw(l, 'dec_attn.layer_norm.bias', e.P), self.h1, eps=c.layer_norm_epsilon)

@@ -558,9 +558,32 @@ def kv_fill(qkv, kc, vc, T):
     check(lib().mxl_kv_fill(_p(qkv), _p(kc), _p(vc), B, T, M, H * dh, dh, _stream()), 'mxl_kv_fill')
 
 
-def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf, scale=None, qr_ready=False):
+def decode_ring_pieces(B: int, H: int, M: int) -> int:
+    """workgroups per (sequence, head) ring of a decode step (mxl_relattn_decode_split).  With fewer rings than CUs a ring per
+    workgroup leaves CUs idle and every workgroup streaming 512 KB alone: two pieces up to 256 rings, four up to 96 (measured on
+    the C5 shape, scripts/perf_decode_attn.py: B = 4: 27.3 -> 14.4 us, B = 8: 28.4 -> 17.7, B = 16: 29.7 -> 25.0, B = 21: 31.8 -> 27.3;
+    from 384 rings on the pieces cost more than they balance: B = 32: 39.4 -> 42.7).  One piece for short rings.
+    MXL_DECODE_PIECES overrides."""
+    env = os.environ.get('MXL_DECODE_PIECES')
+    if env:
+        return max(1, min(8, int(env)))
+    if M < 1024 or B * H > 256:
+        return 1
+    return 4 if B * H <= 96 else 2
+
+
+def relattn_decode_split_scratch(B: int, H: int, dh: int, pieces: int, dev):
+    """(ws, arrived) of mxl_relattn_decode_split, or None for one piece"""
+    if pieces <= 1:
+        return None
+    n = int(lib().mxl_relattn_decode_split_ws_bytes(B, H, dh, pieces)) // 4
+    return torch.empty(n, device=dev, dtype=torch.float32), torch.zeros(B * H, device=dev, dtype=torch.int32)
+
+
+def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf, scale=None, qr_ready=False, split=None, pieces=1):
     """qr_buf (B, H*dh) bf16 and bd_buf (B, H, M) f32 are scratch: BD = (q + r_r_bias) . rd^T for the whole batch.
-    qr_ready: qr_buf already holds q + r_r_bias (written by kv_append)."""
+    qr_ready: qr_buf already holds q + r_r_bias (written by kv_append).  split = relattn_decode_split_scratch(...) with the same
+    `pieces`: the ring of every (sequence, head) goes to that many workgroups."""
     B, _, M, _ = kc.shape
     d = H * dh
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
@@ -571,6 +594,11 @@ def relattn_decode(qkv, kc, vc, rd, rwb, rrb, out, t_dev, H, dh, qr_buf, bd_buf,
     else:
         gemm_batched(qr_buf, rd, bd_buf, B, M, dh, lda=d, ldb=d, ldc=H * M, flags=GEMM_OUT_F32, batch=H, bdiv=1,
                      sA=(dh, 0), sB=(dh, 0), sC=(M, 0))
+    if split is not None and pieces > 1:
+        check(lib().mxl_relattn_decode_split(_p(qkv), _p(kc), _p(vc), _p(bd_buf), _p(rwb), _p(out), _p(t_dev), B, H, dh, M,
+                                             C.c_float(float(scale)), pieces, _p(split[0]), _p(split[1]), _stream()),
+              'mxl_relattn_decode_split')
+        return
     check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(bd_buf), _p(rwb), _p(out), _p(t_dev), B, H, dh, M,
                                    float(scale), _stream()), 'mxl_relattn_decode')
 

@@ -179,6 +179,69 @@ def test_decode_qkv_fused_equals_projection_plus_append(dev):
         assert torch.equal(kc2[:, :, untouched], kc0[:, :, untouched]) and not torch.equal(kc2[:, :, slot], kc0[:, :, slot])
 
 
+@pytest.mark.parametrize('B,H,dh,M,t,pieces', [(3, 2, 64, 512, 40, 2), (3, 2, 64, 512, 299, 4), (2, 3, 64, 512, 5000, 2),
+                                               (2, 2, 64, 512, 5000, 3), (5, 1, 64, 256, 0, 4), (2, 2, 32, 128, 77, 2),
+                                               (2, 2, 64, 2048, 1152, 8)])
+def test_decode_attention_ring_pieces(dev, B, H, dh, M, t, pieces):
+    """mxl_relattn_decode_split: every (sequence, head) ring cut into `pieces` workgroups, merged by the last arrival in piece
+    order.  Against fp64 single-query attention over the ring (written slots + zero memories) and against the one-piece kernel
+    (the probabilities are rounded to bf16 relative to the piece's maximum: last-bit differences only); two launches in a row
+    give identical bits (the arrival counters come back to zero, the merge order is fixed)."""
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd.ops import lib, _p, _stream, check
+    torch.manual_seed(B * 100 + t)
+    d = H * dh
+    kc = torch.randn(B, H, M, dh, device=dev).bfloat16(); vc = torch.randn(B, H, M, dh, device=dev).bfloat16()
+    nvalid = min(t + 1, M)
+    if nvalid < M:                       # never-written slots are zero memories
+        order = torch.arange(M, device=dev)
+        kc[:, :, nvalid:] = 0; vc[:, :, nvalid:] = 0
+    qkv = torch.randn(B, 3 * d, device=dev).bfloat16()
+    bd = torch.randn(B, H, M, device=dev) * 2
+    rwb = torch.randn(H, dh, device=dev) * .3
+    t_dev = torch.tensor([t], device=dev, dtype=torch.int32)
+    scale = dh ** -0.5
+    one = torch.empty(B, d, device=dev, dtype=torch.bfloat16); out = torch.empty_like(one); out2 = torch.empty_like(one)
+    check(lib().mxl_relattn_decode(_p(qkv), _p(kc), _p(vc), _p(bd), _p(rwb), _p(one), _p(t_dev), B, H, dh, M, scale, _stream()), 'decode')
+    ws, arrived = ops.relattn_decode_split_scratch(B, H, dh, pieces, dev)
+    for o in (out, out2):
+        check(lib().mxl_relattn_decode_split(_p(qkv), _p(kc), _p(vc), _p(bd), _p(rwb), _p(o), _p(t_dev), B, H, dh, M, scale, pieces,
+                                             _p(ws), _p(arrived), _stream()), 'decode split')
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and int(arrived.abs().sum().item()) == 0
+    # fp64 reference: slot s holds position with distance (t mod M - s) mod M
+    q = (qkv[:, :d].float().view(B, H, dh) + rwb).bfloat16().double()
+    tm = t % M
+    dist = (tm - torch.arange(M, device=dev)) % M
+    sc = (torch.einsum('bhe,bhse->bhs', q, kc.double()) + bd.double().gather(2, dist[None, None].expand(B, H, M))) * scale
+    pr = torch.softmax(sc, dim=-1)
+    ref = torch.einsum('bhs,bhse->bhe', pr, vc.double()).reshape(B, d)
+    assert (out.double() - ref).abs().max().item() < 2e-2
+    assert (out.float() - one.float()).abs().max().item() <= 2e-2 and (one.double() - ref).abs().max().item() < 2e-2
+
+
+def test_ring_pieces_in_the_decoder_graph_equals_eager(dev, monkeypatch):
+    """the decoder with every ring cut into pieces (forced: the tiny model's rings are short): hipGraph replay == eager launches,
+    token for token -- the arrival counters return to zero after every launch, the merge order is fixed -- and the first tokens
+    are the one-piece decoder's (last-bit differences of the attention output do not move a greedy choice that is not a near-tie)"""
+    from symbolic_music_generation_amd.generate import XLDecoder
+    ref, m = _pair(dev, n_layer=2, mem_len=64, max_length=128, seed=31)
+    m.eval()
+    g = torch.Generator().manual_seed(32)
+    prompt = torch.randint(4, 1190, (3, 10), generator=g).to(dev)
+    monkeypatch.setenv('MXL_DECODE_PIECES', '2')
+    d2 = XLDecoder(m.engine, 3, 128, seed=3)
+    assert d2.pieces == 2 and d2.split is not None
+    a = d2.generate(prompt, 90, do_sample=False, use_graph=True)
+    b = XLDecoder(m.engine, 3, 128, seed=3).generate(prompt, 90, do_sample=False, use_graph=False)
+    assert torch.equal(a, b) and int(d2.split[1].abs().sum().item()) == 0
+    # and the tokens are the oracle's as long as the oracle's own margin is not a near-tie
+    monkeypatch.setenv('MXL_DECODE_PIECES', '1')
+    one = XLDecoder(m.engine, 3, 128, seed=3).generate(prompt, 90, do_sample=False, use_graph=True)
+    same = (a == one).all(dim=0).float()
+    assert same[:30].all(), 'ring pieces change a greedy token within the first 20 generated positions'
+
+
 @pytest.mark.parametrize('B,H,M', [(64, 12, 2048), (5, 2, 300), (17, 3, 301), (1, 1, 64)])
 def test_decode_bd_vs_einsum(dev, B, H, M):
     """mxl_decode_bd == einsum('bhe,rhe->bhr') of the bf16 operands in fp32 (HF: BD = einsum("ibnd,jnd->ijbn", rr_head_q,
