@@ -431,6 +431,69 @@ def _save_trained(trainer):
             torch.distributed.barrier()
 
 
+# The reference's table of its author's training runs (musicnlp/trainer/eval.py:37-76): (model name, datasets, epochs, comment) ->
+# [run directory, checkpoint directory] below <base>/models.  Data only -- the checkpoints themselves are the author's and are not
+# part of any repository; the table lets the reference's `load_trained(model_key=...)` calls resolve to the same paths here.
+TRAINED_KEY2PATH = {
+    'full': {
+        ('reformer', 'P&M', '256-256ep', 'mid-pch'): ['2022-10-03_11-58-11_reformer', 'trained'],
+        ('reformer', 'All', '5-16ep', 'mid-pch_1e-4'): ['2022-10-09_01-36-18_reformer', 'checkpoint-6850'],
+        ('reformer', 'All', '16-16ep', 'mid-pch_1e-4'): ['2022-10-09_01-36-18_reformer', 'trained'],
+        ('reformer', 'All', 'x-128ep', '1st-prop-mix'): ['2022-10-15_22-44-10_reformer', 'trained'],
+        ('transf-xl', 'All', 'x-128ep', 'prop-mix'): ['2022-10-19_04-50-21_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128-128ep', 'deg-pch_eval-no-mixup'): ['2022-10-26_08-41-26_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128-128ep', 'with-crop'): ['2022-10-27_07-56-03_transf-xl', 'trained'],
+        ('transf-xl', 'All', '256-256ep', 'with-crop_train-longer'): ['2022-10-29_08-28-57_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'no-mixup'): ['2022-11-11_18-04-07_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'midi'): ['2022-11-14_13-04-30_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'midi_no-wp'): ['2022-11-18_18-22-47_transf-xl', 'checkpoint-10863'],
+        ('transf-xl', 'All', '128ep', 'midi_longer-seq'): ['2022-11-21_21-22-24_transf-xl', 'checkpoint-30348'],
+        ('transf-xl', 'All', '128ep', 'degree_no-wp'): ['2022-11-24_01-18-17_transf-xl', 'checkpoint-7755'],
+        ('transf-xl', 'All', '128ep', 'degree_no-wp_2'): ['2022-11-24_16-29-59_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'no-wp_seg-len-512'): ['2022-11-27_13-03-40_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'large-wp'): ['2022-11-28_15-52-20_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'no-ch-mix'): ['2022-11-30_20-00-10_transf-xl', 'trained'],
+        ('transf-xl', 'All', '128ep', 'small_long-seq'): ['2022-12-04_16-03-03_transf-xl', 'trained'],
+    }
+}
+
+
+def load_trained(model_name: str = None, directory_name=None, model_key: Tuple[str, str, str, str] = None, mode: str = 'full',
+                 base_path: str = None, model_dir: str = 'models', device='cuda:0'):
+    """`musicnlp.trainer.eval.load_trained` (eval.py:32-95): a trained model from <base_path>/<model_dir>/<directory...>, named either
+    by `directory_name` (a string or a sequence of path parts) or by a `model_key` of TRAINED_KEY2PATH (whose first element then
+    also names the model).  Same argument checks: model names 'reformer' / 'transf-xl' ('transfo-xl' is accepted as well -- the
+    reference validates against that spelling and then compares with the other), mode 'melody' not supported.  For
+    Transformer-XL `pad_token_id = eos_token_id` is set for open-ended generation (eval.py:93-94).  `base_path` defaults to
+    $MUSICNLP_BASE_PATH or the working directory (the reference's `get_base_path()` is its own checkout's parent)."""
+    from .reformer import MyReformerModelWithLMHead
+    from .transformer_xl import MyTransfoXLLMHeadModel
+    if mode == 'melody':
+        raise NotImplementedError("Current Tokenizer don't support prior melody-only representation ")
+    if mode not in TRAINED_KEY2PATH:
+        raise ValueError(f'Unexpected mode: expect one of {sorted(TRAINED_KEY2PATH)}, got {mode!r}')
+    parts = [base_path or os.environ.get('MUSICNLP_BASE_PATH') or os.getcwd(), model_dir]
+    if model_key is not None:
+        model_key = tuple(model_key)
+        if model_key not in TRAINED_KEY2PATH[mode]:
+            raise KeyError(f'Unknown model key {model_key}: expect one of {sorted(TRAINED_KEY2PATH[mode])}')
+        model_name = model_key[0]
+        parts.extend(TRAINED_KEY2PATH[mode][model_key])
+    elif directory_name is None:
+        raise ValueError('load_trained needs a directory_name or a model_key')
+    elif isinstance(directory_name, str):
+        parts.append(directory_name)
+    else:
+        parts.extend(directory_name)
+    if model_name not in ('reformer', 'transf-xl', 'transfo-xl'):
+        raise ValueError(f"Unexpected Model Name: expect one of ['reformer', 'transf-xl'], got {model_name!r}")
+    cls = MyReformerModelWithLMHead if model_name == 'reformer' else MyTransfoXLLMHeadModel
+    model = cls.from_pretrained(os.path.join(*parts), device=device)
+    if model_name != 'reformer':
+        model.config.pad_token_id = model.config.eos_token_id      # for open-end generation
+    return model
+
+
 def train_xl(dataset_names, model_size: str = 'base', model_config: Dict = None, train_args: Dict = None,
              my_train_args: Dict = None, dataset_args: Dict = None, device='cuda:0', **train_kwargs):
     """The reference's `train_xl()` (train.py:492-593) with its hard-wired settings as defaults: max_length 1024, mem_len 512,

@@ -251,3 +251,26 @@ def test_no_backward_path_regenerates_the_ffn_hidden_dropout_mask():
         stmt = xl[m.start():xl.find('\n\n', m.start())]
         assert '_site(l, 1)' not in stmt.split(')\n')[0]
 
+
+
+def test_load_trained_key_table_and_argument_checks(tmp_path):
+    """trainer.load_trained mirrors musicnlp.trainer.eval.load_trained (eval.py:32-95): the author's run table resolves a model_key
+    to <base>/models/<run>/<checkpoint>, a model_key also names the model, and the argument errors come before any GPU work"""
+    from symbolic_music_generation_amd import trainer
+    tab = trainer.TRAINED_KEY2PATH['full']
+    assert len(tab) == 18
+    assert tab[('reformer', 'P&M', '256-256ep', 'mid-pch')] == ['2022-10-03_11-58-11_reformer', 'trained']
+    assert tab[('transf-xl', 'All', '128ep', 'midi_longer-seq')] == ['2022-11-21_21-22-24_transf-xl', 'checkpoint-30348']
+    assert sum(k[0] == 'reformer' for k in tab) == 4 and sum(k[0] == 'transf-xl' for k in tab) == 14
+    with pytest.raises(NotImplementedError):
+        trainer.load_trained('transf-xl', 'x', mode='melody')
+    with pytest.raises(KeyError):
+        trainer.load_trained(model_key=('transf-xl', 'All', '1ep', 'nope'), base_path=str(tmp_path))
+    with pytest.raises(ValueError):
+        trainer.load_trained('gpt2', 'x', base_path=str(tmp_path))
+    with pytest.raises(ValueError):
+        trainer.load_trained('transf-xl', base_path=str(tmp_path))
+    # a key resolves to the run directory below <base>/models (nothing is there: the config read fails with that path in the message)
+    with pytest.raises(Exception) as e:
+        trainer.load_trained(model_key=('transf-xl', 'All', '128ep', 'midi'), base_path=str(tmp_path))
+    assert os.path.join(str(tmp_path), 'models', '2022-11-14_13-04-30_transf-xl', 'trained') in str(e.value)

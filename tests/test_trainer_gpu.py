@@ -56,6 +56,16 @@ def test_transfxl_train_eval_save_generate(dev, tmp_path):
     assert torch.equal(g1, g2) and g1.shape == (1, 40) and torch.equal(g1[:, :10], prompt)
     s = model.generate(input_ids=prompt.repeat(4, 1), max_length=40, do_sample=True, top_k=8, temperature=1.0)
     assert s.shape == (4, 40) and (s >= 0).all() and (s < tok.vocab_size).all()
+    # the reference's eval.load_trained: by directory parts and by a key of the run table (the run directory laid out as the table says)
+    import shutil
+    from symbolic_music_generation_amd.trainer import load_trained, TRAINED_KEY2PATH
+    key = ('transf-xl', 'All', '128ep', 'midi')
+    dst = os.path.join(str(tmp_path), 'base', 'models', *TRAINED_KEY2PATH['full'][key])
+    shutil.copytree(ck, dst)
+    m3 = load_trained(model_key=key, base_path=os.path.join(str(tmp_path), 'base'), device=dev).eval()
+    m4 = load_trained('transf-xl', [TRAINED_KEY2PATH['full'][key][0], 'trained'], base_path=os.path.join(str(tmp_path), 'base'), device=dev).eval()
+    assert torch.equal(m3(input_ids=ids).logits, a) and torch.equal(m4(input_ids=ids).logits, a)
+    assert m3.config.pad_token_id == m3.config.eos_token_id == 0
 
 
 def test_reformer_train_eval(dev, tmp_path):
