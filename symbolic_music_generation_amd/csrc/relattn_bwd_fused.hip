@@ -479,8 +479,12 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     // dRd flush.  A block leaves the window once per tile, in the registers of ONE wave.  Thirty-two atomics from that wave stalled it
     // (issue stalls beyond 16 outstanding) and sat in its in-order vmcnt queue in front of the next tile's staged rows; parked in LDS
     // instead (32 ds_write_b32), every wave adds four rows of it in the next tile: the same four atomics per wave and tile on every path.
-    const __amdgpu_buffer_rsrc_t rs_drd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.drd + h * 64), 0, -1, 0x00020000);
+    // (num_records = this head's last element: an atomic whose lane offset lies beyond it is dropped by the address unit -- that is
+    // where the blocks outside [0, M) go, so that every path still issues the same operations without adding zeros to memory:
+    // until round 5 they went onto block 0, 0.4 GB of atomic traffic per layer onto one 8 KB target)
     const int ld4 = p.drd_ld * 4;
+    const __amdgpu_buffer_rsrc_t rs_drd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.drd + h * 64), 0, (int)((32 * MB - 1) * ld4 + 256), 0x00020000);
+    constexpr int DRD_OOB = 0x7ffff000;
     auto drd_park = [&](const f32x4& leave) {   // this wave's slice of the block that leaves the window -> sPark[distance][e]
 #pragma unroll
         for (int t = 0; t < 4; t++) sPark[(16 * (w & 1) + 4 * (l >> 4) + t) * 64 + 16 * (w >> 1) + (l & 15)] = leave[t];
@@ -490,9 +494,9 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     // four 64-byte requests) -- and every wave issues the same four per tile
     auto drd_add = [&](const f32x4& leave, int nL) {
         const bool ok = nL >= 0 && nL < MB;
-        const float f = ok ? 1.f / p.scale_log2e : 0.f;     // the Qr image carries scale * log2(e); out of range: zeros onto block 0
+        const float f = 1.f / p.scale_log2e;                 // the Qr image carries scale * log2(e)
         const int so = (ok ? 32 * nL : 0) + 16 * (w & 1);
-        const int vo = 4 * (l >> 4) * ld4 + (16 * (w >> 1) + (l & 15)) * 4;
+        const int vo = ok ? 4 * (l >> 4) * ld4 + (16 * (w >> 1) + (l & 15)) * 4 : DRD_OOB;      // out of range: dropped
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #ifndef MXL_ABL_NO_ATOMICS
@@ -506,14 +510,14 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
 #pragma unroll
         for (int i = 0; i < 4; i++) pk[i] = sPark[(4 * w + i) * 64 + l];
     };
-    auto park_add = [&](int nL) {               // block nL (out of range: zeros onto block 0 -- the operation count stays the same)
+    auto park_add = [&](int nL) {               // block nL (out of range: dropped -- the operation count stays the same)
         const bool ok = nL >= 0 && nL < MB;
         const int so = ok ? 32 * nL * ld4 : 0;
-        const float f = ok ? 1.f / p.scale_log2e : 0.f;     // the Qr image carries scale * log2(e)
+        const float f = 1.f / p.scale_log2e;                 // the Qr image carries scale * log2(e)
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #ifndef MXL_ABL_NO_ATOMICS
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pk[i] * f, rs_drd, l * 4, so + (4 * w + i) * ld4, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pk[i] * f, rs_drd, ok ? l * 4 : DRD_OOB, so + (4 * w + i) * ld4, 0);
 #else
             asm volatile("" :: "v"(pk[i]));
 #endif
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
     }
 #pragma unroll
     for (int i = 0; i < VM_PER_TILE; i++)       // the loop is entered with as many operations behind the first staged rows as every later tile has
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(0.f, rs_drd, l * 4, i * ld4, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(0.f, rs_drd, DRD_OOB, i * ld4, 0);
 
     int cur = 0;
     STAMP(15)
