@@ -33,8 +33,11 @@ def rank() -> int:
 
 
 def layer_buckets(layout, n_layer: int) -> Tuple[List[List[Tuple[int, int]]], List[Tuple[int, int]]]:
-    """Per-layer [(lo, hi), ...] slices of the flat buffer (decay-segment weights + no-decay-segment small params) and
-    the remaining head/embedding slices (final only after the embedding backward)."""
+    """Per-layer [(lo, hi)] slice of the flat buffer -- the layer's decay-segment weights, one contiguous ~28 MB message at
+    12L/768d -- and the remainder, the TAIL bucket(s): head / embedding rows and the whole no-decay segment (every layer's
+    LayerNorm parameters and biases: a few KB per layer, latency-bound as messages of their own, so they travel together in one
+    message once the embedding backward is enqueued).  12L: 12 + 2 all-reduces per step (26 when each layer sent its own
+    no-decay slice)."""
     ent = layout.entries
     names = list(ent.keys())
 
@@ -48,8 +51,7 @@ def layer_buckets(layout, n_layer: int) -> Tuple[List[List[Tuple[int, int]]], Li
     for l in range(n_layer):
         offs = span(prefix(l))
         dec = [o for o in offs if o[0] < layout.n_decay]
-        nod = [o for o in offs if o[0] >= layout.n_decay]
-        sl = [(min(o[0] for o in dec), _r8(max(o[1] for o in dec))), (min(o[0] for o in nod), _r8(max(o[1] for o in nod)))]
+        sl = [(min(o[0] for o in dec), _r8(max(o[1] for o in dec)))]
         per_layer.append(sl)
         covered += sl
     covered.sort()

@@ -174,13 +174,19 @@ def _check_partition(layout, n_layer):
         assert 0 <= lo < hi <= layout.total
         hits[lo:hi] += 1
     assert hits.min() == 1 and hits.max() == 1, f'covered {int((hits == 1).sum())} of {layout.total} once, max {hits.max()}'
-    # every parameter of layer l lies in layer l's buckets (so its exchange can start when that layer's backward is enqueued)
+    # every decay-segment parameter of layer l lies in layer l's ONE bucket (so its exchange can start when that layer's backward
+    # is enqueued); the layers' no-decay parameters (LayerNorm, biases: a few KB each) travel together in the tail
     prefix = getattr(layout, 'layer_prefix', lambda l: f'transformer.layers.{l}.')
     for l in range(n_layer):
+        assert len(per_layer[l]) == 1
         for name, (off, shape) in layout.entries.items():
             if name.startswith(prefix(l)):
                 n = int(np.prod(shape))
-                assert any(lo <= off and off + n <= hi for lo, hi in per_layer[l]), name
+                if off < layout.n_decay:
+                    assert any(lo <= off and off + n <= hi for lo, hi in per_layer[l]), name
+                else:
+                    assert any(lo <= off and off + n <= hi for lo, hi in rest), name
+    assert len(rest) <= 3, f'{len(rest)} tail messages'
 
 
 def test_gradient_buckets_partition_the_flat_buffer():
