@@ -80,8 +80,8 @@ def test_weight_gradient_split_k_under_reserved_cus(dev, reserve, O, K, NTOK):
 
 def test_c3_shape_train_step_under_reserved_cus(dev, reserve):
     """one forward + backward of the C3 layer shapes (768d / H12 / dh64 / F3072, T = M = 2048, two layers, batch 4, dropout on)
-    with k = 16 against k = 0 from the same parameters and rng_step: the forward is NT GEMMs and attention only, so the loss is
-    bit-identical; gradients agree to the atomics' reordering (the bound test_c3_bench_batch_dropout_step_... uses for two runs
+    with k = 16 against k = 0 from the same parameters and rng_step: the forward is NT GEMMs and attention only, so the loss agrees to
+    the last bits of its own atomic reduction; gradients agree to the atomics' reordering (the bound test_c3_bench_batch_dropout_step_... uses for two runs
     of the SAME configuration)"""
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
     T = M = 2048
@@ -105,7 +105,7 @@ def test_c3_shape_train_step_under_reserved_cus(dev, reserve):
     l0, g0 = step()
     reserve(K_RESERVED)
     l1, g1 = step()
-    assert l0 == l1, (l0, l1)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)      # (the loss reduction itself sums with float atomics)
     worst = 0.0
     for name in eng.layout.real_names():
         a, b = eng.layout.view(g0, name).double(), eng.layout.view(g1, name).double()
