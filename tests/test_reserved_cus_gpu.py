@@ -101,13 +101,22 @@ def test_c3_shape_train_step_under_reserved_cus(dev, reserve):
         torch.cuda.synchronize()
         return o.loss.item(), eng.G.clone()
 
+    def worst(ga, gb):
+        w, wn = 0.0, ''
+        for name in eng.layout.real_names():
+            a, b = eng.layout.view(ga, name).double(), eng.layout.view(gb, name).double()
+            e = ((a - b).norm() / (a.norm() + 1e-30)).item()
+            if e > w:
+                w, wn = e, name
+        return w, wn
+
     reserve(0)
     l0, g0 = step()
+    l0b, g0b = step()                           # the same configuration again: what the float atomics alone move
     reserve(K_RESERVED)
     l1, g1 = step()
     assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)      # (the loss reduction itself sums with float atomics)
-    worst = 0.0
-    for name in eng.layout.real_names():
-        a, b = eng.layout.view(g0, name).double(), eng.layout.view(g1, name).double()
-        worst = max(worst, ((a - b).norm() / (a.norm() + 1e-30)).item())
-    assert worst < 1e-4, worst
+    noise, _ = worst(g0, g0b)
+    w, wn = worst(g0, g1)
+    print(f'k = 0 twice: {noise:.2e}; k = {K_RESERVED} against k = 0: {w:.2e} ({wn})')
+    assert w < max(3.0 * noise, 3e-4), (w, wn, noise)
