@@ -402,6 +402,15 @@ int mxl_sample_large(const float* logprobs, int ldl, int V, void* ids, int ld_id
                      void* stream);
 /* t_dev += 1; rng_ctr += 1 */
 int mxl_decode_advance(int* t_dev, unsigned long long* rng_ctr, void* stream);
+/* Round 6: mxl_sample + mxl_decode_embed of the sampled token + mxl_decode_advance in one launch -- the tail of one decode step and
+ * the head of the next.  The row's workgroup writes ids[b][t + 1] and emb_out[b] = E[token] * scale (bf16, (B, d)); the workgroup
+ * that finishes last advances *t_dev and *rng_ctr (counter: one int, zero before the first call, left zero).  `scores` (B, ldl) may
+ * be log-probabilities or, when repetition_penalty == 1, the head's raw logits: argmax, top-k / top-p / typical-p and the
+ * renormalised draw do not change under the per-row shift that separates the two.  V <= 2048. */
+int mxl_sample_step(const float* scores, int ldl, int V, void* ids, int ld_ids, int* t_dev, unsigned long long* rng_ctr,
+                    unsigned long long seed, int B, int do_sample, int top_k, float top_p, float temperature,
+                    float repetition_penalty, float typical_p, const void* E, void* emb_out, int d, float scale, int* counter,
+                    void* stream);
 /* Contrastive search (the reference's 'contrastive' strategy, musicnlp/trainer/eval.py:296-302, over the mems patch of
  * musicnlp/models/transformer_xl.py:229-234; HF 4.25.1 GenerationMixin.contrastive_search with `_ranking_fast`):
  *   score[b*K + k] = (1 - alpha) * probs[b*K + k] - alpha * max_{s < S} cos(hid[b*K + k], ctx[b][s]);  sel[b] = argmax_k score

@@ -339,12 +339,14 @@ __global__ __launch_bounds__(256) void decode_bd_kernel(const bf16_t* qr, const 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int SORT_N = 2048;
 
-__global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl, int V, long long* ids, int ld_ids,
-                                                     const int* t_dev, unsigned long long* rng_ctr, unsigned long long seed,
-                                                     int do_sample, int top_k, float top_p, float temperature,
-                                                     float repetition_penalty, float typical_p, float* out_probs) {
+// the row's next token (returned to every thread of the workgroup)
+__device__ __forceinline__ int sample_row(const float* logp, int ldl, int V, const long long* ids, int ld_ids,
+                                          const int* t_dev, const unsigned long long* rng_ctr, unsigned long long seed,
+                                          int do_sample, int top_k, float top_p, float temperature,
+                                          float repetition_penalty, float typical_p, float* out_probs) {
     __shared__ float key[SORT_N];
     __shared__ int idx[SORT_N];
+    __shared__ int sh_pick;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logp + (size_t)b * ldl;
     const float invt = 1.f / temperature;
@@ -428,11 +430,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
             __syncthreads();
         }
     }
-    const int t = *t_dev;
-    long long* dst = ids + (size_t)b * ld_ids + t + 1;
     if (!do_sample) {
-        if (tid == 0) *dst = idx[0];
-        return;
+        if (tid == 0) sh_pick = idx[0];
+        __syncthreads();
+        return sh_pick;
     }
     int keep = (top_k > 0 && top_k < V) ? top_k : V;
     __shared__ int sh_keep;
@@ -525,10 +526,55 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl,
             if (u < c && p > 0.f) { pick = i; break; }
         }
         if (pick < 0) pick = last;
-        *dst = idx[pick];
+        sh_pick = idx[pick];
         if (out_probs) {   // diagnostic / test hook: renormalised probabilities of the kept support, in vocab order
             for (int i = 0; i < V; i++) out_probs[(size_t)b * V + i] = 0.f;
             for (int i = 0; i < keep; i++) out_probs[(size_t)b * V + idx[i]] = __expf(key[i] - m) / s;
+        }
+    }
+    __syncthreads();
+    return sh_pick;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(const float* logp, int ldl, int V, long long* ids, int ld_ids,
+                                                     const int* t_dev, unsigned long long* rng_ctr, unsigned long long seed,
+                                                     int do_sample, int top_k, float top_p, float temperature,
+                                                     float repetition_penalty, float typical_p, float* out_probs) {
+    const int tok = sample_row(logp, ldl, V, ids, ld_ids, t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature,
+                               repetition_penalty, typical_p, out_probs);
+    if (threadIdx.x == 0) ids[(size_t)blockIdx.x * ld_ids + *t_dev + 1] = tok;
+}
+
+// Round 6: the sampler with the two launches that always follow it.  The sampled token's embedding row E[tok] * scale -- the input
+// of the NEXT decode step (mxl_decode_embed's arithmetic) -- is written by the row's workgroup, and the workgroup that finishes last
+// advances the position and RNG counters (mxl_decode_advance): every other workgroup has read them by then.  `scores` may be the
+// head's raw logits instead of log-probabilities when no repetition penalty is in force: every other warper, the argmax and the
+// renormalised draw are invariant under the per-row shift log-softmax applies.
+__global__ __launch_bounds__(256) void sample_step_kernel(const float* scores, int ldl, int V, long long* ids, int ld_ids,
+                                                          int* t_dev, unsigned long long* rng_ctr, unsigned long long seed,
+                                                          int do_sample, int top_k, float top_p, float temperature,
+                                                          float repetition_penalty, float typical_p, const bf16_t* E, bf16_t* emb_out,
+                                                          int d, float scale, int* counter) {
+    const int tok = sample_row(scores, ldl, V, ids, ld_ids, t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature,
+                               repetition_penalty, typical_p, nullptr);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) ids[(size_t)b * ld_ids + *t_dev + 1] = tok;
+    const int id = (tok < 0 || tok >= V) ? 0 : tok;
+    for (int c = tid; c < (d >> 3); c += 256) {
+        const bf16x8 e = *reinterpret_cast<const bf16x8*>(E + (size_t)id * d + c * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = bf2f((bf16_t)e[j]) * scale;
+        const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(emb_out + (size_t)b * d + c * 8) = o;
+    }
+    __syncthreads();                            // every thread of the workgroup is past its reads of *t_dev / *rng_ctr
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (int)gridDim.x - 1) {
+            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *t_dev += 1;
+            *rng_ctr += 1;
         }
     }
 }
@@ -633,6 +679,20 @@ extern "C" int mxl_sample(const float* logprobs, int ldl, int V, void* ids, int 
     MXL_CHECK_ARG(repetition_penalty > 0.f && typical_p > 0.f);
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logprobs, ldl, V, (long long*)ids, ld_ids,
                        t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature, repetition_penalty, typical_p, out_probs);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_sample_step(const float* scores, int ldl, int V, void* ids, int ld_ids, int* t_dev, unsigned long long* rng_ctr,
+                               unsigned long long seed, int B, int do_sample, int top_k, float top_p, float temperature,
+                               float repetition_penalty, float typical_p, const void* E, void* emb_out, int d, float scale,
+                               int* counter, void* stream) {
+    MXL_CHECK_ARG(scores && ids && t_dev && rng_ctr && E && emb_out && counter && B > 0 && V > 0 && V <= SORT_N && temperature > 0.f);
+    MXL_CHECK_ARG(repetition_penalty > 0.f && typical_p > 0.f && d > 0 && (d % 8) == 0);
+    MXL_CHECK_ARG(((uintptr_t)E % 16) == 0 && ((uintptr_t)emb_out % 16) == 0);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, ldl, V, (long long*)ids, ld_ids,
+                       t_dev, rng_ctr, seed, do_sample, top_k, top_p, temperature, repetition_penalty, typical_p,
+                       (const bf16_t*)E, (bf16_t*)emb_out, d, scale, counter);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }

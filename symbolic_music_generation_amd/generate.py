@@ -13,6 +13,7 @@ Contrastive search raises: HF 4.25.1's `contrastive_search` requires `past_key_v
 TransfoXL (`mems`) nor Reformer (`past_buckets_states`) returns, so that strategy fails in the reference too.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -53,6 +54,11 @@ class XLDecoder:
         self.logp = torch.empty(batch, c.vocab_size, device=dev, dtype=torch.float32)
         self.graph = None
         self._graph_key = None
+        # Round 6: sampler + the sampled token's embedding row (the next step's input) + counter advance in ONE launch
+        # (mxl_sample_step), and no log-softmax launch where nothing reads log-probabilities: 2 launches per step around the layers
+        # instead of 5.  MXL_DECODE_UNFUSED=1 keeps the five (A/B runs, tests).
+        self.fused_sampler = c.vocab_size <= 2048 and os.environ.get('MXL_DECODE_UNFUSED') != '1'
+        self.step_ctr = torch.zeros(1, device=dev, dtype=torch.int32)
         # optional (B, Tmax, V) f32 buffer: row t receives the log-probs computed FROM position t (parity tests compare them
         # with a one-shot forward); written on the device by position, so it also works under hipGraph replay
         self.trace = None
@@ -102,24 +108,51 @@ class XLDecoder:
         self.t_dev.fill_(Tp - 1)
         self._trace()
         if sampling is not None:                       # None: the caller picks the token from self.logp (beam search)
-            ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
-            ops.decode_advance(self.t_dev, self.rng)   # t = Tp: position of the token just sampled
+            self._sample_advance(self.logp, sampling)  # t = Tp: position of the token just sampled
         return out
 
-    # ---------------------------------------------------------------- one token
-    def step(self, sampling: dict):
-        self._forward_token()
-        ops.sample(self.logp, self.ids, self.t_dev, self.rng, self.seed, **sampling)
-        ops.decode_advance(self.t_dev, self.rng)
+    def _sample_advance(self, scores, sampling: dict):
+        """next token of every row from `scores` (log-probabilities, or the head's logits: see mxl_sample_step) -> ids[:, t + 1];
+        position and RNG counters advanced.  Short chain: the same launch leaves the token's embedding row in h[0] for the next step."""
+        c = self.eng.cfg
+        if self.fused_sampler:
+            ops.sample_step(scores, c.vocab_size, self.ids, self.t_dev, self.rng, self.seed,
+                            self.eng.w16('transformer.word_emb.emb_layers.0.weight'), self.h[0], math.sqrt(c.d_model), self.step_ctr,
+                            **sampling)
+        else:
+            ops.sample(scores[:, :c.vocab_size] if scores.shape[1] != c.vocab_size else scores, self.ids, self.t_dev, self.rng,
+                       self.seed, **sampling)
+            ops.decode_advance(self.t_dev, self.rng)
 
-    def _forward_token(self):
+    # ---------------------------------------------------------------- one token
+    def force_tokens(self, tokens: torch.Tensor):
+        """teacher forcing / constrained decoding: `tokens` (B,) replace the ids at the current position t (what the sampler just
+        wrote) before the next `step`; with the fused sampler the embedding row the sampler left for that step follows"""
+        self.ids.index_copy_(1, self.t_dev.to(torch.int64), tokens.to(self.ids.device, torch.int64).unsqueeze(1))
+        if self.fused_sampler:
+            c = self.eng.cfg
+            ops.decode_embed(self.ids, self.t_dev, self.eng.w16('transformer.word_emb.emb_layers.0.weight'), self.h[0], math.sqrt(c.d_model))
+
+    def step(self, sampling: dict, want_logp: bool = False):
+        """one more token for every row.  want_logp: self.logp is needed after the step (it always holds the log-probabilities when
+        a trace is attached, the head is adaptive or a repetition penalty is in force)"""
+        # the log-softmax launch is only needed for what reads log-probabilities: the trace, an adaptive (clustered) head, and the
+        # repetition penalty (sign-dependent); every other warper and the draw itself are shift-invariant (mxl_sample_step)
+        raw = (self.fused_sampler and self.trace is None and not want_logp and not tuple(self.eng.cfg.cutoffs)
+               and float(sampling.get('repetition_penalty', 1.0) or 1.0) == 1.0)
+        self._forward_token(embed=not self.fused_sampler, want_logp=not raw)
+        self._sample_advance(self.logits if raw else self.logp, sampling)
+
+    def _forward_token(self, embed: bool = True, want_logp: bool = True):
         """the token at position t (ids[:, t], t on the device) through the model: K/V appended to the rings at slot t mod M,
-        self.logp = log-probabilities of position t + 1"""
+        self.logp = log-probabilities of position t + 1 (want_logp=False: only self.logits, the head's raw rows).
+        embed=False: h[0] already holds the token's embedding row (written by the previous step's sampler launch)."""
         e, c = self.eng, self.eng.cfg
         B, d, H, dh, M, Fi, L = self.B, c.d_model, c.n_head, c.d_head, c.mem_len, c.d_inner, c.n_layer
         E = e.w16('transformer.word_emb.emb_layers.0.weight')
         G = ops.gemm_skinny if B <= 64 else ops.gemm     # weight-streaming form for decode batches
-        ops.decode_embed(self.ids, self.t_dev, E, self.h[0], math.sqrt(d))
+        if embed:
+            ops.decode_embed(self.ids, self.t_dev, E, self.h[0], math.sqrt(d))
         for l in range(L):
             h_in, h_out = self.h[l & 1], self.h[(l + 1) & 1]
             rrb = e._lw(l, 'dec_attn.r_r_bias', e.P)
@@ -147,10 +180,11 @@ class XLDecoder:
                   bias=e._lw(l, 'pos_ff.CoreNet.3.bias', e.P))
                 ops.ln_residual_fwd(self.tmp, self.h1, e._lw(l, 'pos_ff.layer_norm.weight', e.P),
                                     e._lw(l, 'pos_ff.layer_norm.bias', e.P), h_out, eps=c.layer_norm_epsilon)
-        self._head(self.h[L & 1])
-        self._trace()
+        self._head(self.h[L & 1], want_logp)
+        if want_logp:
+            self._trace()
 
-    def _head(self, hid):
+    def _head(self, hid, want_logp: bool = True):
         """(B, d) hidden states -> self.logp: all head rows (vocabulary + cluster rows) in one weight-streaming GEMM, then the
         adaptive log-softmax over the row (HF `ProjectedAdaptiveLogSoftmax.log_prob`, the labels=None branch)"""
         e, c = self.eng, self.eng.cfg
@@ -160,7 +194,8 @@ class XLDecoder:
         head_w = e.W[:nrow_p * d].view(nrow_p, d)
         boff = e.layout.entries['crit.out_layers.0.bias'][0]
         G(hid, head_w, self.logits, B, nrow, d, flags=ops.GEMM_OUT_F32 | ops.GEMM_BIAS, bias=e.P[boff:boff + nrow])
-        ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
+        if want_logp:
+            ops.adaptive_logprob(self.logits, self.logp, B, c.vocab_size, tuple(c.cutoffs))
 
     # ---------------------------------------------------------------- beam-search hooks (see beam_search below)
     def beam_prefill(self, prompt: torch.Tensor):
@@ -199,7 +234,7 @@ class XLDecoder:
             if self.graph is None or self._graph_key != key:
                 # warm-up on a side stream (first launches set function attributes), then capture one step
                 state = (self.t_dev.clone(), self.rng.clone(), self.ids.clone(),
-                         [k.clone() for k in self.kc], [v.clone() for v in self.vc])
+                         [k.clone() for k in self.kc], [v.clone() for v in self.vc], self.h[0].clone())
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
@@ -215,6 +250,7 @@ class XLDecoder:
                     a.copy_(b)
                 for a, b in zip(self.vc, state[4]):
                     a.copy_(b)
+                self.h[0].copy_(state[5])         # (short chain: the next step's embedding row is step state too)
         return max(steps, 0)
 
     def replay_once(self):

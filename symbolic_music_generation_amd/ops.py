@@ -133,6 +133,18 @@ def decode_qkv(x, wqkv, qkv, kc, vc, t_dev, rrb, qr_out, dh):
                                _stream()), 'mxl_decode_qkv')
 
 
+def sample_step(scores, V, ids, t_dev, rng_ctr, seed, E, emb_out, scale, counter, do_sample=False, top_k=0, top_p=1.0,
+                temperature=1.0, repetition_penalty=1.0, typical_p=1.0):
+    """sampler + embedding row of the sampled token (-> emb_out (B, d) bf16) + counter advance, one launch (V <= 2048).
+    scores (B, >= V) f32: log-probabilities, or raw logits when repetition_penalty == 1."""
+    B = scores.shape[0]
+    check(lib().mxl_sample_step(_p(scores), scores.stride(0), int(V), _p(ids), ids.stride(0), _p(t_dev), _p(rng_ctr), seed, B,
+                                int(do_sample), int(top_k or 0), float(top_p if top_p is not None else 1.0), float(temperature),
+                                float(repetition_penalty if repetition_penalty is not None else 1.0),
+                                float(typical_p if typical_p is not None else 1.0), _p(E), _p(emb_out), emb_out.shape[1],
+                                float(scale), _p(counter), _stream()), 'mxl_sample_step')
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, relu=False, out=None,
            out_f32=False, drop_p=0.0, seed=0, site=0) -> torch.Tensor:
     """y = x @ w.T (+bias)(relu)(dropout); x (N, K) bf16, w (O, K) bf16."""

@@ -36,8 +36,8 @@ def test_decode_logprobs_match_full_forward(dev):
     dec.prefill(ids[:, :10], samp)
     errs = []
     for t in range(10, 100):
-        dec.ids[:, t] = ids[:, t]                      # teacher forcing: overwrite the sampled token
-        dec.step(samp)
+        dec.force_tokens(ids[:, t])                    # teacher forcing: replace the sampled token
+        dec.step(samp, want_logp=True)
         errs.append((dec.logp - full[:, t]).abs().max().item())
     assert max(errs) < 4e-2, max(errs)
 
