@@ -447,9 +447,11 @@ int mxl_lsh_sort(const int* buckets, int* sorted_idx, int* sorted_pos, int BH, i
 int mxl_chunk_attn_fwd(const void* q, const void* k, const void* v, const int* sorted_pos, void* out, float* lse, int B, int T,
                        int H, int dh, int n_h, int lsh, long long bs, int rs, float drop_p, unsigned long long seed,
                        unsigned site, void* stream);
-/* backward: dq, dk, dv (B,T,H*dh) f32.  n_h > 1: ACCUMULATED with atomics (zero them first).  n_h == 1: every element is written
- * exactly once (no pre-zeroing), and each of the three may instead go out as bf16 through dq16 / dk16 / dv16 (rows of ld16
- * elements; NULL = use the f32 destination) -- e.g. straight into the (N, 3d) operand of the projection-gradient GEMMs.
+/* backward: dq, dk, dv (B, n_h, T, H*dh) f32 -- one (T, H*dh) slab per hash round; every element is written exactly once (plain
+ * stores, no pre-zeroing) and the rounds are summed by the consumer (mxl_lsh_keynorm_bwd_rounds).  (Until round 6 the rounds of
+ * n_h > 1 met in one (B, T, H*dh) buffer through a float atomic per element: 2.9 ms per call at the reference's logged
+ * Reformer-base shape against 0.45 ms now.)  n_h == 1: each of the three may instead go out as bf16 through dq16 / dk16 / dv16 (rows
+ * of ld16 elements; NULL = use the f32 destination) -- e.g. straight into the (N, 3d) operand of the projection-gradient GEMMs.
  * For lsh, dk is w.r.t. the normalised key (see keynorm_bwd); dout has out's layout; dlse (B,n_h,H,T) f32 or NULL */
 int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* sorted_pos, const void* out, const float* lse,
                        const void* dout, const float* dlse, float* dq, float* dk, float* dv, void* dq16, void* dk16, void* dv16,
@@ -459,6 +461,10 @@ int mxl_chunk_attn_bwd(const void* q, const void* k, const void* v, const int* s
  * dk_eff */
 int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, void* dqk, int ld_dqk, int B,
                         int T, int H, int dh, void* stream);
+/* the same over per-round slabs: dq, dk_eff (and dv) (B, n_h, T, H*dh) f32 are summed over the rounds, in round order, on the way
+ * in; dv's sum (the rounds' value gradients) leaves as bf16 rows of ld_dv elements through dv16 (both NULL: no dv) */
+int mxl_lsh_keynorm_bwd_rounds(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, const float* dv, void* dqk,
+                               int ld_dqk, void* dv16, int ld_dv, int B, int T, int H, int dh, int n_h, void* stream);
 /* hash-round merge: out = sum_r softmax_r(lse) * out_r, and its backward (dout_r, dlse) */
 int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T, int H, int dh, int n_h, void* stream);
 int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r, float* dlse,

@@ -668,7 +668,10 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
                                                                 __builtin_bit_cast(mfma_bf16x8, pf), aq[e], 0, 0, 0);
             }
         }
-    float* dqp = p.dq + ((size_t)b * p.T + qpos) * d + h * DH;
+    // the gradient row of (round, position): with several hash rounds every round has its own (T, d) slab -- each element is
+    // written exactly once, with plain stores, and the rounds are summed by mxl_lsh_keynorm_bwd_rounds (until round 6 the rounds
+    // met in ONE (T, d) buffer through a float atomic per element: 16 atomic instructions of 4-byte pieces per lane)
+    float* dqp = p.dq + orow * d + h * DH;
     if (p.dq16) {       // n_h == 1, bf16 straight into the projection-gradient operand
         bf16_t* o16 = p.dq16 + ((size_t)b * p.T + qpos) * p.ld16 + h * DH;
 #pragma unroll
@@ -679,21 +682,13 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
                 if (e0 < DH)
                     *reinterpret_cast<u32x2*>(o16 + e0) = u32x2{pack2bf(aq[e][4 * grp], aq[e][4 * grp + 1]), pack2bf(aq[e][4 * grp + 2], aq[e][4 * grp + 3])};
             }
-    } else if (p.n_h == 1) {   // every (position, head) occurs once: plain 16-byte stores, no atomics, no pre-zeroing needed
+    } else {            // every (round, position, head) occurs once: plain 16-byte stores, no atomics, no pre-zeroing needed
 #pragma unroll
         for (int e = 0; e < EB; e++)
 #pragma unroll
             for (int grp = 0; grp < 4; grp++) {
                 const int e0 = 32 * e + 8 * grp + 4 * hh;
                 if (e0 < DH) *reinterpret_cast<f32x4*>(dqp + e0) = f32x4{aq[e][4 * grp], aq[e][4 * grp + 1], aq[e][4 * grp + 2], aq[e][4 * grp + 3]};
-            }
-    } else {
-#pragma unroll
-        for (int e = 0; e < EB; e++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int ee = 32 * e + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                if (ee < DH) atomicAdd(dqp + ee, aq[e][j]);
             }
     }
 }
@@ -886,7 +881,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
         }
     }
     // the two query chunks that see this key live in different waves of the workgroup (qsel): combine them through LDS so
-    // each (key, e) is written once -- plain stores for n_h == 1, one atomic per element otherwise
+    // each (round, key, e) is written once, with plain stores
     __syncthreads();
     constexpr int RS = DH + 4;                        // padded row: spreads the 32 key rows of a wave over the banks
     float* red = reinterpret_cast<float*>(smem);     // [2 kinds][64 keys][RS] f32 (re-uses the whole query staging area)
@@ -902,8 +897,9 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
     }
     __syncthreads();
     if (qsel == 0) {
-        float* dkp = p.dk + ((size_t)b * p.T + kpos) * d + h * DH;
-        float* dvp = p.dv + ((size_t)b * p.T + kpos) * d + h * DH;
+        const size_t krow_g = ((size_t)b * p.n_h + kslot / p.T) * p.T + kpos;      // (round, position) row: see the query-owner kernel
+        float* dkp = p.dk + krow_g * d + h * DH;
+        float* dvp = p.dv + krow_g * d + h * DH;
 #pragma unroll
         for (int e = 0; e < EB; e++)
 #pragma unroll
@@ -916,16 +912,11 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
                         vk[t] = ak[e][4 * grp + t] + red[krow * RS + e0 + t];
                         vv[t] = av[e][4 * grp + t] + red[64 * RS + krow * RS + e0 + t];
                     }
-                    if (p.n_h == 1) {
-                        const size_t o16 = ((size_t)b * p.T + kpos) * p.ld16 + h * DH + e0;
-                        if (p.dk16) *reinterpret_cast<u32x2*>(p.dk16 + o16) = u32x2{pack2bf(vk[0], vk[1]), pack2bf(vk[2], vk[3])};
-                        else *reinterpret_cast<f32x4*>(dkp + e0) = vk;
-                        if (p.dv16) *reinterpret_cast<u32x2*>(p.dv16 + o16) = u32x2{pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3])};
-                        else *reinterpret_cast<f32x4*>(dvp + e0) = vv;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) { atomicAdd(dkp + e0 + t, vk[t]); atomicAdd(dvp + e0 + t, vv[t]); }
-                    }
+                    const size_t o16 = ((size_t)b * p.T + kpos) * p.ld16 + h * DH + e0;
+                    if (p.dk16) *reinterpret_cast<u32x2*>(p.dk16 + o16) = u32x2{pack2bf(vk[0], vk[1]), pack2bf(vk[2], vk[3])};
+                    else *reinterpret_cast<f32x4*>(dkp + e0) = vk;
+                    if (p.dv16) *reinterpret_cast<u32x2*>(p.dv16 + o16) = u32x2{pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3])};
+                    else *reinterpret_cast<f32x4*>(dvp + e0) = vv;
                 }
             }
     }
@@ -935,8 +926,9 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
 // LSH glue: key-normalisation chain, hash-round combine (HF515:636-655) and its backward
 // =====================================================================================================================
 // dqk[n][h][:] = dq + f * dk' - x * (sum_e dk'_e x_e) * (m + eps)^(-3/2) / dh^(3/2),  m = mean(x^2),  f = (m+eps)^(-1/2)/sqrt(dh)
+// n_h > 1: dq, dk' (and dv) are per-round slabs (B, n_h, T, d), summed here in round order; dv's sum leaves as bf16 through dv16
 __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, const float* dq, const float* dkp, bf16_t* dqk,
-                                       int ld_dqk, int B, int T, int H, int dh) {
+                                       int ld_dqk, int B, int T, int H, int dh, int n_h, const float* dv, bf16_t* dv16, int ld_dv) {
     // dh/8 consecutive lanes own one (b, t, h) vector: 16-byte bf16 loads, 2 x 16-byte fp32 loads per operand
     const int lpv = dh >> 3;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,9 +940,22 @@ __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, c
     const long long n = v_ / H;
     const int t = (int)(n % T), b = (int)(n / T);
     const bf16x8 xv = *reinterpret_cast<const bf16x8*>(qk + (size_t)b * bs + (size_t)t * rs + h * dh + c * 8);
-    const size_t o = (size_t)n * H * dh + (size_t)h * dh + c * 8;
-    const f32x4 k0 = *reinterpret_cast<const f32x4*>(dkp + o), k1 = *reinterpret_cast<const f32x4*>(dkp + o + 4);
-    const f32x4 q0 = *reinterpret_cast<const f32x4*>(dq + o), q1 = *reinterpret_cast<const f32x4*>(dq + o + 4);
+    const size_t rstride = (size_t)T * H * dh;                                                   // one round's slab
+    const size_t o = ((size_t)b * n_h * T + t) * (size_t)(H * dh) + (size_t)h * dh + c * 8;      // round 0
+    f32x4 k0 = *reinterpret_cast<const f32x4*>(dkp + o), k1 = *reinterpret_cast<const f32x4*>(dkp + o + 4);
+    f32x4 q0 = *reinterpret_cast<const f32x4*>(dq + o), q1 = *reinterpret_cast<const f32x4*>(dq + o + 4);
+    for (int r = 1; r < n_h; r++) {
+        k0 += *reinterpret_cast<const f32x4*>(dkp + o + r * rstride); k1 += *reinterpret_cast<const f32x4*>(dkp + o + r * rstride + 4);
+        q0 += *reinterpret_cast<const f32x4*>(dq + o + r * rstride); q1 += *reinterpret_cast<const f32x4*>(dq + o + r * rstride + 4);
+    }
+    if (dv16 && ok) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(dv + o), v1 = *reinterpret_cast<const f32x4*>(dv + o + 4);
+        for (int r = 1; r < n_h; r++) {
+            v0 += *reinterpret_cast<const f32x4*>(dv + o + r * rstride); v1 += *reinterpret_cast<const f32x4*>(dv + o + r * rstride + 4);
+        }
+        const u32x4 wv = {pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(dv16 + (size_t)n * ld_dv + (size_t)h * dh + c * 8) = wv;
+    }
     float x[8], dk[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
     float dqv[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
     float m = 0.f, dot = 0.f;
@@ -989,31 +994,44 @@ __global__ void lsh_combine_kernel(const bf16_t* out_r, const float* lse, bf16_t
     out[gid] = f2bf(acc / den);
 }
 
-// dout_r = w_r * dout ;  dlse_r = w_r * sum_e dout_e (out_r,e - out_e)      one wave-lane group per (b,t,h)
+// dout_r = w_r * dout ;  dlse_r = w_r * sum_e dout_e (out_r,e - out_e).  dh / 8 consecutive lanes own one (b, t, h) vector: 16-byte
+// loads and stores, the dot product by a lane reduction.  (Until round 6: one thread per vector walking its dh elements with 2-byte
+// accesses, 128 bytes apart from its neighbour's -- 6.7 ms per call at the reference's logged shape, a quarter of that step.)
 __global__ void lsh_combine_bwd_kernel(const bf16_t* out_r, const float* lse, const bf16_t* out, const bf16_t* dout,
                                        bf16_t* dout_r, float* dlse, int B, int T, int H, int dh, int n_h) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b,t,h)
-    if (gid >= (long long)B * T * H) return;
-    const int h = (int)(gid % H);
-    const long long n = gid / H;
+    const int lpv = dh >> 3;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long vec = gid / lpv;
+    const int c = (int)(gid % lpv);
+    const bool ok = vec < (long long)B * T * H;
+    const long long v_ = ok ? vec : 0;
+    const int h = (int)(v_ % H);
+    const long long n = v_ / H;
     const int t = (int)(n % T), b = (int)(n / T);
     const int d = H * dh;
     float mx = -INFINITY;
     for (int r = 0; r < n_h; r++) mx = fmaxf(mx, lse[(((size_t)b * n_h + r) * H + h) * T + t]);
     float den = 0.f;
     for (int r = 0; r < n_h; r++) den += __expf(lse[(((size_t)b * n_h + r) * H + h) * T + t] - mx);
-    const size_t o = (size_t)n * d + (size_t)h * dh;
+    const size_t o = (size_t)n * d + (size_t)h * dh + c * 8;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(dout + o), ov = *reinterpret_cast<const bf16x8*>(out + o);
+    float g[8], oo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { g[j] = bf2f((bf16_t)gv[j]); oo[j] = bf2f((bf16_t)ov[j]); }
     for (int r = 0; r < n_h; r++) {
         const size_t si = (((size_t)b * n_h + r) * H + h) * T + t;
         const float w = __expf(lse[si] - mx) / den;
-        const size_t orr = (((size_t)b * n_h + r) * T + t) * d + (size_t)h * dh;
-        float dot = 0.f;
-        for (int e = 0; e < dh; e++) {
-            const float g = bf2f(dout[o + e]);
-            dot += g * (bf2f(out_r[orr + e]) - bf2f(out[o + e]));
-            dout_r[orr + e] = f2bf(w * g);
+        const size_t orr = (((size_t)b * n_h + r) * T + t) * d + (size_t)h * dh + c * 8;
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(out_r + orr);
+        float dot = 0.f, wg[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { dot += g[j] * (bf2f((bf16_t)rv[j]) - oo[j]); wg[j] = w * g[j]; }
+        for (int off = 1; off < lpv; off <<= 1) dot += __shfl_xor(dot, off, 64);
+        if (ok) {
+            const u32x4 wv = {pack2bf(wg[0], wg[1]), pack2bf(wg[2], wg[3]), pack2bf(wg[4], wg[5]), pack2bf(wg[6], wg[7])};
+            *reinterpret_cast<u32x4*>(dout_r + orr) = wv;
+            if (c == 0) dlse[si] = w * dot;
         }
-        dlse[si] = w * dot;
     }
 }
 
@@ -1307,7 +1325,21 @@ extern "C" int mxl_lsh_keynorm_bwd(const void* qk, long long bs, int rs, const f
     MXL_CHECK_ARG((dh % 8) == 0 && (64 % (dh / 8)) == 0);
     const long long n = (long long)B * T * H * (dh / 8);
     hipLaunchKernelGGL(lsh_keynorm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, ld_dqk, B, T, H, dh);
+                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, ld_dqk, B, T, H, dh, 1, nullptr, nullptr, 0);
+    MXL_LAUNCH_CHECK();
+    return MXL_OK;
+}
+
+extern "C" int mxl_lsh_keynorm_bwd_rounds(const void* qk, long long bs, int rs, const float* dq, const float* dk_eff, const float* dv,
+                                          void* dqk, int ld_dqk, void* dv16, int ld_dv, int B, int T, int H, int dh, int n_h,
+                                          void* stream) {
+    MXL_CHECK_ARG(qk && dq && dk_eff && dqk && B > 0 && T > 0 && H > 0 && dh > 0 && n_h >= 1 && ld_dqk >= H * dh && (ld_dqk % 8) == 0);
+    MXL_CHECK_ARG((dh % 8) == 0 && (64 % (dh / 8)) == 0);
+    MXL_CHECK_ARG((dv == nullptr) == (dv16 == nullptr));
+    if (dv16) MXL_CHECK_ARG(ld_dv >= H * dh && (ld_dv % 8) == 0 && ((uintptr_t)dv16 % 16) == 0);
+    const long long n = (long long)B * T * H * (dh / 8);
+    hipLaunchKernelGGL(lsh_keynorm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qk, bs, rs, dq, dk_eff, (bf16_t*)dqk, ld_dqk, B, T, H, dh, n_h, dv, (bf16_t*)dv16, ld_dv);
     MXL_LAUNCH_CHECK();
     return MXL_OK;
 }
@@ -1324,7 +1356,8 @@ extern "C" int mxl_lsh_combine(const void* out_r, const float* lse, void* out, i
 extern "C" int mxl_lsh_combine_bwd(const void* out_r, const float* lse, const void* out, const void* dout, void* dout_r,
                                    float* dlse, int B, int T, int H, int dh, int n_h, void* stream) {
     MXL_CHECK_ARG(out_r && lse && out && dout && dout_r && dlse && B > 0 && T > 0 && n_h >= 1);
-    const long long n = (long long)B * T * H;
+    MXL_CHECK_ARG(dh > 0 && (dh % 8) == 0 && (64 % (dh / 8)) == 0);
+    const long long n = (long long)B * T * H * (dh / 8);
     hipLaunchKernelGGL(lsh_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)out_r, lse, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dout_r, dlse, B, T, H, dh, n_h);
     MXL_LAUNCH_CHECK();

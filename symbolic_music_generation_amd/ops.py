@@ -699,7 +699,8 @@ def chunk_attn_fwd(q, k, v, spos, out, lse, B, T, H, dh, n_h, lsh, bs, rs, drop_
 
 def chunk_attn_bwd(q, k, v, spos, out, lse, dout, dlse, dq, dk, dv, B, T, H, dh, n_h, lsh, bs, rs, drop_p=0.0, seed=0, site=0,
                    dq16=None, dk16=None, dv16=None, ld16=0):
-    """dq / dk / dv: f32 (B*T, d) (may be None when the matching bf16 destination is given; n_h == 1 only)"""
+    """dq / dk / dv: f32 (B, n_h, T, d), one slab per hash round, every element written once (may be None when the matching bf16
+    destination is given; n_h == 1 only)"""
     check(lib().mxl_chunk_attn_bwd(_p(q), _p(k), _p(v), _p(spos), _p(out), _p(lse), _p(dout), _p(dlse), _p(dq), _p(dk), _p(dv),
                                    _p(dq16), _p(dk16), _p(dv16), int(ld16),
                                    B, T, H, dh, n_h, int(lsh), bs, rs, float(drop_p), seed, site, _stream()),
@@ -709,6 +710,12 @@ def chunk_attn_bwd(q, k, v, spos, out, lse, dout, dlse, dq, dk, dv, B, T, H, dh,
 def lsh_keynorm_bwd(qk, bs, rs, dq, dk_eff, dqk, B, T, H, dh, ld_dqk=None):
     check(lib().mxl_lsh_keynorm_bwd(_p(qk), bs, rs, _p(dq), _p(dk_eff), _p(dqk), int(ld_dqk or H * dh), B, T, H, dh, _stream()),
           'mxl_lsh_keynorm_bwd')
+
+
+def lsh_keynorm_bwd_rounds(qk, bs, rs, dq, dk_eff, dv, dqk, dv16, B, T, H, dh, n_h, ld_dqk=None, ld_dv=None):
+    """lsh_keynorm_bwd over per-round slabs (B, n_h, T, d) f32; dv (optional) summed over the rounds into dv16 (bf16)"""
+    check(lib().mxl_lsh_keynorm_bwd_rounds(_p(qk), bs, rs, _p(dq), _p(dk_eff), _p(dv), _p(dqk), int(ld_dqk or H * dh), _p(dv16),
+                                           int(ld_dv or H * dh), B, T, H, dh, n_h, _stream()), 'mxl_lsh_keynorm_bwd_rounds')
 
 
 def lsh_combine(out_r, lse, out, B, T, H, dh, n_h):

@@ -272,7 +272,9 @@ class RFEngine:
             ws.g1 = torch.empty(N, d, **bf); ws.g2 = torch.empty(N, d, **bf)
             ws.t1 = torch.empty(N, d, **bf); ws.t2 = torch.empty(N, d, **bf)
             ws.dF = torch.empty(N, Fi, **bf)
-            ws.dq = torch.empty(N, d, **f32); ws.dk = torch.empty(N, d, **f32); ws.dv = torch.empty(N, d, **f32)
+            # one (T, d) slab per hash round: the chunk kernels write every element once, the key-normalisation backward sums the rounds
+            ws.dq = torch.empty(B * n_h * T, d, **f32); ws.dk = torch.empty(B * n_h * T, d, **f32)
+            ws.dv = torch.empty(B * n_h * T, d, **f32) if n_h > 1 else None
             ws.dqkv = torch.empty(N, 3 * d, **bf)
             ws.dout_r = torch.empty(B, n_h, T, d, **bf)
             ws.dlse = torch.empty(B, n_h, H, T, **f32)
@@ -513,15 +515,14 @@ class RFEngine:
                     o_in, do_in, dl_in = ws.out_r[l], ws.dout_r, ws.dlse
                 else:
                     o_in, do_in, dl_in = ws.av[l], dav, None
-                if n_h > 1:
-                    ws.dq.zero_(); ws.dk.zero_(); ws.dv.zero_()          # accumulated over the hash rounds with atomics
                 ops.chunk_attn_bwd(qkv, qkv, qkv[:, d:], None if getattr(ws, 'single', False) else ws.spos[l], o_in, ws.lse[l], do_in,
                                    dl_in, ws.dq, ws.dk, ws.dv if n_h > 1 else None, B, T, H,
                                    dh, n_h, 1, bs, rs, drop_p=ws.p_lsh, seed=seed, site=self._site(l, 0),
                                    dv16=None if n_h > 1 else dqkv[:, d:], ld16=0 if n_h > 1 else 2 * d)
-                ops.lsh_keynorm_bwd(qkv, bs, rs, ws.dq, ws.dk, dqkv, B, T, H, dh, ld_dqk=2 * d)
-                if n_h > 1:
-                    dqkv[:, d:].copy_(ws.dv)
+                if n_h > 1:     # the rounds' slabs summed on the way in; the value gradient's sum goes out as bf16 beside dqk
+                    ops.lsh_keynorm_bwd_rounds(qkv, bs, rs, ws.dq, ws.dk, ws.dv, dqkv, dqkv[:, d:], B, T, H, dh, n_h, ld_dqk=2 * d, ld_dv=2 * d)
+                else:
+                    ops.lsh_keynorm_bwd(qkv, bs, rs, ws.dq, ws.dk, dqkv, B, T, H, dh, ld_dqk=2 * d)
             ops.gemm(dqkv, ws.hn[l], self._proj_w(l, kind, G), nproj * d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(nproj * d, d))
             dhn = ws.dF.view(-1)[:N * d].view(N, d)

@@ -73,7 +73,7 @@ def _chunk_case(dev, B, T, H, dh, n_h, lsh, drop_p=0.0, seed=0):
 
 
 @pytest.mark.parametrize('B,T,H,dh,n_h,lsh', [(2, 256, 2, 64, 1, 0), (1, 192, 2, 64, 1, 0), (2, 256, 2, 32, 1, 0),
-                                              (2, 256, 2, 64, 1, 1), (1, 256, 2, 64, 2, 1), (1, 128, 4, 16, 1, 1)])
+                                              (2, 256, 2, 64, 1, 1), (1, 256, 2, 64, 2, 1), (2, 128, 3, 32, 3, 1), (1, 128, 4, 16, 1, 1)])
 def test_chunk_attention_fwd_bwd(dev, B, T, H, dh, n_h, lsh):
     from symbolic_music_generation_amd import ops
     c = _chunk_case(dev, B, T, H, dh, n_h, lsh)
@@ -100,19 +100,31 @@ def test_chunk_attention_fwd_bwd(dev, B, T, H, dh, n_h, lsh):
     do_s = dout.float().view(B, n_h, T, H, dh)[bi, rnd, spos, hi]
     dl_s = dlse[bi, rnd, hi, spos]
     (c['out_s'] * do_s).sum().add((c['lse_s'] * dl_s).sum()).backward()
-    dq = torch.zeros(B, T, d, device=dev); dk = torch.zeros_like(dq); dv = torch.zeros_like(dq)
+    # one (T, d) slab per hash round, every element written exactly once: no zero-fill (NaN-filled here to prove it)
+    dq = torch.full((B, n_h, T, d), float('nan'), device=dev); dk = dq.clone(); dv = dq.clone()
     ops.chunk_attn_bwd(qd, kd, vd, sp, out, lse, dout.to(dev), dlse.to(dev) if n_h > 1 else None, dq, dk, dv, B, T, H, dh,
                        n_h, lsh, T * d, d)
+    assert not torch.isnan(dq).any() and not torch.isnan(dk).any() and not torch.isnan(dv).any()
     ref_dv = c['vh'].grad.transpose(1, 2).reshape(B, T, d)
-    assert rel_err(dv.cpu(), ref_dv) < 2e-2
-    if lsh:
+    assert rel_err(dv.sum(1).cpu(), ref_dv) < 2e-2
+    if lsh and n_h > 1:
+        # the rounds summed by the key-normalisation backward (dq, dk') and on the way out (dv, bf16, a column block of a wider matrix)
+        wide = torch.full((B * T, 2 * d + 8), float('nan'), device=dev, dtype=torch.bfloat16)
+        ops.lsh_keynorm_bwd_rounds(qd, T * d, d, dq, dk, dv, wide, wide[:, d:], B, T, H, dh, n_h, ld_dqk=2 * d + 8, ld_dv=2 * d + 8)
+        ref = c['qh'].grad.transpose(1, 2).reshape(B * T, d)
+        assert rel_err(wide[:, :d].cpu(), ref) < 2e-2
+        assert torch.equal(wide[:, d:2 * d], dv.sum(1).view(B * T, d).to(torch.bfloat16)) and torch.isnan(wide[:, 2 * d:].float()).all()
+        one = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16)
+        ops.lsh_keynorm_bwd(qd, T * d, d, dq.sum(1), dk.sum(1), one, B, T, H, dh)        # == the one-slab form on the summed slabs
+        assert torch.equal(one, wide[:, :d].contiguous())
+    elif lsh:
         dqk = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
         ops.lsh_keynorm_bwd(qd, T * d, d, dq, dk, dqk, B, T, H, dh)
         ref = c['qh'].grad.transpose(1, 2).reshape(B, T, d)
         assert rel_err(dqk.cpu(), ref) < 2e-2
     else:
-        assert rel_err(dq.cpu(), c['qh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
-        assert rel_err(dk.cpu(), c['kh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
+        assert rel_err(dq.view(B, T, d).cpu(), c['qh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
+        assert rel_err(dk.view(B, T, d).cpu(), c['kh'].grad.transpose(1, 2).reshape(B, T, d)) < 2e-2
     if n_h == 1:
         # one round: the bf16 destinations (strided rows of a wider matrix, as the engine passes them) hold exactly the rounded
         # f32 results, and need no zero-fill
