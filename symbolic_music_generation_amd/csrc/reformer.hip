@@ -975,23 +975,30 @@ __global__ void lsh_keynorm_bwd_kernel(const bf16_t* qk, long long bs, int rs, c
     }
 }
 
-// out[b,t,h,:] = sum_r w_r out_r[b,r,t,h,:],  w = softmax_r(lse[b,r,h,t])
+// out[b,t,h,:] = sum_r w_r out_r[b,r,t,h,:],  w = softmax_r(lse[b,r,h,t]); a thread owns 8 consecutive elements of one (b, t, h)
+// vector (16-byte loads and stores; the round weights once per thread instead of once per element)
 __global__ void lsh_combine_kernel(const bf16_t* out_r, const float* lse, bf16_t* out, int B, int T, int H, int dh, int n_h) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int d = H * dh;
-    if (gid >= (long long)B * T * d) return;
-    const int k = (int)(gid % d), h = k / dh;
-    const long long n = gid / d;
+    const int d = H * dh, cpr = d >> 3;
+    if (gid >= (long long)B * T * cpr) return;
+    const int c = (int)(gid % cpr), h = (c * 8) / dh;
+    const long long n = gid / cpr;
     const int t = (int)(n % T), b = (int)(n / T);
     float mx = -INFINITY;
     for (int r = 0; r < n_h; r++) mx = fmaxf(mx, lse[(((size_t)b * n_h + r) * H + h) * T + t]);
-    float den = 0.f, acc = 0.f;
+    float den = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
     for (int r = 0; r < n_h; r++) {
         const float w = __expf(lse[(((size_t)b * n_h + r) * H + h) * T + t] - mx);
         den += w;
-        acc += w * bf2f(out_r[(((size_t)b * n_h + r) * T + t) * d + k]);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(out_r + (((size_t)b * n_h + r) * T + t) * d + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] += w * bf2f((bf16_t)v[j]);
     }
-    out[gid] = f2bf(acc / den);
+    const u32x4 wv = {pack2bf(acc[0] / den, acc[1] / den), pack2bf(acc[2] / den, acc[3] / den), pack2bf(acc[4] / den, acc[5] / den),
+                      pack2bf(acc[6] / den, acc[7] / den)};
+    *reinterpret_cast<u32x4*>(out + (size_t)n * d + c * 8) = wv;
 }
 
 // dout_r = w_r * dout ;  dlse_r = w_r * sum_e dout_e (out_r,e - out_e).  dh / 8 consecutive lanes own one (b, t, h) vector: 16-byte
@@ -1345,8 +1352,8 @@ extern "C" int mxl_lsh_keynorm_bwd_rounds(const void* qk, long long bs, int rs, 
 }
 
 extern "C" int mxl_lsh_combine(const void* out_r, const float* lse, void* out, int B, int T, int H, int dh, int n_h, void* stream) {
-    MXL_CHECK_ARG(out_r && lse && out && B > 0 && T > 0 && n_h >= 1);
-    const long long n = (long long)B * T * H * dh;
+    MXL_CHECK_ARG(out_r && lse && out && B > 0 && T > 0 && n_h >= 1 && dh > 0 && (dh % 8) == 0);
+    const long long n = (long long)B * T * H * (dh / 8);
     hipLaunchKernelGGL(lsh_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)out_r, lse, (bf16_t*)out, B, T, H, dh, n_h);
     MXL_LAUNCH_CHECK();
