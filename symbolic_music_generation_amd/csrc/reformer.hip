@@ -359,6 +359,12 @@ struct ChunkP {
     unsigned thresh; float dscale; unsigned long long seed; unsigned site;
 };
 
+#ifndef CHUNK_BWD_WPE
+#define CHUNK_BWD_WPE 3                    // waves per SIMD the backward chunk kernels are compiled for: these kernels are bound by the latency
+                                           // of their gathers (sorted position -> K / V row), so a third workgroup per CU is worth more than the
+                                           // five registers the key-owner kernel spills for it: 312 -> 269 us and 411 -> 369 us at C4 (same-box A/B,
+                                           // profiles/r06_rf_ab1_waves_per_simd.log)
+#endif
 template <int DH> struct GeoC {
     static constexpr int KS = DH / 16, EB = (DH + 31) / 32, ROWB = DH * 2, CH = DH / 8;
     static constexpr int ROWS = 192;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_fwd_kernel(ChunkP p) {
 // With dropout: O = (keep*P/(1-p)) V;  dS = P * (keep*dPd/(1-p) - delta) + dlse * P,  delta = rowsum(dO * O).
 // =====================================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
+__global__ __launch_bounds__(256, CHUNK_BWD_WPE) void chunk_attn_bwd_q_kernel(ChunkP p) {
     using G = GeoC<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void chunk_attn_bwd_q_kernel(ChunkP p) {
 
 // key-owner: workgroup = key chunk kc; wave w owns 32 keys of it for one of the two query chunks: w = 2*qsel + khalf
 template <int DH>
-__global__ __launch_bounds__(256, 1) void chunk_attn_bwd_kv_kernel(ChunkP p) {
+__global__ __launch_bounds__(256, CHUNK_BWD_WPE) void chunk_attn_bwd_kv_kernel(ChunkP p) {
     using G = GeoC<DH>;
     constexpr int KS = G::KS, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
