@@ -168,13 +168,13 @@ int mxl_relattn_drd_recompute(const void* dg, const void* qr, float* d_rd, int B
                               const float* lse, const float* delta, float scale, int Kc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Round 4: the attention backward as ONE pass over the score cells (dh = 64, T % 32 == 0, M % 256 == 0, Kc % 32 == 0;
- * MXL_EUNSUPPORTED otherwise -- use mxl_relattn_bwd + mxl_relattn_drd).  Same gradients as that pair, no dg tensor:
+ * Round 4: the attention backward as ONE pass over the score cells (dh = 64, T % 32 == 0, M % 32 == 0 [round 6; M % 256 until then:
+ * the reference's `small` preset has mem_len 128], Kc % 32 == 0; MXL_EUNSUPPORTED otherwise -- use mxl_relattn_bwd + mxl_relattn_drd).  Same gradients as that pair, no dg tensor:
  *   a workgroup owns 256 keys of one (sequence, head): dk, dv written once; d_rd accumulated on chip per 32-distance block and
  *   added with float atomics (d_rd (M, drd_ld) f32, +=); the partial dq of every (query tile, key block) pair goes to a
  *   slab in `ws` (mxl_relattn_bwd_fused_ws_bytes bytes, opaque) and a finishing kernel sums a query's slabs in fp32 and rounds dq
  *   to bf16 once.  The slabs are bf16 in the shipped build: each (query, key block) partial is rounded to bf16 before that sum,
- *   at most M / 256 + 1 roundings per dq element (fp32 slabs: build with -DMXL_SLAB_BF16=0; the 12-layer gradient errors are the
+ *   at most ceil(M / 256) + 1 roundings per dq element (fp32 slabs: build with -DMXL_SLAB_BF16=0; the 12-layer gradient errors are the
  *   same to four digits either way).
  *   d_r_w_bias, d_r_r_bias (H, 64) f32 are accumulated (+=), each with its own gradient (no fix-up pass).
  * Zero memories (Kc < M + T; musicnlp/models/transformer_xl.py:163-171 calls the model without mems, so upstream init_mems
@@ -207,7 +207,7 @@ int mxl_relattn_fwd_phantom2(const void* q, const void* k, const void* v, const 
 /* d_rd[delta, h*64 + e] += sum over the PHANTOM cells (key position i - delta below T - Kc) of dG[b,h,i,delta] * qr[b,i,h,e],
  * qr = q + r_r_bias, with dG[i,delta] = -scale * delta_i * exp(scale * qr_i . rd[delta] - lse_i) rebuilt on MFMA (two products and
  * one exponential per cell, nothing streamed) -- cell by cell, so that together with mxl_relattn_bwd_fused every (query, distance)
- * pair is counted once.  (T - Kc) % 64 == 0, T % 32 == 0, M % 256 == 0, M <= 8192, dh == 64.
+ * pair is counted once.  (T - Kc) % 64 == 0, T % 32 == 0, M % 32 == 0, M <= 8192, dh == 64.
  * `ws` (mxl_relattn_drd_phantom_ws_bytes bytes, 16-byte aligned) holds one record per (sequence, head, 32-query tile): the tile's
  * bf16((q + r_r_bias) * scale * log2 e) rows in the kernel's LDS image order and -lse * log2 e of its queries -- written by the
  * forward (mxl_relattn_fwd_phantom2(..., ph_ws)) or by mxl_relattn_drd_phantom_prep; `delta` (B,H,T) f32 is the array

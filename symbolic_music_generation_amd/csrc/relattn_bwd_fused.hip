@@ -1027,7 +1027,7 @@ extern "C" int mxl_debug_fused_stamps(unsigned long long* host_out16) {
 
 extern "C" size_t mxl_relattn_bwd_fused_ws_bytes(int B, int T, int H, int dh, int M) {
     if (B <= 0 || T <= 0 || H <= 0 || dh != 64 || M <= 0) return 0;
-    return (size_t)(M / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(slab_t);
+    return (size_t)((M + KBLK - 1) / KBLK + 1) * (size_t)B * T * H * 64 * sizeof(slab_t);     // a query tile's M + 31 keys touch at most that many key blocks
 }
 
 extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v, const void* rd, const float* r_w_bias,
@@ -1041,7 +1041,7 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
                   d_r_r_bias && ws);
     if (dh != 64) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T && drd_ld >= H * 64);
-    if ((T % 32) != 0 || (M % 256) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
+    if ((T % 32) != 0 || (M % 32) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
     // key positions below the first stored one are phantom distances: the caller must have their dq part in oph / mph (zero memories),
     // unless every visible key is stored (Kc == M + T)
     MXL_CHECK_ARG(Kc == M + T || (oph && mph));
@@ -1083,7 +1083,7 @@ extern "C" int mxl_relattn_dq_finish(const void* ws, const void* oph, const floa
                                      float* d_r_r_bias, int B, int T, int H, int dh, int M, int Kc, long long o_bs, int o_rs,
                                      long long dq_bs, int dq_rs, float scale, void* stream) {
     MXL_CHECK_ARG(ws && lse && delta && dq && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
-    if (dh != 64 || (T % 32) != 0 || (M % 256) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
+    if (dh != 64 || (T % 32) != 0 || (M % 32) != 0 || (Kc % 32) != 0) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG(Kc == M + T || (oph && mph));
     MXL_CHECK_ARG((o_rs % 8) == 0 && (o_bs % 8) == 0 && (dq_rs % 8) == 0 && (dq_bs % 8) == 0 && ((uintptr_t)dq % 16) == 0 &&
                   ((uintptr_t)ws % 16) == 0 && (oph == nullptr || ((uintptr_t)oph % 16) == 0));

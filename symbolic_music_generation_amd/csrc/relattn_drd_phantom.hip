@@ -165,8 +165,9 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            const int dd = d0 + 64 * wid + 32 * nt + r;
-            rdf[nt][ks] = *reinterpret_cast<const bf16x8*>(p.rd + (size_t)dd * p.rd_rs + h * 64 + 16 * ks + 8 * hh);
+            const int dd = d0 + 64 * wid + 32 * nt + r;      // (M need not be a multiple of 256: the last block's rows past M - 1 are zeros
+            const bf16x8 zz = {0, 0, 0, 0, 0, 0, 0, 0};       // here and are not written back in the epilogue)
+            rdf[nt][ks] = dd < p.M ? *reinterpret_cast<const bf16x8*>(p.rd + (size_t)dd * p.rd_rs + h * 64 + 16 * ks + 8 * hh) : zz;
         }
     // ---- LDS addresses (bytes inside a stage)
     const int A0 = r * 128 + ((hh ^ ph_swz(r)) << 4);                    // row read, k-step ks: A0 ^ (ks << 5)
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void relattn_drd_phantom_kernel(PhP p) {
         for (int t = 0; t < 16; t++) {
             const int dd = d0 + 64 * wid + 32 * nt + (t & 3) + 8 * (t >> 2) + 4 * hh;
             float* dst = p.drd + (size_t)dd * p.drd_ld + h * 64 + r;
+            if (dd < p.M) {
 #pragma unroll
-            for (int et = 0; et < 2; et++) {
-                atomicAdd(dst + 32 * et, acc[nt][et][t] * nsc);
+                for (int et = 0; et < 2; et++) atomicAdd(dst + 32 * et, acc[nt][et][t] * nsc);
             }
         }
     STAMP(14)
@@ -384,7 +385,7 @@ extern "C" int mxl_relattn_drd_phantom_prep(const void* q, long long q_bs, int q
 extern "C" int mxl_relattn_drd_phantom(const void* ws, const float* delta, float* d_rd, int B, int T, int H, int dh, int M, int drd_ld,
                                        const void* rd, int rd_rs, int Kc, void* stream) {
     MXL_CHECK_ARG(ws && delta && d_rd && rd && B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
-    if (dh != 64 || (T % 32) != 0 || (M % 256) != 0 || M / 256 > 32) return MXL_EUNSUPPORTED;
+    if (dh != 64 || (T % 32) != 0 || (M % 32) != 0 || (M + 255) / 256 > 32) return MXL_EUNSUPPORTED;
     MXL_CHECK_ARG(((T - Kc) % 64) == 0);
     MXL_CHECK_ARG((rd_rs % 8) == 0 && drd_ld >= H * 64 && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)rd % 16) == 0);
     // 32-bit byte offsets inside one sequence's records and inside delta
@@ -404,7 +405,7 @@ extern "C" int mxl_relattn_drd_phantom(const void* ws, const float* delta, float
     // Batch groups sized for the LONGEST distance block (steps per sequence: min(T / 32, (256 k + pz) / 32 + 8), 8 .. 64 at M = 2048),
     // `fac` times as many of them as resident workgroup slots (two per CU), the long blocks dispatched first; a shorter block takes a
     // power-of-two number of groups per workgroup so that every workgroup runs between half and all of the longest one's steps.
-    const int nk = M / 256, spb = T / 32;
+    const int nk = (M + 255) / 256, spb = T / 32;
     int nph[32], ref = 0;
     for (int k = 0; k < nk; k++) {
         const int v = (256 * k + p.pz) / 32 + 8;          // (256 k + pz is a multiple of 32; negative: no phantom cell at all)

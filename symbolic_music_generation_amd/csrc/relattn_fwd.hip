@@ -775,7 +775,8 @@ static int relattn_fwd_launch(const void* q, const void* k, const void* v, const
     MXL_CHECK_ARG(q && k && v && rd && r_w_bias && r_r_bias && out);
     if (oph_all) MXL_CHECK_ARG(oph && ((T - Kc) % 64) == 0);
     if (ph_ws) MXL_CHECK_ARG(oph_all && dh == 64 && ((uintptr_t)ph_ws % 16) == 0);
-    if (oph) MXL_CHECK_ARG(mph && (M % 256) == 0 && (T % 32) == 0 && ((uintptr_t)oph % 8) == 0);
+    // (oph over the all-phantom 256-distance blocks needs whole blocks; over every phantom cell, oph_all, any multiple of 32 distances)
+    if (oph) MXL_CHECK_ARG(mph && (M % (oph_all ? 32 : 256)) == 0 && (T % 32) == 0 && ((uintptr_t)oph % 8) == 0);
     MXL_CHECK_ARG(B > 0 && T > 0 && H > 0 && M > 0 && Kc >= T && Kc <= M + T);
     MXL_CHECK_ARG((q_rs % 8) == 0 && (kv_rs % 8) == 0 && (rd_rs % 8) == 0 && (o_rs % 4) == 0);
     MXL_CHECK_ARG((q_bs % 8) == 0 && (kv_bs % 8) == 0 && (o_bs % 4) == 0);

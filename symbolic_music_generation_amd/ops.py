@@ -262,7 +262,7 @@ def fused_bwd_applies(*, T, dh, M, Kc, B=None, H=None) -> bool:
     """the shapes mxl_relattn_bwd_fused (and, with zero memories, mxl_relattn_drd_phantom) take -- one pass over the score cells, no
     dG tensor: the training shapes of every BASELINE config; anything else stays on relattn_bwd's three kernels.  B, H (optional):
     also the 32-bit offset limits of the phantom-cell kernel's buffer addressing."""
-    ok = (dh == 64 and T % 32 == 0 and M % 256 == 0 and M <= 8192 and Kc % 32 == 0 and (T - Kc) % 64 == 0
+    ok = (dh == 64 and T % 32 == 0 and M % 32 == 0 and M <= 8192 and Kc % 32 == 0 and (T - Kc) % 64 == 0
           and os.environ.get('MXL_NO_FUSED_BWD') != '1')
     if ok and B is not None and H is not None and Kc < M + T:
         ok = H * (T // 32) * 4352 < 2 ** 31 and B * H * T * 4 < 2 ** 31

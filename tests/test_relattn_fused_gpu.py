@@ -58,7 +58,7 @@ def _run_fused(dev, qkv, rd, rwb, rrb, dout, B, T, H, dh, M, Kc, records_from_fo
 
 
 FUSED_CASES = [
-    # B, T, H, dh, M, Kc, name          (dh = 64, T % 32 == 0, M % 256 == 0, (T - Kc) % 64 == 0)
+    # B, T, H, dh, M, Kc, name          (dh = 64, T % 32 == 0, M % 32 == 0, (T - Kc) % 64 == 0)
     (2, 512, 2, 64, 512, 512, 'zero mems, T = M (the training shape in small)'),
     (1, 256, 2, 64, 256, 512, 'full carried memory (Kc = M + T)'),
     (3, 768, 1, 64, 1024, 768 + 192, 'partial memory, T < M'),
@@ -67,6 +67,12 @@ FUSED_CASES = [
     (1, 64, 1, 64, 256, 64, 'T < M, zero mems: mostly phantom distances'),
     (1, 1280, 1, 64, 512, 1280, 'T = 2.5 M, zero mems: queries past the memory window'),
     (1, 96, 2, 64, 512, 96 + 512, 'short segment over a long carried memory'),
+    # round 6: M need only be a multiple of 32 (the reference's `small` preset has mem_len 128: musicnlp/models/transformer_xl.py:16-34)
+    (2, 1024, 2, 64, 128, 1024, 'mem_len 128 (the reference small preset), zero mems'),
+    (1, 512, 2, 64, 128, 512 + 128, 'mem_len 128, full carried memory'),
+    (2, 512, 1, 64, 384, 512, 'mem_len 384: a window of one and a half key blocks'),
+    (1, 256, 2, 64, 96, 256 + 64, 'mem_len 96, partial memory'),
+    (1, 640, 1, 64, 608, 640, 'mem_len 608 = 19 distance blocks, zero mems'),
 ]
 
 
@@ -159,9 +165,57 @@ def test_relattn_bwd_fused_rejects_shapes_it_does_not_take(dev):
     from symbolic_music_generation_amd._lib import lib
     assert not ops.fused_bwd_applies(T=200, dh=64, M=256, Kc=200)
     assert not ops.fused_bwd_applies(T=256, dh=32, M=256, Kc=256)
-    assert not ops.fused_bwd_applies(T=256, dh=64, M=320, Kc=256)
+    assert ops.fused_bwd_applies(T=256, dh=64, M=320, Kc=256)               # (round 6: any multiple of 32 distances)
+    assert not ops.fused_bwd_applies(T=256, dh=64, M=330, Kc=256)
     assert not ops.fused_bwd_applies(T=256, dh=64, M=256, Kc=256 + 32)      # first stored key not on a 64-key tile boundary
     assert ops.fused_bwd_applies(T=2048, dh=64, M=2048, Kc=2048)
     assert not ops.fused_bwd_applies(T=2048, dh=64, M=16384, Kc=2048)       # the phantom-cell kernel tables 32 distance blocks
     assert not ops.fused_bwd_applies(T=2048, dh=64, M=2048, Kc=2048, B=8192, H=64)      # 32-bit offsets of its buffer addressing
     assert lib().mxl_relattn_bwd_fused_ws_bytes(2, 256, 2, 32, 256) == 0
+
+
+@pytest.mark.parametrize('with_mem', [False, True])
+def test_reference_small_preset_default_memory_trains_on_the_fused_pass(dev, monkeypatch, with_mem):
+    """the reference's `small` preset with its DEFAULT mem_len = max(128, 1024 // 8) = 128 (musicnlp/models/transformer_xl.py:16-34;
+    d = 512, 8 heads of 64), two layers: the engine picks the fused backward (until round 6: M % 256 != 0 -> the three-kernel path);
+    its gradients are those of the three-kernel path from the same forward (1e-2 per tensor) and match the oracle's autograd as
+    closely as that path does (at this test's weight scale -- 3 x the initialisation -- both sit at 6-10 % on every tensor)"""
+    from tests.test_xl_model_gpu import _pair
+    from symbolic_music_generation_amd import ops
+    from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig
+    assert MyTransfoXLConfig('small', vocab_size=1190).mem_len == 128          # the preset's own default
+    B, T, M, d = 2, 384, 128, 512
+    ids = torch.randint(4, 1190, (B, T), generator=torch.Generator().manual_seed(1))
+    lab = ids.clone(); lab[0, 300:] = -100
+    mems_r = [torch.randn(M, B, d, generator=torch.Generator().manual_seed(2 + i)).to(torch.bfloat16).float() for i in range(2)] if with_mem else None
+
+    def run(legacy):
+        monkeypatch.setenv('MXL_NO_FUSED_BWD', '1' if legacy else '0')
+        ref, m = _pair(dev, preset='small', n_layer=2, mem_len=128, max_length=384, seed=7)
+        assert m.config.mem_len == 128 and m.config.d_head == 64
+        m.train()
+        m.zero_grad()
+        o = m(input_ids=ids.to(dev), labels=lab.to(dev), mems=[x.to(dev) for x in mems_r] if with_mem else None)
+        m.backward()
+        torch.cuda.synchronize()
+        assert m.engine._last.fused_bwd == (not legacy)
+        return ref, o.loss.item(), {n: m.engine.g32(n).float().cpu().clone() for n, _ in ref.named_parameters() if n != 'crit.out_layers.0.weight'}
+
+    assert ops.fused_bwd_applies(T=T, dh=64, M=M, Kc=T + (M if with_mem else 0), B=B, H=8)
+    ref, loss_f, gf = run(False)
+    _, loss_l, gl = run(True)
+    assert abs(loss_f - loss_l) <= 1e-6 * abs(loss_l)      # (the same forward kernels; the loss reduction sums with float atomics)
+    ref.train()
+    ro = ref(ids, labels=lab, mems=mems_r)
+    ro.loss.backward()
+    assert abs(loss_f - ro.loss.item()) / ro.loss.item() < 1e-2
+    bad = {}
+    for name, p in ref.named_parameters():
+        if name not in gf:
+            continue
+        e_paths = ((gf[name] - gl[name]).norm() / (gl[name].norm() + 1e-12)).item()
+        e_f = ((gf[name] - p.grad).norm() / (p.grad.norm() + 1e-12)).item()
+        e_l = ((gl[name] - p.grad).norm() / (p.grad.norm() + 1e-12)).item()
+        if e_paths > 1e-2 or e_f > max(0.12, 1.1 * e_l):
+            bad[name] = (e_paths, e_f, e_l)
+    assert not bad, f'(fused vs three-kernel, fused vs oracle, three-kernel vs oracle): {bad}'
