@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument('--eager', action='store_true', help='decode leg without hipGraph replay (PMC passes: rocprofv3 cannot '
                                                          'collect counters over graph replays)')
     ap.add_argument('--decode-steps', type=int, default=0, help='decode steps to time (0 = the whole C5 generation)')
+    ap.add_argument('--decode-prompt', type=int, default=256, help='prompt length of the decode leg (256 = SURVEY C5; the PMC passes use a\n'
+                    '                    longer one so that their short eager window sits at the mean ring occupancy of the generation)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-context-legs', action='store_true', help='skip the C2 / mode-S / published-config legs of the default line')
@@ -492,7 +494,7 @@ def decode_leg(args, ranks: Ranks, warmup: int):
     from symbolic_music_generation_amd.transformer_xl import MyTransfoXLConfig, MyTransfoXLLMHeadModel
     from symbolic_music_generation_amd.generate import XLDecoder, XLDecoderLanes
     dev, rank = ranks.dev, ranks.rank
-    B, Tp, M = (args.batch if args.mode == 'decode' and args.batch else 64), 256, 2048
+    B, Tp, M = (args.batch if args.mode == 'decode' and args.batch else 64), args.decode_prompt, 2048
     cfg = MyTransfoXLConfig('base', max_length=2048, vocab_size=V, mem_len=M, cutoffs=[])
     model = MyTransfoXLLMHeadModel(cfg, device=dev, seed=77).eval()
     # room past T = 2048 so that a full-ring window can be timed after the C5 generation proper

@@ -36,7 +36,8 @@ def per_kernel(path, counter):
     return df.groupby('k').Counter_Value.agg(['count', 'mean'])
 
 
-def main(fetch_csv, write_csv, out_json, batch=32, kind='train'):
+def main(fetch_csv, write_csv, out_json, batch=32, kind='train', prompt_len=256):
+    prompt_len = int(prompt_len)
     f = per_kernel(fetch_csv, 'FETCH_SIZE')
     w = per_kernel(write_csv, 'WRITE_SIZE')
     out = {}
@@ -51,15 +52,16 @@ def main(fetch_csv, write_csv, out_json, batch=32, kind='train'):
     if kind == 'decode':
         # eager decode window (bench.py --mode decode --eager --decode-steps 40): bytes of the kernels of the decode loop per step
         loop = ['advance_kernel', 'decode_attn_kernel<64>', 'decode_bd_kernel', 'decode_embed_kernel', 'gemm_skinny_kernel',
-                'ln_res_fwd_kernel<2>', 'ln_res_partial_fwd_kernel<2>', 'logprob_full_kernel', 'sample_kernel']
-        steps = float(out['advance_kernel']['launches'])
+                'ln_res_fwd_kernel<2>', 'ln_res_partial_fwd_kernel<2>', 'logprob_full_kernel', 'sample_kernel', 'sample_step_kernel']
+        # one launch per step (round 6: the sampler launch also advances the counters)
+        steps = float(out['advance_kernel' if 'advance_kernel' in out else 'sample_step_kernel']['launches'])
         d, L, V, B = 768, 12, 1190, int(batch)
-        first = 256 + 1 + 3          # prompt, its sample, warm-up steps (bench.decode_leg): first ring slot count of the window
+        first = prompt_len + 1 + 3   # prompt, its sample, warm-up steps (bench.decode_leg): first ring slot count of the window
         valid = sum(min(first + i, 2048) for i in range(int(steps))) / steps
-        rec.update(command='python3 bench.py --mode decode --eager --decode-steps 40 --no-cpu-baseline (SURVEY C5, eager launches: '
+        rec.update(command=f'python3 bench.py --mode decode --eager --decode-steps 40 --decode-prompt {prompt_len} --no-cpu-baseline (SURVEY C5, eager launches: '
                            'rocprofv3 cannot collect counters over hipGraph replays)',
                    decode_loop_kernels=loop, decode_steps_profiled=steps,
-                   positions=f'prompt 256 + warm-up: ring slots ~{first}..{first + int(steps)} written',
+                   positions=f'prompt {prompt_len} + warm-up: ring slots ~{first}..{first + int(steps)} written',
                    hbm_bytes_per_decode_step=sum(out[k]['hbm_bytes_per_launch'] * out[k]['launches'] for k in loop if k in out) / steps,
                    algorithmic_bytes_per_step_at_these_positions=L * 12 * d * d * 2 + V * d * 2 + B * L * 2 * valid * d * 2)
     elif kind == 'reformer':
@@ -68,4 +70,4 @@ def main(fetch_csv, write_csv, out_json, batch=32, kind='train'):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
