@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 H, dh, M = 12, 64, 2048
 d = H * dh
 for B in [int(x) for x in os.environ.get("BS", "16,32,64").split(",")]:
-    for nv in (int(os.environ.get('NV', M)), 1153):
+    for nv in [int(x) for x in os.environ.get('NVS', f"{os.environ.get('NV', M)},1153").split(',')]:
         NB = 6                                   # rotate ring buffers so that nothing is served from the Infinity Cache
         kc = [torch.randn(B, H, M, dh, device=dev).bfloat16() for _ in range(NB)]
         vc = [torch.randn(B, H, M, dh, device=dev).bfloat16() for _ in range(NB)]
@@ -19,7 +19,7 @@ for B in [int(x) for x in os.environ.get("BS", "16,32,64").split(",")]:
         out = torch.empty(B, d, device=dev, dtype=torch.bfloat16)
         t_dev = torch.tensor([nv - 1 if nv < M else 3 * M + 5], device=dev, dtype=torch.int32)
         ref = None
-        for pieces in (1, 2, 4):
+        for pieces in [int(x) for x in os.environ.get('PIECES', '1,2,4').split(',')]:
             sp = ops.relattn_decode_split_scratch(B, H, dh, pieces, dev)
             def run(i):
                 if pieces == 1:
