@@ -62,6 +62,16 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef FUSED_DVDK_LATE
 #define FUSED_DVDK_LATE 1                       // dV / dK MFMAs behind barrier 1 (1) or in front of it, as in round 4 (0)
 #endif
+#ifndef FUSED_PRIO
+#define FUSED_PRIO 3                            // s_setprio(1) around MFMA clusters.  bit 0: S / dP chains and dV / dK; bit 1: the 26 units of phase B; bit 2: the next
+                                                // tile's G.  The wave that is issuing MFMAs wins the SIMD's issue port over the other wave's vector work, which fills
+                                                // the gaps instead of delaying the chain: 3.877 -> 3.726 ms per layer (-3.9 %, four alternating same-box rounds,
+                                                // profiles/r06_fused_bwd_setprio_ab.log; bit 0 alone -1.7 %, bit 1 alone -1.6 %, bit 2 adds nothing)
+#endif
+#define PRIO_UP() do { if (FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(1); } while (0)
+#define PRIO_DOWN() do { if (FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(0); } while (0)
+#define PRIO_UP_B(bit_) do { if (FUSED_PRIO & (bit_)) __builtin_amdgcn_s_setprio(1); } while (0)
+#define PRIO_DOWN_B(bit_) do { if (FUSED_PRIO & (bit_)) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef FUSED_TRF_EARLY
 #define FUSED_TRF_EARLY 1                       // transposed dO / Qw fragments requested ahead of barrier 1 (1) or behind it (0)
 #endif
@@ -639,6 +649,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) ad[ks] = *reinterpret_cast<const bf16x8*>(sDO + (rowq ^ (ks << 5)));
+            PRIO_UP();
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) s = mfma32(aq[ks], kfl[ks], s);
             __builtin_amdgcn_sched_barrier(0);
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) dp = mfma32(ad[ks], vf[ks], dp);
 #endif
+            PRIO_DOWN();
             // the positional term of the wave's cells: sixteen 16-bit reads of the skew buffer, issued behind the chains' MFMAs (their
             // 256 cycles cover the reads; ahead of the chains' operand reads the sixteen result registers were live beside the 48 operand
             // registers -- the kernel's peak)
@@ -742,13 +754,16 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
 #pragma unroll
             for (int n = 0; n < FUSED_PF; n++) rd_unit(n);
             UNIT_FENCE();
+            PRIO_UP();
             if (FUSED_DVDK_LATE && active) dvdk();
+            PRIO_DOWN();
             UNIT_FENCE();
             STAMP(5)
             f32x4 aw4[2], ar4[2];               // two independent accumulator chains per half of the contraction
 #pragma unroll
             for (int c = 0; c < 2; c++) { aw4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ar4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             f32x4 leave;
+            PRIO_UP_B(2);
 #pragma unroll
             for (int n = 0; n < 26; n++) {
                 if (n < 8) aw4[n & 1] = mfma16(ua[n], ub[n], aw4[n & 1]);
@@ -758,6 +773,7 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
                 if (n + FUSED_PF < 26) rd_unit(n + FUSED_PF);
                 UNIT_FENCE();
             }
+            PRIO_DOWN_B(2);
             racc[8] = f32x4{0.f, 0.f, 0.f, 0.f};
             STAMP(6)
             // the next tile's G operands (its Qr image was stored before barrier 1; its window starts one ring slot further)
@@ -818,8 +834,10 @@ __global__ __launch_bounds__(512, 1) void relattn_bwd_fused_kernel(FusedP p) {
                 f32x16 g;
 #pragma unroll
                 for (int t = 0; t < 16; t++) g[t] = 0.f;
+                PRIO_UP_B(4);
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) g = mfma32(ga[ks], gq_[ks], g);
+                PRIO_DOWN_B(4);
                 char* gw = sG + r * GP + (32 * w + 4 * hh) * 2;
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++) {

@@ -142,6 +142,13 @@ __device__ unsigned long long g_fwd_stamps[16];
 #define STAMP_FLUSH
 #endif
 
+#ifndef FWD_PRIO
+#define FWD_PRIO 4                              // s_setprio(1) around MFMA clusters: bit 0 G / S chains of the tile loop, bit 1 P V, bit 2 the phantom loop's chains and
+                                                // value-sum products.  Only bit 2 pays: 1.630 -> 1.600 ms per layer (-1.8 %, four alternating same-box rounds,
+                                                // profiles/r06_fwd_setprio_ab.log); bits 0 and 1 move nothing (1.636 / 1.631)
+#endif
+#define FPRIO_UP(bit_) do { if (FWD_PRIO & (bit_)) __builtin_amdgcn_s_setprio(1); } while (0)
+#define FPRIO_DOWN(bit_) do { if (FWD_PRIO & (bit_)) __builtin_amdgcn_s_setprio(0); } while (0)
 constexpr float RESCALE_THRESH = 8.0f;   // log2 units: accumulators are re-based when a score exceeds the reference by 2^8
 // The common path does not look for the maximum at all.  It exponentiates against the reference as it stands and keeps the block
 // when every row's sum of the new terms is at most 2^13 (no term is then more than 2^13 above the reference; fp32 sums and bf16
@@ -399,12 +406,14 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                         for (int ks = 0; ks < KS; ks++) ra[gb][ks] = *reinterpret_cast<const bf16x8*>(rb + gb * 32 * G::ROWB + rfr[ks]);
                     __builtin_amdgcn_sched_barrier(0);
                     g[0] = cinit; g[1] = cinit;
+                    FPRIO_UP(4);
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++)
 #pragma unroll
                         for (int gb = 0; gb < 2; gb++)
                             g[gb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[gb][ks]),
                                                                             __builtin_bit_cast(mfma_bf16x8, qr[ks]), g[gb], 0, 0, 0);
+                    FPRIO_DOWN(4);
 #pragma unroll
                     for (int gb = 0; gb < 2; gb++) {
                         if (!fl[gb]) {          // (a block that is off altogether is masked out cell by cell: d <= qi - pz or d > M - 1)
@@ -444,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 l_run += rs;
                 STAMP(12)
                 // oph: only over the blocks the backward skips (every cell of them is phantom and in range)
+                FPRIO_UP(4);
 #pragma unroll
                 for (int gb = 0; gb < 2; gb++) {
                     const int dblk = db + 32 * gb;
@@ -478,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                         }
                     }
                 }
+                FPRIO_DOWN(4);
             }
             STAMP(13)
             __syncthreads();
@@ -585,6 +596,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                 f32x16 g0, g1;
 #pragma unroll
                 for (int j = 0; j < 16; j++) { g0[j] = 0.f; g1[j] = 0.f; }
+                FPRIO_UP(1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[0][ks]),
@@ -592,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ra[1][ks]),
                                                                  __builtin_bit_cast(mfma_bf16x8, qr[ks]), g1, 0, 0, 0);
                 }
+                FPRIO_DOWN(1);
                 STAMP(1)
 #pragma unroll
                 for (int grp = 0; grp < 4; grp++) {
@@ -629,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                             ka[kb][ks] = *reinterpret_cast<const bf16x8*>(cK + G::koff(32 * kb + r, 2 * ks + hh));
                     __builtin_amdgcn_sched_barrier(0);
                     s[0] = cinit; s[1] = cinit;      // = -m_run: the scores come out relative to the softmax reference
+                    FPRIO_UP(1);
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
@@ -636,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                             s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ka[kb][ks]),
                                                                             __builtin_bit_cast(mfma_bf16x8, qw[ks]), s[kb], 0, 0, 0);
                     }
+                    FPRIO_DOWN(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 STAMP(3)
@@ -676,6 +691,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
             l_run += rs;
             STAMP(5)
             // ---- O^T += V^T . P^T
+            FPRIO_UP(2);
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
@@ -698,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fwd_kernel(RelAttnP p) {
                     }
                 }
             }
+            FPRIO_DOWN(2);
         }
         STAMP(6)
         __syncthreads();                     // every wave is done reading this tile
