@@ -441,11 +441,32 @@ def _grad_table(named_ref_grads, eng, limits, skip=()):
     return bad, worst
 
 
+def _rnet_limits(ref, ids, lab, eng, mems=None):
+    """Limits of the r_net.weight gradients, RELATIVE to what bf16 storage of activations and gradient streams costs the oracle
+    itself on the same inputs (`_bf16_storage_train_step`; call after the exact backward has been read): rel-Frobenius
+    <= max(6 %, 1.5 x that envelope), never beyond 20 %; cosine likewise (1 - cosine is quadratic in the deviation).  Round 6
+    measured why this tensor reads 2 - 18 % while the others read 1 - 6 %: the storage envelope of the oracle is itself 2 - 8.5 % on
+    it (12-layer C3), the kernels sit at 1.07 - 1.46 x that like on every other tensor, and the layer-local rounding the kernels
+    add (dS and q + r_r_bias in bf16 inside the dRd contraction) is 0.24 % per layer in isolation, 0.17 % with a hi + lo split
+    of dS (scripts/exp_rnet_fidelity.py, profiles/r06_rnet_fidelity.txt)."""
+    exact = {n: p.grad.clone() for n, p in ref.named_parameters() if n.endswith('r_net.weight')}
+    env = _bf16_storage_train_step(ref, ids, lab, mems=mems)
+    lims, table = {}, {}
+    for n, rg in exact.items():
+        ee = ((env[n] - rg).norm() / (rg.norm() + 1e-12)).item()
+        ecos = torch.nn.functional.cosine_similarity(env[n].flatten(), rg.flatten(), dim=0).item()
+        g = eng.g32(n).float().cpu().reshape(rg.shape)
+        table[int(n.split('.')[2])] = (round(((g - rg).norm() / (rg.norm() + 1e-12)).item(), 4), round(ee, 4))
+        lims[n] = (min(0.20, max(0.06, 1.5 * ee)), max(0.98, min(0.998, 1.0 - 2.25 * (1.0 - ecos))))
+    print(f'r_net.weight per layer (HIP rel, bf16-storage oracle rel): {table}')
+    return lims
+
+
 def test_c2_train_step_gradients_vs_oracle(dev):
     """SURVEY C2 at full size, one training step's backward: 6L / 512d / H8, T = M = 1024, B = 1, mode R (no carried mems: the
     reference's training), dropout 0, a padded label tail -- loss and EVERY parameter's gradient against the fp32 oracle's
     autograd on the host.  Limits as at the small shapes (tests/test_xl_model_gpu.py): rel-Frobenius <= 6 %, cosine >= 0.998;
-    r_net.weight <= 20 % / >= 0.98 (its gradient is a sum with exact cancellation over the distances)."""
+    r_net.weight relative to the bf16-storage envelope of the oracle itself (`_rnet_limits`; a fixed 20 % / 0.98 until round 6)."""
     T2 = 1024
     ref, m = _oracle_pair(dev, 'small', 6, T2, T2, seed=33, wscale=1.0)
     ref.train(); m.train()
@@ -459,8 +480,10 @@ def test_c2_train_step_gradients_vs_oracle(dev):
     m.backward()
     torch.cuda.synchronize()
     assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-3
-    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (0.06, 0.998)
-    bad, worst = _grad_table([(n, p.grad) for n, p in ref.named_parameters()], m.engine, lim, skip=('crit.out_layers.0.weight',))
+    named = [(n, p.grad.clone()) for n, p in ref.named_parameters()]
+    rnet = _rnet_limits(ref, ids, lab, m.engine)
+    lim = lambda k: rnet[k] if k.endswith('r_net.weight') else (0.06, 0.998)
+    bad, worst = _grad_table(named, m.engine, lim, skip=('crit.out_layers.0.weight',))
     print(f'C2 gradients vs oracle: worst rel {worst[0]:.4f}, worst cosine {worst[1]:.5f} (r_net.weight aside)')
     assert not bad, bad
 
@@ -493,10 +516,12 @@ def test_c3_shape_two_layer_gradients_vs_oracle(dev, with_mem):
     torch.cuda.synchronize()
     assert abs(o.loss.item() - ro.loss.item()) / ro.loss.item() < 1e-3
     last_ln_bias = 'transformer.layers.1.pos_ff.layer_norm.bias'
-    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (0.10, 0.995) if k == last_ln_bias else (0.06, 0.998)
-    bad, worst = _grad_table([(n, p.grad) for n, p in ref.named_parameters() if n != last_ln_bias], m.engine, lim,
+    named = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    rnet = _rnet_limits(ref, ids, lab, m.engine, mems=mems_r)
+    lim = lambda k: rnet[k] if k.endswith('r_net.weight') else (0.10, 0.995) if k == last_ln_bias else (0.06, 0.998)
+    bad, worst = _grad_table([(n, g_) for n, g_ in named.items() if n != last_ln_bias], m.engine, lim,
                              skip=('crit.out_layers.0.weight',))
-    bad2, w2 = _grad_table([(last_ln_bias, dict(ref.named_parameters())[last_ln_bias].grad)], m.engine, lim)
+    bad2, w2 = _grad_table([(last_ln_bias, named[last_ln_bias])], m.engine, lim)
     bad.update(bad2)
     print(f'C3-shape 2-layer gradients vs oracle (mems: {with_mem}): worst rel {worst[0]:.4f}, worst cosine {worst[1]:.5f}; '
           f'last LayerNorm bias {w2[0]:.4f} / {w2[1]:.5f}')
@@ -615,22 +640,32 @@ class _RoundBoth(torch.autograd.Function):
         return g.to(torch.bfloat16).float()
 
 
-def _bf16_storage_train_step(ref, ids, lab):
+import contextlib
+
+
+@contextlib.contextmanager
+def bf16_storage(ref):
     """the fp32 oracle with every module output (Linear, LayerNorm, Embedding, positional table) rounded to bf16 as it is written
     and every gradient rounded to bf16 as it flows back through the same points: what bf16 STORAGE of activations and gradient
-    streams costs by itself, with exact arithmetic everywhere else.  Returns {name: gradient}."""
+    streams costs by itself, with exact arithmetic everywhere else"""
     from torch import nn
     from oracle import transfoxl_ref as R
     kinds = (nn.Linear, nn.LayerNorm, nn.Embedding, R.PositionalEmbedding)
     rnd = lambda mod, inp, out: _RoundBoth.apply(out) if torch.is_tensor(out) else out
     hooks = [mod.register_forward_hook(rnd) for mod in ref.modules() if isinstance(mod, kinds)]
     try:
-        ref.zero_grad()
-        ref(ids, labels=lab).loss.backward()
-        return {n: p.grad.clone() for n, p in ref.named_parameters()}
+        yield ref
     finally:
         for h in hooks:
             h.remove()
+
+
+def _bf16_storage_train_step(ref, ids, lab, mems=None):
+    """one backward of the oracle under `bf16_storage`.  Returns {name: gradient}."""
+    with bf16_storage(ref):
+        ref.zero_grad()
+        ref(ids, labels=lab, mems=mems).loss.backward()
+        return {n: p.grad.clone() for n, p in ref.named_parameters()}
 
 
 def test_c3_train_step_gradients_vs_oracle(dev):
@@ -639,8 +674,8 @@ def test_c3_train_step_gradients_vs_oracle(dev):
     EVERY parameter's gradient of the 12-layer backward against the fp32 oracle's autograd.  The oracle recomputes each layer in
     its backward (`checkpoint_layers`: the same arithmetic; the dense (2048, 4096, 12) score tensors of twelve layers would need
     ~25 GB otherwise).
-    Limits: the fixed ones of C2 and of the two-layer C3 test (rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight <= 12 % /
-    >= 0.99, the last LayerNorm's bias <= 10 % / >= 0.995) or, where bf16 STORAGE alone costs more than that, 1.5 x the deviation
+    Limits: the fixed ones of C2 and of the two-layer C3 test (rel-Frobenius <= 6 %, cosine >= 0.998; r_net.weight <= 7 % /
+    >= 0.995, the last LayerNorm's bias <= 10 % / >= 0.995) or, where bf16 STORAGE alone costs more than that, 1.5 x the deviation
     of the same oracle run with bf16 storage of activations and gradient streams and exact arithmetic everywhere else
     (`_bf16_storage_train_step`), never beyond 15 % / 0.985.  Measured: that envelope is 5.9 % (layer 11) to 8.8 % (layer 0) on
     the worst tensor of a layer (the first FFN weight: 2048 tokens, one sequence), the HIP path 1.19 x it at every depth --
@@ -676,8 +711,9 @@ def test_c3_train_step_gradients_vs_oracle(dev):
         layer = int(parts[2]) if parts[1] == 'layers' else None
         # r_r_bias: like r_net.weight a sum of the un-skewed score gradient over every (query, distance) cell of a head, with
         # cancellation (the rows of dG sum to zero): 6.2 % measured at layer 1, the others 2-5 %
-        # r_net.weight: measured 2.2 - 10.0 % per layer (round 4, fused backward + phantom-cell kernel; the limit was 20 % until then)
-        base = ((0.12, 0.99) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias or name.endswith('r_r_bias')
+        # r_net.weight: measured 2.2 - 10.0 % per layer, the bf16-storage oracle 2.1 - 8.5 % on the same tensor: 7 % or 1.5 x that envelope
+        # (a fixed 12 % until round 6, 20 % until round 4; see _rnet_limits)
+        base = ((0.07, 0.995) if name.endswith('r_net.weight') else (0.10, 0.995) if name == last_ln_bias or name.endswith('r_r_bias')
                 else (0.06, 0.998))
         # "1.5 x the deviation" on both measures: 1 - cosine is quadratic in the relative deviation, so 1.5 x in deviation is
         # 2.25 x in 1 - cosine.  (Until round 4 the cosine term used 1.5 x, i.e. 1.22 x in deviation, while the HIP path sits at
@@ -693,7 +729,9 @@ def test_c3_train_step_gradients_vs_oracle(dev):
         print(f'C3 12-layer gradients, layer {l:2d}: HIP worst rel {w[0]:.4f} cos {w[1]:.5f} | bf16-storage oracle {w[2]:.4f} / {w[3]:.5f}')
     rnet = {int(n.split('.')[2]): round(err(m.engine.g32(n).float().cpu().reshape(gr.shape), gr)[0], 4)
             for n, gr in exact.items() if n.endswith('r_net.weight')}
+    rnet_env = {int(n.split('.')[2]): round(err(env[n], gr)[0], 4) for n, gr in exact.items() if n.endswith('r_net.weight')}
     print(f'r_net.weight rel per layer {rnet}')
+    print(f'r_net.weight, bf16-storage oracle per layer {rnet_env}')
     assert not bad, bad
 
 

@@ -60,13 +60,16 @@ def test_bucketed_adaptive_softmax_vs_oracle(dev, V, cut, force, monkeypatch):
     assert rel_loss < 2e-3
     assert (a - b).abs().max().item() < 6e-2 and (a - b).abs().mean().item() < 8e-3
     bad = {}
-    for name, p in ref.named_parameters():
+    exact = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    from tests.test_fullsize_gpu import _rnet_limits
+    rnet = _rnet_limits(ref, ids, lab, m.engine)        # r_net.weight: relative to the oracle's own bf16-storage envelope (a fixed 25 % until round 6)
+    for name, rgrad in exact.items():
         if name == 'crit.out_layers.0.weight':
             continue
-        gg = m.engine.g32(name).float().cpu().reshape(p.grad.shape)
-        e = ((gg - p.grad).norm() / (p.grad.norm() + 1e-12)).item()
-        cos = torch.nn.functional.cosine_similarity(gg.flatten(), p.grad.flatten(), dim=0).item()
-        lim = (0.25, 0.97) if name.endswith('r_net.weight') else (0.06, 0.998)
+        gg = m.engine.g32(name).float().cpu().reshape(rgrad.shape)
+        e = ((gg - rgrad).norm() / (rgrad.norm() + 1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), rgrad.flatten(), dim=0).item()
+        lim = rnet[name] if name.endswith('r_net.weight') else (0.06, 0.998)
         if e > lim[0] or cos < lim[1]:
             bad[name] = (round(e, 4), round(cos, 5))
     assert not bad, bad

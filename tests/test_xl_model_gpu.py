@@ -138,7 +138,7 @@ def test_loss_decreases(dev):
     assert last < 0.6 * first, (first, last)
 
 
-MOVE_REL, MOVE_COS = 0.06, 0.998          # r_net.weight: 0.20 / 0.98 (see the test's docstring)
+MOVE_REL, MOVE_COS = 0.06, 0.998          # r_net.weight: relative to the bf16-storage oracle (see the test's docstring)
 
 
 def test_training_trajectory_matches_oracle_optimisation(dev):
@@ -152,9 +152,11 @@ def test_training_trajectory_matches_oracle_optimisation(dev):
     gradient is a cancellation residue: the score gradients of a softmax row sum to zero and every query sees exactly mem_len
     distances, so sum_d dRd[d] = 0 exactly and only the VARIATION of the positional table over the distance axis carries
     signal -- with clamp_len = 64 of 256 distances here, three quarters of the rows are one and the same vector.  The engine
-    therefore contracts dRd with the table centred over d (mxl_center_columns_bf16: 24-27 % before, 12-18 % after); what is
-    left is the bf16 rounding of the score gradients themselves, which Adam's normalisation turns into full-size update
-    differences on the entries whose gradient is at that noise level)."""
+    therefore contracts dRd with the table centred over d (mxl_center_columns_bf16: 24-27 % before, 12-18 % after).  What is
+    left is what the storage format costs: the SAME oracle trained with bf16 storage of activations and gradient streams and
+    exact arithmetic everywhere else moves r_net.weight 16.0 % / 22.5 % (layer 0 / 1) away from the fp32 trajectory -- more than
+    the HIP path does (round 6; Adam's normalisation turns gradient entries at the rounding-noise level into full-size update
+    differences).  r_net.weight's limit is therefore 1.1 x that envelope, measured in the test, never beyond 20 % / 0.98)."""
     import math
     import os
     import numpy as np
@@ -168,10 +170,28 @@ def test_training_trajectory_matches_oracle_optimisation(dev):
     ref.train(); m.train()
     start = {n: p.detach().clone() for n, p in ref.named_parameters()}
     no_decay = lambda n: 'bias' in n or 'layer_norm' in n
-    named = list(ref.named_parameters())
-    opt = torch.optim.AdamW([dict(params=[p for n, p in named if not no_decay(n)], weight_decay=wd),
-                             dict(params=[p for n, p in named if no_decay(n)], weight_decay=0.0)],
-                            lr=base_lr, betas=(0.9, 0.999), eps=1e-8)
+
+    def adamw(model):
+        named = list(model.named_parameters())
+        return torch.optim.AdamW([dict(params=[p for n, p in named if not no_decay(n)], weight_decay=wd),
+                                  dict(params=[p for n, p in named if no_decay(n)], weight_decay=0.0)],
+                                 lr=base_lr, betas=(0.9, 0.999), eps=1e-8)
+
+    # the same oracle trained under bf16 STORAGE of activations and gradient streams (exact arithmetic otherwise): what the format
+    # costs the trajectory by itself -- the scale r_net.weight's movement is judged on
+    import copy
+    from tests.test_fullsize_gpu import bf16_storage
+    env_model = copy.deepcopy(ref)
+    env_opt = adamw(env_model)
+    with bf16_storage(env_model):
+        for st in range(steps):
+            for g in env_opt.param_groups:
+                g['lr'] = lr_at(st, steps, base_lr, 'cosine', 0.1)
+            env_opt.zero_grad()
+            env_model(ids, labels=lab).loss.backward()
+            torch.nn.utils.clip_grad_norm_(env_model.parameters(), 1.0)
+            env_opt.step()
+    opt = adamw(ref)
     ref_losses, hip_losses = [], []
     for st in range(steps):
         lr = lr_at(st, steps, base_lr, 'cosine', 0.1)
@@ -205,7 +225,14 @@ def test_training_trajectory_matches_oracle_optimisation(dev):
         cos = torch.nn.functional.cosine_similarity(dg, dr, dim=0).item()
         stats[n] = (round(e, 4), round(cos, 5))
     print('movement (rel err, cosine):', stats)
-    lim = lambda k: (0.20, 0.98) if k.endswith('r_net.weight') else (MOVE_REL, MOVE_COS)
+    env = {}
+    for n, p in env_model.named_parameters():
+        if n.endswith('r_net.weight'):
+            dr, de = (dict(ref.named_parameters())[n].detach() - start[n]).flatten(), (p.detach() - start[n]).flatten()
+            env[n] = (((de - dr).norm() / (dr.norm() + 1e-12)).item(), torch.nn.functional.cosine_similarity(de, dr, dim=0).item())
+    print('r_net.weight movement of the bf16-storage oracle (rel err, cosine):', {k: (round(a, 4), round(b, 5)) for k, (a, b) in env.items()})
+    lim = lambda k: ((min(0.20, max(MOVE_REL, 1.1 * env[k][0])), max(0.98, min(MOVE_COS, 1.0 - 1.21 * (1.0 - env[k][1]))))
+                     if k.endswith('r_net.weight') else (MOVE_REL, MOVE_COS))
     bad = {k: v for k, v in stats.items() if v[0] > lim(k)[0] or v[1] < lim(k)[1]}
     assert not bad, f'parameter movement differs from the oracle optimiser: {bad}'
 
