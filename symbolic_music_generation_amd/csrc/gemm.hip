@@ -14,6 +14,7 @@
 // K-contiguous operands are read with ds_read_b128, K-strided ones with ds_read_b64_tr_b16.
 // The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4 consecutive n of one m (8-byte stores).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "musicxl_internal.h"
 
@@ -461,6 +462,9 @@ typedef __attribute__((address_space(3))) void* g2_lptr;
 // EPI >= 0: the epilogue flags as a compile-time constant (the common combinations; EPI == 0 also means alpha == 1).  With the
 // flags only known at run time the general epilogue's pointers, dropout constants and 64-bit indices all stay live next to the 128
 // accumulators and spill (71 values at BN = 256).
+#ifndef NT_ABL
+#define NT_ABL 0                // timing ablations (garbage results): 1 no DMA in the loop, 2 no fragment reads, 4 no barrier
+#endif
 template <int NFN, int EPI = -1>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     constexpr int BN = 64 * NFN;
@@ -560,10 +564,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         // -2 ... -7 %, K >= 2304 -1 % (profiles/r04_gemm_wave_phases.txt).
         const bool late = wid >= 4;
         if (!late) {
-            if (issued) issue_next();
+            if (issued && !(NT_ABL & 1)) issue_next();
             // (with a bias epilogue not across a tile boundary: the 48 fragment registers are what the preloaded bias values live in;
             // the next tile's first fragments are then read after the epilogue)
-            if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
+            if (g + 1 < S && !(last_of_tile && !PF_ACROSS) && !(NT_ABL & 2)) frags(g + 1, na, nb);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -575,8 +579,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         if (late) {
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 1 < S && !(last_of_tile && !PF_ACROSS)) frags(g + 1, na, nb);
-            if (issued) issue_next();
+            if (g + 1 < S && !(last_of_tile && !PF_ACROSS) && !(NT_ABL & 2)) frags(g + 1, na, nb);
+            if (issued && !(NT_ABL & 1)) issue_next();
         }
         // (the fragment reads of step g+1 need not finish before this barrier: their stage is not re-filled before the
         // barrier of step g+1, and the MFMAs of step g+1 wait for them anyway)
@@ -584,7 +588,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
         else if (!first_of_later_tile) {
             if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(NT_ABL & 4)) __builtin_amdgcn_s_barrier();
+        if (NT_ABL & 1) gi++;
         g++;
     };
 
@@ -715,6 +720,224 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmP p) {
     }
 }
 
+
+// =====================================================================================================================
+// The same machine with FOUR waves of 128 x 128 (round 6): a wave's fragment reads per 32-deep K-step are (128 + 128) rows x 64 B =
+// 16 KB for 64 MFMAs instead of (128 + 64) x 64 B = 12 KB for 32 -- 64 KB per workgroup and step instead of 96, against a matrix
+// pipe that needs 1024 cycles for the step and an LDS that moves 128 B per cycle (96 KB of reads + the 32 KB the DMA writes = the
+// same 1024: the eight-wave kernel sits on both roofs at once).
+// One wave per SIMD, 256 accumulator registers: they live in a[0:255] for the whole kernel because every MFMA is an asm statement
+// with a "+a" operand -- hipcc's own allocation of this loop moved accumulators between the two register files ~100 times per
+// K-step and spilled; with the constraint it has nothing to decide.  Fragment reads are asm too (two
+// register sets, the next step's reads spread over the second half of this step's MFMAs), so their wait is this kernel's own:
+// lgkmcnt(0) at the end of a step.
+//   step g:   MFMAs 0..31 of step g with the 8 LDS-DMA pieces of step g+3 between them (stage (g+3)&3: last read in step g-2)
+//             s_waitcnt vmcnt(16) [g+1 has landed; g+2, g+3 may fly]    s_barrier
+//             MFMAs 32..63 with the 16 fragment reads of step g+1 between them        s_waitcnt lgkmcnt(0)
+//   What the loop costs (ablation builds, K = 8192, TF/s: profiles/r06_gemm_w4_notes.txt): 1349 as it stands; without the pieces
+//   1894, without the fragment reads 1517, without the barrier 1386, the MFMAs alone 2219.  A piece costs its SIMD ~60 cycles of
+//   issue wherever it is placed and whoever issues it (the eight-wave kernel, 1234: without its pieces 1619 -- the partner wave
+//   does not fill the hole), because the vector-memory path takes 16 B per cycle and SIMD: a 256 x 256 x 32 step is 8 KB per SIMD
+//   = 512 cycles beside 1024 cycles of MFMA.  Plain loads into registers are no cheaper (1097 against 1227 on one box).
+//   last step of a tile: + vmcnt(0) (this wave's pieces of g+2, g+3 landed; the next mid-step barrier publishes them), epilogue;
+//   the two steps after an epilogue place no vmcnt wait (what they need was drained), so the epilogue's stores -- which share
+//   the counter -- are first waited for two and a half steps later.
+// =====================================================================================================================
+// Accumulator (i, j) is pinned: a[4 (8 i + j) : + 3] in every asm statement that touches it (the constraint strings spell the physical
+// registers: csrc/gemm_w4_gen.inc, generated by scripts/gen_gemm_w4.py).  With "+a" alone the loop compiled clean, but hipcc then spilled
+// ~80 accumulators to scratch in front of the epilogue and reloaded them into v[] from there -- every reload a vmcnt(0) between the
+// tile's stores; with the registers named, the epilogue reads them with v_accvgpr_read and nothing moves.
+#define W4S_(x) #x
+#define W4S(x) W4S_(x)
+#define W4_AREG(lo, hi) "{a[" W4S(lo) ":" W4S(hi) "]}"
+#define W4_MFMA(i, j, lo, hi)                                                                                                     \
+    do {                                                                                                                          \
+        if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=" W4_AREG(lo, hi)(acc[i][j]) : "v"(fb[j]), "v"(fa[i])); \
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+" W4_AREG(lo, hi)(acc[i][j]) : "v"(fb[j]), "v"(fa[i]));     \
+    } while (0)
+#define W4_ACC_READ(i, j, r0, r1, r2, r3, lo, hi, q_)                                                                             \
+    do {                                                                                                                          \
+        float x0_, x1_, x2_, x3_;                                                                                                 \
+        asm volatile("v_accvgpr_read_b32 %0, a" W4S(r0) "\n\tv_accvgpr_read_b32 %1, a" W4S(r1) "\n\tv_accvgpr_read_b32 %2, a" W4S(r2)  \
+                     "\n\tv_accvgpr_read_b32 %3, a" W4S(r3)                                                                       \
+                     : "=&v"(x0_), "=&v"(x1_), "=&v"(x2_), "=&v"(x3_) : W4_AREG(lo, hi)(acc[i][j]));                               \
+        q_ = f32x4{x0_, x1_, x2_, x3_};                                                                                           \
+    } while (0)
+#include "gemm_w4_gen.inc"
+template <int OFF>
+__device__ __forceinline__ void w4_read(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// fragment read N of a step's sixteen: the eight B fragments first (the next step starts with row 0 against all of them), then A
+template <int N>
+__device__ __forceinline__ void w4_rd(bf16x8 (&na)[8], bf16x8 (&nb)[8], uint32_t aa, uint32_t bb) {
+#if defined(W4_ABL) && (W4_ABL & 2)
+    return;
+#endif
+    if (N < 8) w4_read<(N & 7) * 1024>(nb[N & 7], bb);
+    else w4_read<(N & 7) * 1024>(na[N & 7], aa);
+}
+template <int EPI = -1>
+__global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmP p) {
+    constexpr int BN = 256, FM = 8, FN = 8;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware remap of the launch slots, as in gemm_nt256_kernel
+        const int q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nk = p.K >> 5;                                  // even (host check)
+    const int my_tiles = (nwg - bid + G - 1) / G;
+    const int S = my_tiles * nk;                              // flattened K-steps of this workgroup
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    // ---- issue side: DMA piece i (0..3) of wave w fills LDS rows (4 i + w) * 16 .. + 15 of an operand image (same image as the
+    // eight-wave kernel: lane -> row l >> 2, 16-byte slot l & 3 holding k-chunk (l & 3) ^ g2_swz(l >> 4))
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, -1, 0x00020000);
+    // (named scalars, not arrays, and macros, not lambdas: with the pieces behind branches hipcc kept ga[] / gb[] and the buffer
+    // descriptors in scratch memory and put a waterfall loop around every piece)
+    unsigned ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3;      // byte offsets of this lane's source rows (+ k-chunk): 32 bits (host check)
+    int gi = 0, i_t = 0, i_tile = bid;
+    const int kc2 = ((l & 3) ^ g2_swz(l >> 4)) * 16;
+#define W4_SET_PTRS(tile_)                                                                                                        \
+    do {                                                                                                                          \
+        const int tm_ = (tile_) / p.tiles_n, tn_ = (tile_) % p.tiles_n;                                                           \
+        const int r0_ = wid * 16 + (l >> 2);                                                                                      \
+        ga0 = (unsigned)min(tm_ * 256 + r0_, p.M - 1) * (unsigned)(p.lda * 2) + kc2;      /* rows past the edge re-read the last row */ \
+        ga1 = (unsigned)min(tm_ * 256 + r0_ + 64, p.M - 1) * (unsigned)(p.lda * 2) + kc2;                                          \
+        ga2 = (unsigned)min(tm_ * 256 + r0_ + 128, p.M - 1) * (unsigned)(p.lda * 2) + kc2;                                         \
+        ga3 = (unsigned)min(tm_ * 256 + r0_ + 192, p.M - 1) * (unsigned)(p.lda * 2) + kc2;                                         \
+        gb0 = (unsigned)min(tn_ * BN + r0_, p.N - 1) * (unsigned)(p.ldb * 2) + kc2;                                                \
+        gb1 = (unsigned)min(tn_ * BN + r0_ + 64, p.N - 1) * (unsigned)(p.ldb * 2) + kc2;                                           \
+        gb2 = (unsigned)min(tn_ * BN + r0_ + 128, p.N - 1) * (unsigned)(p.ldb * 2) + kc2;                                          \
+        gb3 = (unsigned)min(tn_ * BN + r0_ + 192, p.N - 1) * (unsigned)(p.ldb * 2) + kc2;                                          \
+    } while (0)
+    W4_SET_PTRS(i_tile);
+    // piece k of the step being issued (k < 4 operand A, else B): LDS rows (4 (k & 3) + w) * 16 .. of the operand image of stage gi & 3
+#if defined(W4_ABL) && (W4_ABL & 8)      // timing ablation: plain loads into registers instead of LDS-DMA (nothing reaches LDS)
+    u32x4 dmy[8];
+#define W4_DMA_A(i_, g_) dmy[i_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(g_), i_t << 6, 0))
+#define W4_DMA_B(i_, g_) dmy[4 + (i_)] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)(g_), i_t << 6, 0))
+#else
+#define W4_DMA_A(i_, g_) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (g2_lptr)(smem + (gi & 3) * G2_STAGE + (4 * (i_) + wid) * 1024), 16, (int)(g_), i_t << 6, 0, 0)
+#define W4_DMA_B(i_, g_) __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (g2_lptr)(smem + (gi & 3) * G2_STAGE + G2_OP_BYTES + (4 * (i_) + wid) * 1024), 16, (int)(g_), i_t << 6, 0, 0)
+#endif
+#define W4_DMA_0 W4_DMA_A(0, ga0)
+#define W4_DMA_1 W4_DMA_A(1, ga1)
+#define W4_DMA_2 W4_DMA_A(2, ga2)
+#define W4_DMA_3 W4_DMA_A(3, ga3)
+#define W4_DMA_4 W4_DMA_B(0, gb0)
+#define W4_DMA_5 W4_DMA_B(1, gb1)
+#define W4_DMA_6 W4_DMA_B(2, gb2)
+#define W4_DMA_7 W4_DMA_B(3, gb3)
+#define W4_ADVANCE_STEP()        /* the bookkeeping of a step's eight pieces (outside the branches that hold the pieces) */          \
+    do {                                                                                                                          \
+        gi++;                                                                                                                     \
+        if (++i_t == nk) {                                                                                                        \
+            i_t = 0;                                                                                                              \
+            i_tile += G;                                                                                                          \
+            if (i_tile < nwg) W4_SET_PTRS(i_tile);                                                                                \
+        }                                                                                                                         \
+    } while (0)
+#define W4_ISSUE_STEP() do { W4_DMA_0; W4_DMA_1; W4_DMA_2; W4_DMA_3; W4_DMA_4; W4_DMA_5; W4_DMA_6; W4_DMA_7; W4_ADVANCE_STEP(); } while (0)
+#ifndef W4_ABL
+#define W4_ABL 0                // timing ablations (garbage results): 1 no DMA pieces in the loop, 2 no fragment reads, 4 no barrier
+#endif
+    // ---- fragment addresses: row = base + (l & 15), k-group l >> 4 in slot (l >> 4) ^ g2_swz((row >> 2) & 3); fragment i at + i * 1024
+    const int fsw = ((l >> 4) ^ g2_swz((l >> 2) & 3)) << 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_off = lds0 + (wr * 128 + (l & 15)) * 64 + fsw;
+    const uint32_t b_off = lds0 + G2_OP_BYTES + (wc * 128 + (l & 15)) * 64 + fsw;
+
+    f32x4 acc[FM][FN];
+    bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+    W4_ISSUE_STEP();
+    W4_ISSUE_STEP();
+    W4_ISSUE_STEP();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int g = 0;                  // flattened step being computed
+    int since_drain = 2;        // steps since the last vmcnt(0) of this wave (the prologue's wait covers steps 0, 1 only: treat as old)
+    // FIRST: first step of a tile (C = 0).  `last`: last step of a tile.
+    auto step = [&](auto first_, const bool last, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN], bf16x8 (&na)[FM], bf16x8 (&nb)[FN]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_)::value;
+        // (no condition on "is there a step g + 3 / g + 1": past the end of the workgroup's sequence the pieces re-read the last
+        // tile's rows into stages nobody reads any more and the fragment reads fetch what is there -- branches between the MFMAs
+        // cost more than three steps' worth of dummy traffic; the kernel drains its DMAs before it ends)
+        const uint32_t aa = a_off + ((g + 1) & 3) * G2_STAGE, bb = b_off + ((g + 1) & 3) * G2_STAGE;
+#define W4_PIECE(k_) do { if (!(W4_ABL & 1)) { W4_DMA_##k_; } } while (0)
+        W4_HALF0
+        if (since_drain >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // in flight may stay: the pieces of steps g + 2 and g + 3
+        if (!(W4_ABL & 4)) __builtin_amdgcn_s_barrier();
+        W4_HALF1
+#undef W4_PIECE
+        W4_ADVANCE_STEP();
+#if defined(W4_ABL) && (W4_ABL & 8)
+#pragma unroll
+        for (int q_ = 0; q_ < 8; q_++) asm volatile("" :: "v"(dmy[q_]));
+#if (W4_ABL & 16)      // ... and written to LDS from there (some stage: timing only)
+#pragma unroll
+        for (int q_ = 0; q_ < 8; q_++) *reinterpret_cast<u32x4*>(smem + (gi & 3) * G2_STAGE + (q_ * 4 + wid) * 1024 + l * 16) = dmy[q_];
+#endif
+#endif
+        if (last) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); since_drain = 0; }
+        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); since_drain++; }
+        g++;
+    };
+    auto first_frags = [&]() __attribute__((always_inline)) {      // fragments of step g (its stage has landed and been published) -> set 0
+        const uint32_t aa = a_off + (g & 3) * G2_STAGE, bb = b_off + (g & 3) * G2_STAGE;
+        w4_rd<0>(fa0, fb0, aa, bb); w4_rd<1>(fa0, fb0, aa, bb); w4_rd<2>(fa0, fb0, aa, bb); w4_rd<3>(fa0, fb0, aa, bb);
+        w4_rd<4>(fa0, fb0, aa, bb); w4_rd<5>(fa0, fb0, aa, bb); w4_rd<6>(fa0, fb0, aa, bb); w4_rd<7>(fa0, fb0, aa, bb);
+        w4_rd<8>(fa0, fb0, aa, bb); w4_rd<9>(fa0, fb0, aa, bb); w4_rd<10>(fa0, fb0, aa, bb); w4_rd<11>(fa0, fb0, aa, bb);
+        w4_rd<12>(fa0, fb0, aa, bb); w4_rd<13>(fa0, fb0, aa, bb); w4_rd<14>(fa0, fb0, aa, bb); w4_rd<15>(fa0, fb0, aa, bb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    first_frags();
+
+    constexpr bool BIAS_INIT = EPI >= 0 && (EPI & MXL_GEMM_BIAS);
+    const int flags = EPI >= 0 ? (BIAS_INIT ? EPI & ~MXL_GEMM_BIAS : EPI) : p.flags;
+    if (EPI == 0 || BIAS_INIT) p.alpha = 1.f;
+#pragma unroll 1
+    for (int tile = bid; tile < nwg; tile += G) {
+        if (BIAS_INIT) {
+            const int nb0 = (tile % p.tiles_n) * BN + wc * (FN * 16) + (l >> 4) * 4;
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                f32x4 b4;
+                const int n = nb0 + j * 16;
+                if (n + 3 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b4[r] = n + r < p.N ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; i++) acc[i][j] = b4;
+            }
+        }
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 2) {
+            if (t == 0 && !BIAS_INIT) step(std::true_type{}, false, fa0, fb0, fa1, fb1);
+            else step(std::false_type{}, false, fa0, fb0, fa1, fb1);
+            step(std::false_type{}, t + 2 >= nk, fa1, fb1, fa0, fb0);
+        }
+        // epilogue.  acc[i][j][r]: m = m0 + wr*128 + i*16 + (l&15), n = n0 + wc*128 + j*16 + (l>>4)*4 + r.  Every tile is interior and
+        // the output bf16 with 16-byte aligned rows (host check: other problems take the eight-wave kernel) -- with the edge path
+        // compiled in, hipcc spilled 156 accumulators to scratch in front of the epilogue
+        const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BN;
+        const int mrow = m0 + wr * (FM * 16) + (l & 15);
+        W4_EPILOGUE_ROW_0(mrow) W4_EPILOGUE_ROW_1(mrow + 16) W4_EPILOGUE_ROW_2(mrow + 32) W4_EPILOGUE_ROW_3(mrow + 48)
+        W4_EPILOGUE_ROW_4(mrow + 64) W4_EPILOGUE_ROW_5(mrow + 80) W4_EPILOGUE_ROW_6(mrow + 96) W4_EPILOGUE_ROW_7(mrow + 112)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy pieces behind the last step: no LDS-DMA in flight when the workgroup ends
+#undef W4_SET_PTRS
+#undef W4_DMA_A
+#undef W4_DMA_B
+#undef W4_ADVANCE_STEP
+#undef W4_ISSUE_STEP
+}
 
 // =====================================================================================================================
 // Large-tile kernel for the weight gradients dW[m][n] += sum_k A[k][m] B[k][n] (A = dY (tokens x out), B = X (tokens x in): both
@@ -979,7 +1202,23 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         if (use192) hipLaunchKernelGGL((gemm_nt256_kernel<3, EPI_>), grid, dim3(512), G2_SMEM, s, p);                       \
         else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
     } while (0)
-        if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
+        // four waves of 128 x 128 (gemm_nt256w4_kernel) where the tile width is 256
+        static const bool w4 = !(getenv("MXL_GEMM_W4") && getenv("MXL_GEMM_W4")[0] == '0');
+#define MXL_NT256W4_LAUNCH(EPI_)                                                                                                 \
+    do {                                                                                                                         \
+        static bool attr_w = false;                                                                                              \
+        if (!attr_w) {                                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256w4_kernel<EPI_>),                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);                             \
+            if (e != hipSuccess) return (int)e;                                                                                  \
+            attr_w = true;                                                                                                       \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((gemm_nt256w4_kernel<EPI_>), grid, dim3(256), G2_SMEM, s, p);                                          \
+    } while (0)
+        const bool w4_ok = w4 && !use192 && (M % 256) == 0 && (N % 256) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && p.alpha == 1.f;
+        if (w4_ok && p.flags == 0) MXL_NT256W4_LAUNCH(0);
+        else if (w4_ok && p.flags == MXL_GEMM_BIAS) MXL_NT256W4_LAUNCH(MXL_GEMM_BIAS);
+        else if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
         else if (p.alpha != 1.f && (p.flags & MXL_GEMM_BIAS) && !(p.flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS))) MXL_NT256_LAUNCH(-1);
         else if (p.alpha != 1.f && (p.flags & MXL_GEMM_SAVE_RELU_MASK)) return MXL_EUNSUPPORTED;
         else if (p.flags == MXL_GEMM_BIAS) MXL_NT256_LAUNCH(MXL_GEMM_BIAS);
@@ -1010,6 +1249,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
             MXL_NT256_LAUNCH(MXL_GEMM_BIAS | MXL_GEMM_ADD_AUX | MXL_GEMM_DROPOUT);
         else MXL_NT256_LAUNCH(-1);
 #undef MXL_NT256_LAUNCH
+#undef MXL_NT256W4_LAUNCH
         MXL_LAUNCH_CHECK();
         return MXL_OK;
     }
