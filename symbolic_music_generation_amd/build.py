@@ -36,7 +36,7 @@ def _newer(src, dst, deps):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h') or f.endswith('.inc')]
     hdrs.append(os.path.join(HERE, '..', 'include', 'musicxl.h'))
     objs, jobs = [], []
     for s in srcs:

@@ -274,3 +274,21 @@ def test_load_trained_key_table_and_argument_checks(tmp_path):
     with pytest.raises(Exception) as e:
         trainer.load_trained(model_key=('transf-xl', 'All', '128ep', 'midi'), base_path=str(tmp_path))
     assert os.path.join(str(tmp_path), 'models', '2022-11-14_13-04-30_transf-xl', 'trained') in str(e.value)
+
+
+def test_gemm_w4_register_table_is_what_its_generator_writes():
+    """csrc/gemm_w4_gen.inc (the four-wave NT GEMM's instruction streams with every accumulator pinned to a[4 (8 i + j) : + 3]) is
+    generated: the committed file must be scripts/gen_gemm_w4.py's output, and every accumulator register must appear exactly once
+    per MFMA stream"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'gen_gemm_w4.py'), '--check'])
+    assert r.returncode == 0, 'run python scripts/gen_gemm_w4.py and commit csrc/gemm_w4_gen.inc'
+    text = open(os.path.join(root, 'symbolic_music_generation_amd', 'csrc', 'gemm_w4_gen.inc')).read()
+    regs = [(int(i), int(j), int(lo), int(hi)) for i, j, lo, hi in re.findall(r'W4_MFMA\((\d+), (\d+), (\d+), (\d+)\)', text)]
+    assert len(regs) == 64 and sorted(lo for _, _, lo, _ in regs) == list(range(0, 256, 4))
+    assert all(lo == 4 * (8 * i + j) and hi == lo + 3 for i, j, lo, hi in regs)
+    assert len(re.findall(r'W4_PIECE\(\d\)', text)) == 8 and len(re.findall(r'w4_rd<\d+>', text)) == 16
