@@ -54,6 +54,65 @@ __global__ void axial_embed_bwd_kernel(const long long* ids, const bf16_t* dout,
     else atomicAdd(dW1 + (size_t)(t % A1) * (d - d0) + (k - d0), gp);
 }
 
+// The position tables' gradients without atomics in the loop (round 6).  The element-wise kernel above spends 0.48 ms of the C4 step on
+// 134 M global float atomics -- 537 MB of added bytes at the chip's ~1.2 TB/s atomic rate -- and half of them go to the two
+// position tables, whose row is a function of t alone: a thread here OWNS a (row, 8 columns) cell of a 32-column slab and walks
+// that row's tokens (W0 row r: t = r A1 .. r A1 + A1 - 1; W1 row c: t = c, c + A1, ...) through registers, eight 16-byte loads in
+// flight, with one atomic per cell at the end (the workgroups of a slab split the sequences).  Masks: the forward's one decision per
+// (sequence, t % A1) column.  (Accumulating the word table's slabs in LDS the same way was tried first: ds_add_f32 ran at about one
+// lane per three cycles and CU, 365 us for the table against 235 us of global atomics -- profiles/r06_experiments_not_kept.txt.)
+__global__ __launch_bounds__(256) void axial_embed_bwd_pos_kernel(const bf16_t* dout, const bf16_t* dout2, float* dW0, float* dW1, int B, int T,
+                                                                   int d, int A0, int A1, int d0, unsigned thresh, float dscale,
+                                                                   unsigned long long seed, unsigned site_pos) {
+    const int c0 = blockIdx.x * 32;
+    const bool w0 = c0 < d0;
+    const int rows = w0 ? A0 : A1, cnt = w0 ? A1 : A0;
+    const int q = threadIdx.x & 3;
+    for (int r = threadIdx.x >> 2; r < rows; r += 64) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = blockIdx.y; b < B; b += gridDim.y) {
+            if (!w0 && thresh && !dropout_keep(seed, site_pos, (uint64_t)b * A1 + r, thresh)) continue;     // W1 row r IS the column t % A1
+            const bf16_t* src = dout + ((size_t)b * T) * d + c0 + 8 * q;
+            const bf16_t* src2 = dout2 ? dout2 + ((size_t)b * T) * d + c0 + 8 * q : nullptr;
+            for (int k0 = 0; k0 < cnt; k0 += 8) {
+                bf16x8 a[8], a2[8];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + u;
+                    const int t = w0 ? r * A1 + k : r + A1 * k;
+                    ok[u] = k < cnt && t < T;
+                    const size_t o = (size_t)(ok[u] ? t : 0) * d;
+                    a[u] = *reinterpret_cast<const bf16x8*>(src + o);
+                    if (src2) a2[u] = *reinterpret_cast<const bf16x8*>(src2 + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (!ok[u]) continue;
+                    if (w0 && thresh && !dropout_keep(seed, site_pos, (uint64_t)b * A1 + (k0 + u), thresh)) continue;   // (t % A1 = k for a W0 row)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += bf2f((bf16_t)a[u][j]) + (src2 ? bf2f((bf16_t)a2[u][j]) : 0.f);
+                }
+            }
+        }
+        float* dst = w0 ? dW0 + (size_t)r * d0 + c0 + 8 * q : dW1 + (size_t)r * (d - d0) + (c0 - d0) + 8 * q;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (acc[j] != 0.f) atomicAdd(dst + j, thresh ? acc[j] * dscale : acc[j]);
+    }
+}
+// ... with it, the element-wise kernel's word-table part alone
+__global__ void axial_embed_bwd_word_kernel(const long long* ids, const bf16_t* dout, const bf16_t* dout2, float* dE, long long n, int d, int V,
+                                            unsigned thresh, float dscale, unsigned long long seed, unsigned site_emb) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const long long id = ids[gid / d];
+    if (id < 0 || id >= V) return;
+    float g = bf2f(dout[gid]);
+    if (dout2) g += bf2f(dout2[gid]);
+    if (thresh) g = dropout_keep(seed, site_emb, (uint64_t)gid, thresh) ? g * dscale : 0.f;
+    atomicAdd(dE + (size_t)id * d + (int)(gid % d), g);
+}
+
 // =====================================================================================================================
 // LSH hashing (HF515:698-770): buckets[b,h,r*T+t] = r*NB + combine_f argmax([x R_f ; -x R_f])
 // rotations (H, dh, n_h, R2) f32 given explicitly (HF draws them from the global RNG inside the layer)
@@ -1235,6 +1294,19 @@ extern "C" int mxl_axial_embed_bwd(const void* ids, const void* dout, const void
                                    unsigned site_emb, unsigned site_pos, void* stream) {
     MXL_CHECK_ARG(ids && dout && dE && dW0 && dW1 && B > 0 && T > 0 && d0 > 0 && d0 < d && T <= A0 * A1);
     const long long n = (long long)B * T * d;
+    // position tables by row-owning threads (32-column slabs that do not straddle d0), the word table by the element-wise atomics
+    const bool split_off = getenv("MXL_AXIAL_BWD_GLOBAL") != nullptr;          // (read per call: the test switches forms)
+    if (!split_off && (d % 32) == 0 && (d0 % 32) == 0 && (long long)B * T >= 4096 && ((uintptr_t)dout % 16) == 0 &&
+        (!dout2 || ((uintptr_t)dout2 % 16) == 0)) {
+        const unsigned thresh = dropout_thresh(drop_p);
+        const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        hipLaunchKernelGGL(axial_embed_bwd_word_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids,
+                           (const bf16_t*)dout, (const bf16_t*)dout2, dE, n, d, V, thresh, dscale, seed, site_emb);
+        hipLaunchKernelGGL(axial_embed_bwd_pos_kernel, dim3(d / 32, B < 16 ? B : 16), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                           (const bf16_t*)dout2, dW0, dW1, B, T, d, A0, A1, d0, thresh, dscale, seed, site_pos);
+        MXL_LAUNCH_CHECK();
+        return MXL_OK;
+    }
     hipLaunchKernelGGL(axial_embed_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)ids, (const bf16_t*)dout, (const bf16_t*)dout2, dE, dW0, dW1, B, T, d, V, A1, d0,
                        dropout_thresh(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, site_emb, site_pos);

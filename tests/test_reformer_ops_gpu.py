@@ -164,6 +164,42 @@ def test_chunk_attention_dropout_consistency(dev):
     assert abs(dv[0, :, 0].sum().item() - rowsum.sum().item()) / rowsum.sum().item() < 1e-2
 
 
+@pytest.mark.parametrize('drop_p,two', [(0.0, False), (0.1, True)])
+def test_axial_embed_bwd_lds_form_at_c4_shape(dev, monkeypatch, drop_p, two):
+    """mxl_axial_embed_bwd at the C4 shape (V 1190, d 512 = 128 + 384, 64 x 128 positions; HF515:222-256's embeddings backward): the
+    form that accumulates 32-column slabs of the tables in LDS (round 6) against the one-atomic-per-element form -- same masks,
+    sums equal up to fp32 summation order -- and, without dropout, against index_add on the host"""
+    import os
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(5)
+    B, T, V, d, A0, A1, d0 = 2, 8192, 1190, 512, 64, 128, 128
+    ids = torch.randint(0, V, (B, T))
+    ids[0, :7] = torch.tensor([0, V - 1, 5, 5, 5, 5, 5])
+    dout = bf(torch.randn(B, T, d)); dout2 = bf(torch.randn(B, T, d)) if two else None
+
+    def run(global_form):
+        if global_form:
+            monkeypatch.setenv('MXL_AXIAL_BWD_GLOBAL', '1')
+        else:
+            monkeypatch.delenv('MXL_AXIAL_BWD_GLOBAL', raising=False)
+        dE = torch.zeros(V, d, device=dev); dW0 = torch.zeros(A0, d0, device=dev); dW1 = torch.zeros(A1, d - d0, device=dev)
+        ops.axial_embed_bwd(ids.to(dev), dout.to(dev), dE, dW0, dW1, A0, A1, drop_p=drop_p, seed=11, site_emb=3, site_pos=4,
+                            dout2=None if dout2 is None else dout2.to(dev))
+        torch.cuda.synchronize()
+        return dE.cpu(), dW0.cpu(), dW1.cpu()
+
+    new, old = run(False), run(True)
+    for a, b, name in zip(new, old, ('dE', 'dW0', 'dW1')):
+        assert rel_err(a, b) < 2e-6, name
+    if drop_p == 0.0:
+        g = dout.float().view(-1, d)
+        t = torch.arange(T)
+        rE = torch.zeros(V, d).index_add_(0, ids.flatten(), g)
+        rW0 = torch.zeros(A0, d0).index_add_(0, (t // A1).repeat(B), g[:, :d0])
+        rW1 = torch.zeros(A1, d - d0).index_add_(0, (t % A1).repeat(B), g[:, d0:])
+        assert rel_err(new[0], rE) < 1e-5 and rel_err(new[1], rW0) < 1e-5 and rel_err(new[2], rW1) < 1e-5
+
+
 def test_axial_embed_and_combine(dev):
     from symbolic_music_generation_amd import ops
     torch.manual_seed(0)
