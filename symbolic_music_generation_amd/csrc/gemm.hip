@@ -1203,7 +1203,8 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
     } while (0)
         // four waves of 128 x 128 (gemm_nt256w4_kernel) where the tile width is 256
-        static const bool w4 = !(getenv("MXL_GEMM_W4") && getenv("MXL_GEMM_W4")[0] == '0');
+        const char* w4_env = getenv("MXL_GEMM_W4");                           // (read per call: the test compares the two kernels)
+        const bool w4 = !(w4_env && w4_env[0] == '0');
 #define MXL_NT256W4_LAUNCH(EPI_)                                                                                                 \
     do {                                                                                                                         \
         static bool attr_w = false;                                                                                              \

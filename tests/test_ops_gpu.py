@@ -461,6 +461,38 @@ def test_gemm_large_tile(dev, M, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,reserve', [(256, 256, 64, 0), (512, 768, 128, 0), (2048, 2304, 768, 0), (256 * 70, 512, 192, 128),
+                                           (256 * 9, 256, 3072, 120)])
+def test_gemm_four_wave_kernel_equals_eight_wave_kernel(dev, monkeypatch, M, N, K, reserve):
+    """gemm_nt256w4_kernel (plain and bias epilogues at interior shapes: four waves of 128 x 128, accumulators pinned in a[0:255])
+    against gemm_nt256_kernel on the same problem: the same products accumulated in the same order, so BIT-identical outputs --
+    one tile per workgroup, several tiles per workgroup (a grid shrunk by mxl_set_reserved_cus: the tile boundary's drain and the
+    two wait-free steps behind an epilogue), two K-steps per tile (every step next to a drain), repeats (a race in the ring shows
+    as run-to-run differences)"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(M + N + K)
+    x, w, b = bf(torch.randn(M, K) * 0.5).to(dev), bf(torch.randn(N, K) * 0.5).to(dev), torch.randn(N).to(dev)
+    ref = x.float() @ w.float().t()
+    ops.check(ops.lib().mxl_set_reserved_cus(reserve), 'mxl_set_reserved_cus')
+    try:
+        outs = {}
+        for form in ('1', '0'):
+            monkeypatch.setenv('MXL_GEMM_W4', form)
+            y = torch.empty(M, N, device=dev, dtype=torch.bfloat16); yb = torch.empty_like(y)
+            ops.gemm(x, w, y, M, N, K)
+            ops.gemm(x, w, yb, M, N, K, flags=ops.GEMM_BIAS, bias=b)
+            for _ in range(3):
+                y2 = torch.empty_like(y)
+                ops.gemm(x, w, y2, M, N, K)
+                assert torch.equal(y, y2)
+            outs[form] = (y, yb)
+        assert torch.equal(outs['1'][0], outs['0'][0]) and torch.equal(outs['1'][1], outs['0'][1])
+        assert rel_err(outs['1'][0].float(), ref) < 6e-3 and rel_err(outs['1'][1].float(), ref + b) < 6e-3
+    finally:
+        ops.check(ops.lib().mxl_set_reserved_cus(0), 'mxl_set_reserved_cus')
+
+
+@pytest.mark.gpu
 def test_transpose_batched(dev):
     from symbolic_music_generation_amd import ops
     torch.manual_seed(3)
