@@ -268,8 +268,14 @@ def train_leg(args, ranks: Ranks):
                         'fused': ('relattn_bwd_fused_kernel', B * T * 12.0 * d * n_real), 'dqfin': ('relattn_dq_finish_kernel', 0.0),
                         'rowbias': ('phantom_prep_kernel', 0.0), 'drd': ('relattn_drd_phantom_kernel', B * T * 2.0 * d * (M - n_real))}
                 group = ('delta', 'fused', 'dqfin', 'rowbias', 'drd')
-                desc = ('attention backward of one layer: fused_delta + relattn_bwd_fused + relattn_dq_finish + relattn_drd_phantom '
-                        '(one HIP-event bracket around all four launches; the phantom kernel reads records the forward wrote)')
+                if 'delta' in kt and kt['delta'][1]:
+                    desc = ('attention backward of one layer: fused_delta + relattn_bwd_fused + relattn_dq_finish + relattn_drd_phantom '
+                            '(one HIP-event bracket around all four launches; the phantom kernel reads records the forward wrote)')
+                else:       # round 6: delta = sum_e dO . O comes out of the epilogue of the GEMM that produces dO (mxl_gemm_bf16_headdot)
+                    desc = ('attention backward of one layer: relattn_bwd_fused + relattn_dq_finish + relattn_drd_phantom (one HIP-event '
+                            'bracket around the three launches; the row term delta is formed in the epilogue of the o_net input-gradient '
+                            'GEMM in front of the bracket, +~16 us there instead of a 91 us pass; the phantom kernel reads records the '
+                            'forward wrote)')
             else:
                 kalg = {'fwd': ('relattn_fwd_kernel', fwd_alg + moved), 'delta': ('relattn_bwd_delta_kernel', 0.0),
                         'dq8': ('relattn_bwd_dq8_kernel', B * T * (4 * d * nbar + 2 * d * M) - moved),
@@ -591,6 +597,8 @@ def pmc_traffic(workload, B):
         else:               # delta, query-owner, key-owner, q + r_r_bias, dRd contraction
             dq = 'relattn_bwd_dq8_kernel<64>' if 'relattn_bwd_dq8_kernel<64>' in k else 'relattn_bwd_dq_kernel<64>'
             names = ['relattn_bwd_delta_kernel', dq, 'relattn_bwd_dkv_kernel<64>', 'add_rowbias_kernel', 'relattn_drd_kernel']
+    # round 6: delta comes out of the o_net input-gradient GEMM's epilogue (in front of the bracket): no fused_delta_kernel launch then
+    names = [n for n in names if n != 'fused_delta_kernel' or n in k]
     if not all(n in k for n in names):
         return None, None
     if 'group_sources_sha16' in rec:      # the record is only as good as the kernels it measured: a changed source needs new PMC passes

@@ -38,8 +38,11 @@ struct GemmP {
     int bdiv;
     long long sA1, sA2, sB1, sB2, sC1, sC2;
     float* colsum;         // [N] f32 or null: += column sums of the epilogue's values (gemm_nt256_kernel, EPI & GEMM_COLSUM_BIT)
+    // GEMM_HEADDOT_BIT (gemm_nt256w4_kernel): hd_delta[(b * (N / 64) + h) * hd_T + t] = sum_{e < 64} C[m][64 h + e] * hd_o[m][64 h + e],  m = b * hd_T + t
+    const bf16_t* hd_o; int hd_ldo, hd_T; float* hd_delta;
 };
 constexpr int GEMM_COLSUM_BIT = 0x80;      // internal epilogue bit (not a public flag): see mxl_gemm_bf16_colsum
+constexpr int GEMM_HEADDOT_BIT = 0x400;    // internal epilogue bit: see mxl_gemm_bf16_headdot
 // MXL_GEMM_SAVE_RELU_MASK (0x100) / MXL_GEMM_RELU_BWD_BITS (0x200): the relu(+dropout) mask as 128 bits per lane and tile, in the
 // large-tile kernel's own accumulator layout -- written by the forward epilogue, read back by ONE 16-byte load per lane and tile in
 // the backward one (the bf16 activations as mask cost two dependent loads per row block: 16 serialized round trips per tile).
@@ -899,8 +902,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmP p) {
     first_frags();
 
     constexpr bool BIAS_INIT = EPI >= 0 && (EPI & MXL_GEMM_BIAS);
-    const int flags = EPI >= 0 ? (BIAS_INIT ? EPI & ~MXL_GEMM_BIAS : EPI) : p.flags;
-    if (EPI == 0 || BIAS_INIT) p.alpha = 1.f;
+    const int flags = EPI >= 0 ? ((BIAS_INIT ? EPI & ~MXL_GEMM_BIAS : EPI) & ~GEMM_HEADDOT_BIT) : p.flags;
+    if (EPI == 0 || BIAS_INIT || EPI == GEMM_HEADDOT_BIT) p.alpha = 1.f;
 #pragma unroll 1
     for (int tile = bid; tile < nwg; tile += G) {
         if (BIAS_INIT) {
@@ -928,8 +931,69 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmP p) {
         // compiled in, hipcc spilled 156 accumulators to scratch in front of the epilogue
         const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BN;
         const int mrow = m0 + wr * (FM * 16) + (l & 15);
-        W4_EPILOGUE_ROW_0(mrow) W4_EPILOGUE_ROW_1(mrow + 16) W4_EPILOGUE_ROW_2(mrow + 32) W4_EPILOGUE_ROW_3(mrow + 48)
-        W4_EPILOGUE_ROW_4(mrow + 64) W4_EPILOGUE_ROW_5(mrow + 80) W4_EPILOGUE_ROW_6(mrow + 96) W4_EPILOGUE_ROW_7(mrow + 112)
+        constexpr bool HD = EPI >= 0 && (EPI & GEMM_HEADDOT_BIT);
+        if (!HD) {
+#define W4_EPAIR(i, j, a0, a1, a2, a3, ah, b0, b1, b2, b3, bh, m_)                                                                \
+            {                                                                                                                     \
+                f32x4 q0_, q1_;                                                                                                   \
+                W4_ACC_READ(i, j, a0, a1, a2, a3, a0, ah, q0_);                                                                   \
+                W4_ACC_READ(i, j + 1, b0, b1, b2, b3, b0, bh, q1_);                                                               \
+                epilogue_pair_bf16(p, flags, m_, n0 + wc * 128 + (j) * 16 + (l >> 4) * 4, l, q0_, q1_);                            \
+            }
+            W4_EPILOGUE_ROW_0(mrow) W4_EPILOGUE_ROW_1(mrow + 16) W4_EPILOGUE_ROW_2(mrow + 32) W4_EPILOGUE_ROW_3(mrow + 48)
+            W4_EPILOGUE_ROW_4(mrow + 64) W4_EPILOGUE_ROW_5(mrow + 80) W4_EPILOGUE_ROW_6(mrow + 96) W4_EPILOGUE_ROW_7(mrow + 112)
+#undef W4_EPAIR
+        } else {
+            // plain bf16 store + the per-(row, 64-column head) dot product of the stored values with a second matrix (mxl_gemm_bf16_headdot:
+            // the attention backward's delta = sum_e dO . O out of the GEMM that produces dO, instead of a pass over dO and O).  Behind the
+            // permlane swap a lane holds 8 consecutive columns of its row: the same 16 bytes of the second matrix, loaded a row block ahead;
+            // the two pairs of a head add up in the lane, then over the four 16-lane groups.
+            const int odd = (l >> 4) & 1;
+            const int cbase = n0 + wc * 128 + (l >> 4) * 4 + (odd ? 12 : 0);        // pair j: + 16 j
+            u32x4 ox[2][4];
+#define W4_HD_LOAD(set_, m_)                                                                                                       \
+            _Pragma("unroll") for (int jj = 0; jj < 4; jj++)                                                                      \
+                ox[set_][jj] = *reinterpret_cast<const u32x4*>(p.hd_o + (size_t)(m_) * p.hd_ldo + cbase + 32 * jj);
+            W4_HD_LOAD(0, mrow)
+            float hs0 = 0.f, hs1 = 0.f;
+#define W4_EPAIR(i, j, a0, a1, a2, a3, ah, b0, b1, b2, b3, bh, m_)                                                                \
+            {                                                                                                                     \
+                f32x4 q0_, q1_;                                                                                                   \
+                W4_ACC_READ(i, j, a0, a1, a2, a3, a0, ah, q0_);                                                                   \
+                W4_ACC_READ(i, j + 1, b0, b1, b2, b3, b0, bh, q1_);                                                               \
+                const unsigned pa0 = pack2bf(q0_[0], q0_[1]), pa1 = pack2bf(q0_[2], q0_[3]);                                       \
+                const unsigned pb0 = pack2bf(q1_[0], q1_[1]), pb1 = pack2bf(q1_[2], q1_[3]);                                       \
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pa0, pb0, false, false);                                         \
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pa1, pb1, false, false);                                         \
+                const u32x4 ov = u32x4{r0[0], r1[0], r0[1], r1[1]};                                                               \
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)(m_) * p.ldc + cbase + 16 * (j)) = ov;          \
+                const u32x4 xv = ox[(i) & 1][(j) >> 1];                                                                           \
+                float t_ = 0.f;                                                                                                   \
+                _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++)                                                                  \
+                    t_ += __builtin_bit_cast(float, ov[k_] << 16) * __builtin_bit_cast(float, xv[k_] << 16) +                      \
+                          __builtin_bit_cast(float, ov[k_] & 0xffff0000u) * __builtin_bit_cast(float, xv[k_] & 0xffff0000u);       \
+                if ((j) < 4) hs0 += t_; else hs1 += t_;                                                                           \
+            }
+            // after a row block: the head sums over the four lane groups, written by group 0 (16 consecutive rows)
+#define W4_HD_ROW(i, ROW_)                                                                                                         \
+            if ((i) < 7) { W4_HD_LOAD(((i) + 1) & 1, mrow + 16 * ((i) + 1)) }                                                      \
+            ROW_(mrow + 16 * (i))                                                                                                 \
+            {                                                                                                                     \
+                hs0 += __shfl_xor(hs0, 16, 64); hs0 += __shfl_xor(hs0, 32, 64);                                                    \
+                hs1 += __shfl_xor(hs1, 16, 64); hs1 += __shfl_xor(hs1, 32, 64);                                                    \
+                if ((l >> 4) == 0) {                                                                                              \
+                    const int mm_ = mrow + 16 * (i), b_ = mm_ / p.hd_T, tt_ = mm_ - b_ * p.hd_T, h_ = (n0 + wc * 128) >> 6;        \
+                    float* dp_ = p.hd_delta + ((size_t)b_ * (p.N >> 6) + h_) * p.hd_T + tt_;                                       \
+                    dp_[0] = hs0; dp_[p.hd_T] = hs1;                                                                              \
+                }                                                                                                                 \
+                hs0 = 0.f; hs1 = 0.f;                                                                                             \
+            }
+            W4_HD_ROW(0, W4_EPILOGUE_ROW_0) W4_HD_ROW(1, W4_EPILOGUE_ROW_1) W4_HD_ROW(2, W4_EPILOGUE_ROW_2) W4_HD_ROW(3, W4_EPILOGUE_ROW_3)
+            W4_HD_ROW(4, W4_EPILOGUE_ROW_4) W4_HD_ROW(5, W4_EPILOGUE_ROW_5) W4_HD_ROW(6, W4_EPILOGUE_ROW_6) W4_HD_ROW(7, W4_EPILOGUE_ROW_7)
+#undef W4_EPAIR
+#undef W4_HD_ROW
+#undef W4_HD_LOAD
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy pieces behind the last step: no LDS-DMA in flight when the workgroup ends
 #undef W4_SET_PTRS
@@ -1104,6 +1168,10 @@ static int gemm_n_cu() {
     const int left = n_cu - g_reserved_cus;
     return left >= 8 ? left : 8;
 }
+// which large-tile kernel the last K-contiguous product went to: 0 none of them, 1 eight waves x 256-wide tiles, 2 eight waves x 192-wide,
+// 3 four waves (tests: the shapes they mean to put on a kernel are on it)
+static int g_last_nt_kernel = 0;
+extern "C" int mxl_gemm_last_nt_kernel() { return g_last_nt_kernel; }
 extern "C" int mxl_set_reserved_cus(int k) {
     MXL_CHECK_ARG(k >= 0 && k <= 128);
     g_reserved_cus = k;
@@ -1128,8 +1196,10 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
                        const void* aux, int ldaux, int ksplits,
                        float drop_p, unsigned long long seed, unsigned site, void* stream,
                        int batch, int bdiv, long long sA1, long long sA2, long long sB1, long long sB2,
-                       long long sC1, long long sC2, float* colsum = nullptr, bool* colsum_fused = nullptr) {
+                       long long sC1, long long sC2, float* colsum = nullptr, bool* colsum_fused = nullptr,
+                       const void* hd_o = nullptr, int hd_ldo = 0, int hd_T = 0, float* hd_delta = nullptr, bool* hd_fused = nullptr) {
     MXL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+    g_last_nt_kernel = 0;
     MXL_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0);
     MXL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
     // K-contiguous operands are fetched in 8-element chunks along K: K must be chunk-exact.
@@ -1162,6 +1232,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
     p.ksplit = per * BK;
     p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.alpha = alpha; p.flags = flags;
     p.colsum = colsum;
+    p.hd_o = (const bf16_t*)hd_o; p.hd_ldo = hd_ldo; p.hd_T = hd_T; p.hd_delta = hd_delta;
     p.seed = seed; p.site = site; p.thresh = dropout_thresh(drop_p);
     { static const bool nt = getenv("MXL_GEMM_NT") != nullptr; if (nt) p.flags |= (1 << 30); }
     p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -1201,6 +1272,7 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
         }                                                                                                                        \
         if (use192) hipLaunchKernelGGL((gemm_nt256_kernel<3, EPI_>), grid, dim3(512), G2_SMEM, s, p);                       \
         else hipLaunchKernelGGL((gemm_nt256_kernel<4, EPI_>), grid, dim3(512), G2_SMEM, s, p);                                     \
+        g_last_nt_kernel = use192 ? 2 : 1;                                                                                      \
     } while (0)
         // four waves of 128 x 128 (gemm_nt256w4_kernel) where the tile width is 256
         const char* w4_env = getenv("MXL_GEMM_W4");                           // (read per call: the test compares the two kernels)
@@ -1215,9 +1287,14 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
             attr_w = true;                                                                                                       \
         }                                                                                                                        \
         hipLaunchKernelGGL((gemm_nt256w4_kernel<EPI_>), grid, dim3(256), G2_SMEM, s, p);                                          \
+        g_last_nt_kernel = 3;                                                                                                    \
     } while (0)
         const bool w4_ok = w4 && !use192 && (M % 256) == 0 && (N % 256) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && p.alpha == 1.f;
-        if (w4_ok && p.flags == 0) MXL_NT256W4_LAUNCH(0);
+        if (w4_ok && p.flags == 0 && hd_delta && (N % 128) == 0 && hd_T > 0 && (M % hd_T) == 0 && (hd_ldo & 7) == 0 && ((uintptr_t)hd_o & 15) == 0) {
+            MXL_NT256W4_LAUNCH(GEMM_HEADDOT_BIT);
+            *hd_fused = true;
+        }
+        else if (w4_ok && p.flags == 0) MXL_NT256W4_LAUNCH(0);
         else if (w4_ok && p.flags == MXL_GEMM_BIAS) MXL_NT256W4_LAUNCH(MXL_GEMM_BIAS);
         else if (p.flags == 0 && p.alpha == 1.f) MXL_NT256_LAUNCH(0);
         else if (p.alpha != 1.f && (p.flags & MXL_GEMM_BIAS) && !(p.flags & (MXL_GEMM_SAVE_RELU_MASK | MXL_GEMM_RELU_BWD_BITS))) MXL_NT256_LAUNCH(-1);
@@ -1316,6 +1393,16 @@ extern "C" int mxl_gemm_bf16_colsum(const void* A, const void* B, void* C, int M
                                stream, 1, 1, 0, 0, 0, 0, 0, 0, colsum, &fused);
     if (rc != MXL_OK || fused) return rc;
     return mxl_colsum_bf16(C, colsum, M, N, ldc, stream);
+}
+
+extern "C" int mxl_gemm_bf16_headdot(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const void* O,
+                                     int ldo, int T, float* delta, void* stream) {
+    MXL_CHECK_ARG(O && delta && T > 0 && ldo >= N);
+    bool fused = false;
+    const int rc = gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1.f, nullptr, nullptr, 0, 1, 0.f, 0, 0, stream, 1, 1, 0, 0, 0, 0, 0, 0,
+                               nullptr, nullptr, O, ldo, T, delta, &fused);
+    if (rc != MXL_OK) return rc;
+    return fused ? MXL_OK : MXL_EUNSUPPORTED;         // (C is written either way; delta only when the four-wave kernel took the problem)
 }
 
 extern "C" int mxl_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,

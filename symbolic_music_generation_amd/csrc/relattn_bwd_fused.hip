@@ -1075,7 +1075,9 @@ extern "C" int mxl_relattn_bwd_fused(const void* q, const void* k, const void* v
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    {
+    const bool delta_ready = (defer_finish & 2) != 0;       // the caller has filled `delta` (mxl_gemm_bf16_headdot)
+    defer_finish &= 1;
+    if (!delta_ready) {
         mxl_kt::Scope kt(MXL_KT_RELATTN_DELTA, s);
         hipLaunchKernelGGL(fused_delta_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, B, T,
                            H, o_bs, o_rs);

@@ -496,15 +496,25 @@ def _phantom_ws(B, T, H, device):
     return buf
 
 
+def gemm_headdot(a, b, c, M, N, K, o, T, delta, lda=None, ldb=None, ldc=None, ldo=None):
+    """c = a @ b^T (bf16) and delta[(b_, h, t)] = sum_e c[m, 64 h + e] * o[m, 64 h + e] in the same launch (mxl_gemm_bf16_headdot).
+    Returns True when delta was written; False when the problem is not the four-wave large-tile kernel's (c is written either way)."""
+    rc = lib().mxl_gemm_bf16_headdot(_p(a), _p(b), _p(c), M, N, K, lda or K, ldb or K, ldc or N, _p(o), ldo or N, T, _p(delta), _stream())
+    if rc == -2:      # MXL_EUNSUPPORTED: not the four-wave kernel's problem (c is written, delta is not)
+        return False
+    check(rc, 'mxl_gemm_bf16_headdot')
+    return True
+
+
 def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq, dk, dv, d_rd, d_rwb, d_rrb, ws, qr_buf, *,
                       B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                      scale=None, oph=None, mph=None, defer_drd=False, ph_buf=None, ph_ready=False):
+                      scale=None, oph=None, mph=None, defer_drd=False, ph_buf=None, ph_ready=False, delta_ready=False):
     """Backward of relattn_fwd in one pass over the score cells (mxl_relattn_bwd_fused): dq, dk, dv written, d_rd (M, H*dh) f32 /
     d_rwb / d_rrb accumulated.  With zero memories (Kc < M + T) `oph` / `mph` must come from relattn_fwd(..., oph_all=True), and
     the phantom cells' part of d_rd is added by mxl_relattn_drd_phantom from per-tile records (`ph_buf`,
     mxl_relattn_drd_phantom_ws_bytes bytes; ph_ready: relattn_fwd(..., ph_buf=) has filled them, otherwise
     mxl_relattn_drd_phantom_prep does; without `ph_buf` one scratch per shape is cached; `qr_buf` is no longer used by this path);
-    their part of d_rrb comes out of the dq finishing kernel."""
+    their part of d_rrb comes out of the dq finishing kernel.  delta_ready: `delta` was filled by gemm_headdot."""
     scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     d = H * dh
     # (the slab sum on a side stream beside the phantom cells' dRd kernel measured 7.16 ms against 7.12 ms in sequence -- the HBM-bound
@@ -512,7 +522,7 @@ def relattn_bwd_fused(q, k, v, rd, r_w_bias, r_r_bias, out, dout, lse, delta, dq
     check(lib().mxl_relattn_bwd_fused(_p(q), _p(k), _p(v), _p(rd), _p(r_w_bias), _p(r_r_bias), _p(out), _p(dout), _p(lse), _p(delta),
                                       _p(dq), _p(dk), _p(dv), _p(d_rd), d_rd.stride(0), _p(d_rwb), _p(d_rrb), _p(oph), _p(mph), _p(ws),
                                       B, T, H, dh, M, Kc, q_bs, q_rs, kv_bs, kv_rs, rd_rs, o_bs, o_rs, dq_bs, dq_rs, dkv_bs, dkv_rs,
-                                      float(scale), 0, _stream()), 'mxl_relattn_bwd_fused')
+                                      float(scale), 2 if delta_ready else 0, _stream()), 'mxl_relattn_bwd_fused')
 
     def phantom():
         if Kc < M + T:

@@ -9,6 +9,7 @@ loss = mean over non-zero per-token NLLs.  Internal layout is batch-major (B, T,
 Precision: bf16 storage / MFMA operands with fp32 accumulation; fp32 master weights, gradients and Adam moments.
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -626,7 +627,12 @@ class XLEngine:
             # now dA = grad into h_in via residual, dB = grad into o_net output
             ops.gemm(ws.dB, ws.av[l], gw(l, 'dec_attn.o_net.weight'), d, d, N, trans_a=True, trans_b=True, flags=AT,
                      ksplits=self._ks(d, d, N))
-            ops.gemm(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d)   # d attn_vec
+            # d attn_vec; on the fused attention backward its row term delta = sum_e d attn_vec . attn_vec rides in the same launch
+            delta_ready = False
+            if ws.fused_bwd and not os.environ.get('MXL_HEADDOT_OFF'):
+                delta_ready = ops.gemm_headdot(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d, ws.av[l], T, ws.delta)
+            else:
+                ops.gemm(ws.dB, self._lwt(l, 'dec_attn.o_net.weight'), ws.dC, N, d, d)
             qkv, dqkv = ws.qkv[l], ws.dqkv
             ws.d_rd.zero_()
             if ws.fused_bwd:
@@ -637,7 +643,8 @@ class XLEngine:
                                       dq_bs=Kc * 3 * d, dq_rs=3 * d, dkv_bs=Kc * 3 * d, dkv_rs=3 * d,
                                       oph=ws.oph[l].view(B, T, d) if ws.oph is not None else None,
                                       mph=ws.mph[l] if ws.oph is not None else None,
-                                      ph_buf=ws.ph[l] if ws.ph is not None else None, ph_ready=ws.ph is not None, **st)
+                                      ph_buf=ws.ph[l] if ws.ph is not None else None, ph_ready=ws.ph is not None,
+                                      delta_ready=delta_ready, **st)
             else:
                 ops.relattn_bwd(qkv[:, Kc - T:, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], ws.rd[l],
                                 self._lw(l, 'dec_attn.r_w_bias', self.P), self._lw(l, 'dec_attn.r_r_bias', self.P), ws.av[l],

@@ -461,8 +461,7 @@ def test_gemm_large_tile(dev, M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M,N,K,reserve', [(256, 256, 64, 0), (512, 768, 128, 0), (2048, 2304, 768, 0), (256 * 70, 512, 192, 128),
-                                           (256 * 9, 256, 3072, 120)])
+@pytest.mark.parametrize('M,N,K,reserve', [(16384, 1024, 64, 0), (16384, 1024, 192, 128), (65536, 768, 128, 0), (16384, 1024, 3072, 0)])
 def test_gemm_four_wave_kernel_equals_eight_wave_kernel(dev, monkeypatch, M, N, K, reserve):
     """gemm_nt256w4_kernel (plain and bias epilogues at interior shapes: four waves of 128 x 128, accumulators pinned in a[0:255])
     against gemm_nt256_kernel on the same problem: the same products accumulated in the same order, so BIT-identical outputs --
@@ -480,7 +479,9 @@ def test_gemm_four_wave_kernel_equals_eight_wave_kernel(dev, monkeypatch, M, N, 
             monkeypatch.setenv('MXL_GEMM_W4', form)
             y = torch.empty(M, N, device=dev, dtype=torch.bfloat16); yb = torch.empty_like(y)
             ops.gemm(x, w, y, M, N, K)
+            assert ops.lib().mxl_gemm_last_nt_kernel() == (3 if form == '1' else 1)         # the shapes are the four-wave kernel's
             ops.gemm(x, w, yb, M, N, K, flags=ops.GEMM_BIAS, bias=b)
+            assert ops.lib().mxl_gemm_last_nt_kernel() == (3 if form == '1' else 1)
             for _ in range(3):
                 y2 = torch.empty_like(y)
                 ops.gemm(x, w, y2, M, N, K)
@@ -490,6 +491,32 @@ def test_gemm_four_wave_kernel_equals_eight_wave_kernel(dev, monkeypatch, M, N, 
         assert rel_err(outs['1'][0].float(), ref) < 6e-3 and rel_err(outs['1'][1].float(), ref + b) < 6e-3
     finally:
         ops.check(ops.lib().mxl_set_reserved_cus(0), 'mxl_set_reserved_cus')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,H,K', [(8, 2048, 16, 128), (64, 256, 16, 64), (32, 2048, 12, 768), (3, 256, 4, 128), (2, 384, 8, 64)])
+def test_gemm_headdot_equals_gemm_plus_delta_pass(dev, B, T, H, K):
+    """mxl_gemm_bf16_headdot: the product is the plain GEMM's bit for bit, and delta[b, h, t] = sum_e C[m, 64 h + e] O[m, 64 h + e]
+    from the bf16 values it stores -- against torch on those values (the attention backward's row term, formed inside the GEMM that
+    produces d attn_vec instead of by a pass over both matrices); shapes the four-wave kernel does not take are refused with the
+    product written"""
+    from symbolic_music_generation_amd import ops
+    torch.manual_seed(B * T + H)
+    M, N = B * T, H * 64
+    x, w, o = bf(torch.randn(M, K) * 0.5).to(dev), bf(torch.randn(N, K) * 0.5).to(dev), bf(torch.randn(M, N)).to(dev)
+    y0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); y1 = torch.empty_like(y0)
+    delta = torch.full((B, H, T), float('nan'), device=dev)
+    ops.gemm(x, w, y0, M, N, K)
+    took = ops.gemm_headdot(x, w, y1, M, N, K, o, T, delta)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if B >= 8:
+        assert took and ops.lib().mxl_gemm_last_nt_kernel() == 3
+        ref = (y0.float() * o.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1)
+        assert not torch.isnan(delta).any()
+        assert (delta - ref).abs().max().item() <= 1e-5 * (y0.float().abs() * o.float().abs()).view(B, T, H, 64).sum(-1).max().item()
+    else:
+        assert not took and torch.isnan(delta).all()
 
 
 @pytest.mark.gpu
