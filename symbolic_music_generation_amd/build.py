@@ -23,7 +23,13 @@ FLAGS += ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # AMDGPU-specific register-pressure trackers in the machine scheduler: A/B on the attention backward 2.27 -> 2.17 ms per layer,
 # whole C3 step +1.9 % (max-ilp / max-memory-clause strategies and the occupancy bias measured neutral or worse).
 FLAGS += ['-mllvm', '-amdgpu-use-amdgpu-trackers']
-EXTRA_FLAGS = {}
+# per translation unit.  relattn_fwd.hip: the max-ilp strategy of the machine scheduler, -1 % on the forward kernel over six alternating
+# same-box runs (1.605 -> 1.589 ms; iterative-ilp -0.4 %, max-memory-clause +0.2 %); on the fused backward the same flag is within noise
+# (profiles/r06_fused_bwd_setprio_ab.log, r06_fwd_setprio_ab.log)
+# reformer.hip: the same flag, chunk-attention forward 172 -> 169 us, query-owner backward 264 -> 243 us, key-owner 360 -> 357 us per
+# launch at C4, the leg +0.5 % (4.850 / 4.817 -> 4.869 / 4.850 M tok/s alternating; profiles/r06_rf_ab2_max_ilp.log).  Not for the
+# phantom dRd kernel (0.659 -> 0.664 ms).
+EXTRA_FLAGS = {'relattn_fwd.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'], 'reformer.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 
 
 def _newer(src, dst, deps):
