@@ -53,6 +53,10 @@ def lib():
             raise MusicXLError(
                 f'{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc, gfx950). '
                 'There is no CPU / PyTorch fallback for the product path.')
+        # torch first: it ships its own libamdhip64, and the library must bind to THAT copy of the HIP runtime -- loaded before torch it
+        # pulls in /opt/rocm's, the process then holds two runtimes, and every call through the second one fails with
+        # hipErrorNoDevice (seen with __graft_entry__.build() followed by smoke() in one process)
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in declared_functions().items():
             fn = getattr(_lib, name)  # AttributeError if the header declares something the .so lacks
