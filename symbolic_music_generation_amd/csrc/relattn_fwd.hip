@@ -143,9 +143,11 @@ __device__ unsigned long long g_fwd_stamps[16];
 #endif
 
 #ifndef FWD_PRIO
-#define FWD_PRIO 4                              // s_setprio(1) around MFMA clusters: bit 0 G / S chains of the tile loop, bit 1 P V, bit 2 the phantom loop's chains and
-                                                // value-sum products.  Only bit 2 pays: 1.630 -> 1.600 ms per layer (-1.8 %, four alternating same-box rounds,
-                                                // profiles/r06_fwd_setprio_ab.log); bits 0 and 1 move nothing (1.636 / 1.631)
+#define FWD_PRIO 6                              // s_setprio(1) around MFMA clusters: bit 0 G / S chains of the tile loop, bit 1 P V, bit 2 the phantom loop's chains and
+                                                // value-sum products.  Bit 2 pays by itself: 1.630 -> 1.600 ms per layer (-1.8 %, four alternating same-box rounds,
+                                                // profiles/r06_fwd_setprio_ab.log); bits 0 and 1 alone move nothing (1.636 / 1.631).  Under the max-ilp scheduling
+                                                // strategy this unit is built with (build.py) bits 1 + 2 read another -1.0 % (1.625 -> 1.609 over ten alternating runs),
+                                                // bit 0 costs 2 % there
 #endif
 #define FPRIO_UP(bit_) do { if (FWD_PRIO & (bit_)) __builtin_amdgcn_s_setprio(1); } while (0)
 #define FPRIO_DOWN(bit_) do { if (FWD_PRIO & (bit_)) __builtin_amdgcn_s_setprio(0); } while (0)
