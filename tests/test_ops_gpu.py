@@ -494,7 +494,7 @@ def test_gemm_four_wave_kernel_equals_eight_wave_kernel(dev, monkeypatch, M, N, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,T,H,K', [(8, 2048, 16, 128), (64, 256, 16, 64), (32, 2048, 12, 768), (3, 256, 4, 128), (2, 384, 8, 64)])
+@pytest.mark.parametrize('B,T,H,K', [(8, 2048, 16, 128), (64, 256, 16, 64), (64, 384, 16, 64), (32, 2048, 12, 768), (3, 256, 4, 128), (2, 384, 8, 64)])
 def test_gemm_headdot_equals_gemm_plus_delta_pass(dev, B, T, H, K):
     """mxl_gemm_bf16_headdot: the product is the plain GEMM's bit for bit, and delta[b, h, t] = sum_e C[m, 64 h + e] O[m, 64 h + e]
     from the bf16 values it stores -- against torch on those values (the attention backward's row term, formed inside the GEMM that
